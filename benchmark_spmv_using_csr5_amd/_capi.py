@@ -1,0 +1,102 @@
+"""ctypes binding of libcsr5hip.so -- the C ABI declared in include/csr5hip.h.
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded, importing the product
+path raises.  Build it with ``python -c 'import __graft_entry__ as g; g.build()'`` or
+``make -C benchmark_spmv_using_csr5_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsr5hip.so")
+
+SUCCESS = 0
+UNKOWN_FORMAT = -1
+UNSUPPORTED_CSR5_OMEGA = -2
+CSR_TO_CSR5_FAILED = -3
+UNSUPPORTED_CSR_SPMV = -4
+UNSUPPORTED_VALUE_TYPE = -5
+HIP_ERROR = -100
+INVALID_ARGUMENT = -101
+
+FORMAT_CSR = 0
+FORMAT_CSR5 = 1
+OMEGA = 64
+AUTO_TUNED_SIGMA = -1
+F64 = 0
+F32 = 1
+OPT_SPMV_MODE = 1
+OPT_XCD_REMAP = 2
+
+
+class Csr5Info(C.Structure):
+    _fields_ = [
+        ("format", C.c_int), ("m", C.c_int), ("n", C.c_int), ("nnz", C.c_int),
+        ("value_type", C.c_int), ("omega", C.c_int), ("sigma", C.c_int),
+        ("bit_y_offset", C.c_int), ("bit_scansum_offset", C.c_int), ("num_packet", C.c_int),
+        ("p", C.c_int), ("tail_partition_start", C.c_int), ("num_offsets", C.c_int),
+        ("d_tile_ptr", C.c_void_p), ("d_tile_desc", C.c_void_p),
+        ("d_offset_ptr", C.c_void_p), ("d_offset", C.c_void_p),
+        ("t_malloc_ms", C.c_double), ("t_tile_ptr_ms", C.c_double),
+        ("t_tile_desc_ms", C.c_double), ("t_transpose_ms", C.c_double),
+    ]
+
+
+# every symbol include/csr5hip.h declares: (name, restype, argtypes)
+_H = C.c_void_p
+SYMBOLS = [
+    ("csr5hip_create", C.c_int, [C.POINTER(_H), C.c_int, C.c_int, C.c_int]),
+    ("csr5hip_free", C.c_int, [_H]),
+    ("csr5hip_set_stream", C.c_int, [_H, C.c_void_p]),
+    ("csr5hip_warmup", C.c_int, [_H]),
+    ("csr5hip_input_csr", C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csr5hip_set_x", C.c_int, [_H, C.c_void_p]),
+    ("csr5hip_set_sigma", C.c_int, [_H, C.c_int]),
+    ("csr5hip_as_csr5", C.c_int, [_H]),
+    ("csr5hip_as_csr", C.c_int, [_H]),
+    ("csr5hip_spmv", C.c_int, [_H, C.c_double, C.c_void_p]),
+    ("csr5hip_spmv_repeat", C.c_int, [_H, C.c_double, C.c_void_p, C.c_int]),
+    ("csr5hip_destroy", C.c_int, [_H]),
+    ("csr5hip_set_option", C.c_int, [_H, C.c_int, C.c_int]),
+    ("csr5hip_get_info", C.c_int, [_H, C.POINTER(Csr5Info)]),
+    ("csr5hip_auto_sigma", C.c_int, [C.c_int, C.c_int, C.c_int]),
+    ("csr5hip_last_error", C.c_char_p, []),
+    ("csr5hip_version", C.c_char_p, []),
+    ("csr5hip_device_count", C.c_int, [C.POINTER(C.c_int)]),
+    ("csr5hip_set_device", C.c_int, [C.c_int]),
+    ("csr5hip_device_name", C.c_int, [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double)]),
+    ("csr5hip_malloc", C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    ("csr5hip_device_free", C.c_int, [C.c_void_p]),
+    ("csr5hip_memcpy_h2d", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("csr5hip_memcpy_d2h", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    ("csr5hip_memset", C.c_int, [C.c_void_p, C.c_int, C.c_size_t]),
+    ("csr5hip_synchronize", C.c_int, []),
+    ("csr5hip_timer_start", C.c_int, [_H]),
+    ("csr5hip_timer_stop", C.c_int, [_H, C.POINTER(C.c_double)]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libcsr5hip.so (once).  Raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the CSR5 HIP extension is not built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().csr5hip_last_error().decode()

@@ -1,0 +1,524 @@
+// csr5_capi.hip -- the extern "C" boundary of libcsr5hip.so (declared in include/csr5hip.h).
+//
+// State machine and ownership follow the reference handle (CSR5_cuda/anonymouslib_cuda.h):
+//   inputCSR borrows the caller's device CSR arrays and sets _format = CSR          (:61-76)
+//   asCSR5   builds tile_ptr / tile_desc / offsets and transposes col/val IN PLACE  (:105-220)
+//   spmv     returns UNSUPPORTED_CSR_SPMV (-4) while the format is CSR              (:262-284)
+//   asCSR / destroy undo the transpose and drop the CSR5 arrays                     (:78-102, :286-291)
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+
+#include "csr5_internal.h"
+
+using namespace csr5;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail_hip(hipError_t e, const char *what)
+{
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return CSR5HIP_HIP_ERROR;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail_hip(e_, #expr);                                                            \
+    } while (0)
+
+struct Buffer {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap)
+            return hipSuccess;
+        if (ptr) {
+            hipError_t e = hipFree(ptr);
+            if (e != hipSuccess)
+                return e;
+            ptr = nullptr;
+            cap = 0;
+        }
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e == hipSuccess)
+            cap = bytes;
+        return e;
+    }
+    void release()
+    {
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        cap = 0;
+    }
+};
+
+struct GraphKey {
+    void *y;
+    int count;
+    int mode;
+    bool operator==(const GraphKey &o) const { return y == o.y && count == o.count && mode == o.mode; }
+};
+struct GraphKeyHash {
+    size_t operator()(const GraphKey &k) const
+    {
+        return std::hash<void *>()(k.y) ^ (size_t)k.count * 1000003u ^ (size_t)k.mode * 7919u;
+    }
+};
+
+double now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+struct csr5hip_handle_s {
+    int format = -1; // uninitialised until inputCSR, as in the reference
+    int value_type = CSR5HIP_F64;
+    Geometry g{};
+    int sigma_request = 0; // what setSigma stored (resolved value, >= 1)
+    int num_offsets = 0;
+    hipStream_t stream = nullptr;
+    const void *x = nullptr;
+    DeviceArrays d{};
+    SpmvOptions opt{0, 1};
+    Buffer b_tile_ptr, b_tile_desc, b_offset_ptr, b_offset, b_calibrator, b_acc, b_cnt, b_meta;
+    double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::unordered_map<GraphKey, hipGraphExec_t, GraphKeyHash> graphs;
+
+    size_t vsize() const { return value_type == CSR5HIP_F64 ? 8 : 4; }
+    void drop_graphs()
+    {
+        for (auto &kv : graphs)
+            (void)hipGraphExecDestroy(kv.second);
+        graphs.clear();
+    }
+};
+
+extern "C" {
+
+const char *csr5hip_last_error(void) { return g_last_error.c_str(); }
+const char *csr5hip_version(void) { return "csr5hip 0.1 (gfx950, omega=64)"; }
+
+int csr5hip_create(csr5hip_handle *out, int m, int n, int value_type)
+{
+    if (!out || m < 0 || n < 0)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (value_type != CSR5HIP_F64 && value_type != CSR5HIP_F32)
+        return CSR5HIP_UNSUPPORTED_VALUE_TYPE;
+    csr5hip_handle h = new csr5hip_handle_s();
+    h->g.m = m;
+    h->g.n = n;
+    h->value_type = value_type;
+    *out = h;
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_free(csr5hip_handle h)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    h->drop_graphs();
+    for (Buffer *b : {&h->b_tile_ptr, &h->b_tile_desc, &h->b_offset_ptr, &h->b_offset,
+                      &h->b_calibrator, &h->b_acc, &h->b_cnt, &h->b_meta})
+        b->release();
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    delete h;
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_set_stream(csr5hip_handle h, void *hip_stream)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    h->stream = (hipStream_t)hip_stream;
+    h->drop_graphs();
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_warmup(csr5hip_handle h)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    HIP_TRY(launch_warmup(h->stream));
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_input_csr(csr5hip_handle h, int nnz, int32_t *d_row_ptr, int32_t *d_col_idx, void *d_val)
+{
+    if (!h || nnz < 0)
+        return CSR5HIP_INVALID_ARGUMENT;
+    h->format = CSR5HIP_FORMAT_CSR;
+    h->g.nnz = nnz;
+    h->d.row_ptr = d_row_ptr;
+    h->d.col = d_col_idx;
+    h->d.val = d_val;
+    h->drop_graphs();
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_set_x(csr5hip_handle h, const void *d_x)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    h->x = d_x;
+    h->drop_graphs();
+    return CSR5HIP_SUCCESS;
+}
+
+// gfx950 table in the shape of the reference's (r, s, t, u) rule (anonymouslib_cuda.h:297-313):
+// k = nnz/m; sigma = r if k <= r; k if k <= s; s if k <= t; else u.
+int csr5hip_auto_sigma(int m, int nnz, int value_type)
+{
+    (void)value_type;
+    const int r = 4, s = 16, t = 256, u = 16;
+    const int k = m > 0 ? nnz / m : 0;
+    if (k <= r) return r;
+    if (k <= s) return k;
+    if (k <= t) return s;
+    return u;
+}
+
+int csr5hip_set_sigma(csr5hip_handle h, int sigma)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (sigma == CSR5HIP_AUTO_TUNED_SIGMA)
+        sigma = csr5hip_auto_sigma(h->g.m, h->g.nnz, h->value_type);
+    if (sigma < CSR5HIP_MIN_SIGMA || sigma > CSR5HIP_MAX_SIGMA)
+        return CSR5HIP_INVALID_ARGUMENT;
+    h->sigma_request = sigma;
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_set_option(csr5hip_handle h, int option, int value)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    switch (option) {
+    case CSR5HIP_OPT_SPMV_MODE:
+        if (value != 0 && value != 1)
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->opt.mode = value;
+        break;
+    case CSR5HIP_OPT_XCD_REMAP:
+        h->opt.xcd_remap = value ? 1 : 0;
+        break;
+    default:
+        return CSR5HIP_INVALID_ARGUMENT;
+    }
+    h->drop_graphs();
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_as_csr5(csr5hip_handle h)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (h->format == CSR5HIP_FORMAT_CSR5)
+        return CSR5HIP_SUCCESS;
+    if (h->format != CSR5HIP_FORMAT_CSR)
+        return CSR5HIP_UNKOWN_FORMAT;
+    if (h->sigma_request < CSR5HIP_MIN_SIGMA)
+        h->sigma_request = csr5hip_auto_sigma(h->g.m, h->g.nnz, h->value_type);
+
+    Geometry &g = h->g;
+    g.sigma = h->sigma_request;
+    g.bit_y = bit_y_of(g.sigma);
+    g.bit_all = g.bit_y + BIT_SS;
+    if (g.bit_all > 31) // the first flag must sit in the first packet (anonymouslib_cuda.h:130)
+        return CSR5HIP_UNSUPPORTED_CSR5_OMEGA;
+    g.num_packet = num_packet_of(g.sigma);
+    g.tile_elems = OMEGA * g.sigma;
+    g.p = (int)(((long long)g.nnz + g.tile_elems - 1) / g.tile_elems);
+    g.tail_start = g.m;
+    h->num_offsets = 0;
+    h->t_malloc = h->t_tile_ptr = h->t_tile_desc = h->t_transpose = 0;
+    h->drop_graphs();
+    hipStream_t s = h->stream;
+
+    double t0 = now_ms();
+    const size_t p1 = (size_t)g.p + 1;
+    const size_t desc_words = (size_t)(g.p > 0 ? g.p : 1) * OMEGA * g.num_packet;
+    HIP_TRY(h->b_tile_ptr.reserve(p1 * 4));
+    HIP_TRY(h->b_tile_desc.reserve(desc_words * 4));
+    HIP_TRY(h->b_offset_ptr.reserve(p1 * 4));
+    HIP_TRY(h->b_calibrator.reserve(p1 * h->vsize()));
+    HIP_TRY(h->b_acc.reserve(p1 * h->vsize()));
+    HIP_TRY(h->b_cnt.reserve(p1 * 4));
+    HIP_TRY(h->b_meta.reserve(2 * p1 * 4));
+    h->d.tile_ptr = (uint32_t *)h->b_tile_ptr.ptr;
+    h->d.tile_desc = (uint32_t *)h->b_tile_desc.ptr;
+    h->d.offset_ptr = (int32_t *)h->b_offset_ptr.ptr;
+    h->d.calibrator = h->b_calibrator.ptr;
+    h->d.carry_acc = h->b_acc.ptr;
+    h->d.carry_cnt = (uint32_t *)h->b_cnt.ptr;
+    h->d.carry_meta = (uint32_t *)h->b_meta.ptr;
+    h->d.offset = nullptr;
+    HIP_TRY(hipMemsetAsync(h->d.tile_desc, 0, desc_words * 4, s));
+    HIP_TRY(hipMemsetAsync(h->d.offset_ptr, 0, p1 * 4, s));
+    HIP_TRY(hipMemsetAsync(h->d.calibrator, 0, p1 * h->vsize(), s));
+    HIP_TRY(hipMemsetAsync(h->d.carry_acc, 0, p1 * h->vsize(), s));
+    HIP_TRY(hipMemsetAsync(h->d.carry_cnt, 0, p1 * 4, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    h->t_malloc += now_ms() - t0;
+
+    if (g.p > 0) {
+        // step 1: tile_ptr (+ empty-row marks) -- flag scatter shares the row pass
+        t0 = now_ms();
+        HIP_TRY(launch_tile_ptr(g, h->d, s));
+        HIP_TRY(launch_row_scan(g, h->d, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        h->t_tile_ptr += now_ms() - t0;
+
+        // step 2: tile_desc, offset_ptr scan; two 4-byte reads as in the reference
+        // (anonymouslib_cuda.h:165-167, format_cuda.h:331-343), issued together
+        t0 = now_ms();
+        HIP_TRY(launch_tile_desc(g, h->d, s));
+        HIP_TRY(launch_offset_scan(g, h->d, s));
+        uint32_t tail_word = 0;
+        int32_t num_offsets = 0;
+        HIP_TRY(hipMemcpyAsync(&tail_word, h->d.tile_ptr + (g.p - 1), 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(&num_offsets, h->d.offset_ptr + g.p, 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        g.tail_start = (int)(tail_word & ROW_MASK);
+        h->num_offsets = num_offsets;
+        h->t_tile_desc += now_ms() - t0;
+
+        if (num_offsets > 0) {
+            t0 = now_ms();
+            HIP_TRY(h->b_offset.reserve((size_t)num_offsets * 4));
+            h->d.offset = (int32_t *)h->b_offset.ptr;
+            h->t_malloc += now_ms() - t0;
+            t0 = now_ms();
+            HIP_TRY(launch_desc_offset(g, h->d, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            h->t_tile_desc += now_ms() - t0;
+        }
+
+        // step 3: in-place tile transpose of column_index and value
+        t0 = now_ms();
+        HIP_TRY(launch_transpose(g, h->d, h->value_type, true, s));
+        HIP_TRY(launch_carry_meta(g, h->d, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        h->t_transpose += now_ms() - t0;
+    }
+    h->format = CSR5HIP_FORMAT_CSR5;
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_as_csr(csr5hip_handle h)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (h->format == CSR5HIP_FORMAT_CSR)
+        return CSR5HIP_SUCCESS;
+    if (h->format != CSR5HIP_FORMAT_CSR5)
+        return CSR5HIP_UNKOWN_FORMAT;
+    h->drop_graphs();
+    HIP_TRY(launch_transpose(h->g, h->d, h->value_type, false, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    // the aux buffers stay cached in the handle (capacity only grows) until csr5hip_free
+    h->format = CSR5HIP_FORMAT_CSR;
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_destroy(csr5hip_handle h) { return csr5hip_as_csr(h); }
+
+int csr5hip_spmv(csr5hip_handle h, double alpha, void *d_y)
+{
+    (void)alpha; // accepted, not applied: csr5_spmv_cuda.h:22 ("// * alpha")
+    if (!h || !d_y)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (h->format == CSR5HIP_FORMAT_CSR)
+        return CSR5HIP_UNSUPPORTED_CSR_SPMV;
+    if (h->format != CSR5HIP_FORMAT_CSR5)
+        return CSR5HIP_UNKOWN_FORMAT;
+    if (!h->x)
+        return CSR5HIP_INVALID_ARGUMENT;
+    HIP_TRY(launch_spmv(h->g, h->d, h->value_type, h->x, d_y, h->opt, h->stream));
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count)
+{
+    if (!h || !d_y || count < 0)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (h->format == CSR5HIP_FORMAT_CSR)
+        return CSR5HIP_UNSUPPORTED_CSR_SPMV;
+    if (h->format != CSR5HIP_FORMAT_CSR5)
+        return CSR5HIP_UNKOWN_FORMAT;
+    if (count == 0)
+        return CSR5HIP_SUCCESS;
+    GraphKey key{d_y, count, h->opt.mode};
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+        // capture on a private stream so the caller's stream state is untouched
+        hipStream_t cs = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        int rc = CSR5HIP_SUCCESS;
+        if (e == hipSuccess) {
+            for (int i = 0; i < count && e == hipSuccess; i++)
+                e = launch_spmv(h->g, h->d, h->value_type, h->x, d_y, h->opt, cs);
+            hipError_t e2 = hipStreamEndCapture(cs, &graph);
+            if (e == hipSuccess)
+                e = e2;
+        }
+        hipGraphExec_t exec = nullptr;
+        if (e == hipSuccess)
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph)
+            (void)hipGraphDestroy(graph);
+        (void)hipStreamDestroy(cs);
+        if (e != hipSuccess)
+            rc = fail_hip(e, "hipGraph capture of spmv");
+        if (rc != CSR5HIP_SUCCESS)
+            return rc;
+        if (h->graphs.size() >= 8)
+            h->drop_graphs();
+        it = h->graphs.emplace(key, exec).first;
+    }
+    HIP_TRY(hipGraphLaunch(it->second, h->stream));
+    (void)alpha;
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
+{
+    if (!h || !info)
+        return CSR5HIP_INVALID_ARGUMENT;
+    memset(info, 0, sizeof(*info));
+    info->format = h->format;
+    info->m = h->g.m;
+    info->n = h->g.n;
+    info->nnz = h->g.nnz;
+    info->value_type = h->value_type;
+    info->omega = OMEGA;
+    info->sigma = h->format == CSR5HIP_FORMAT_CSR5 ? h->g.sigma : h->sigma_request;
+    if (h->format == CSR5HIP_FORMAT_CSR5) {
+        info->bit_y_offset = h->g.bit_y;
+        info->bit_scansum_offset = BIT_SS;
+        info->num_packet = h->g.num_packet;
+        info->p = h->g.p;
+        info->tail_partition_start = h->g.tail_start;
+        info->num_offsets = h->num_offsets;
+        info->d_tile_ptr = h->d.tile_ptr;
+        info->d_tile_desc = h->d.tile_desc;
+        info->d_offset_ptr = h->d.offset_ptr;
+        info->d_offset = h->d.offset;
+    }
+    info->t_malloc_ms = h->t_malloc;
+    info->t_tile_ptr_ms = h->t_tile_ptr;
+    info->t_tile_desc_ms = h->t_tile_desc;
+    info->t_transpose_ms = h->t_transpose;
+    return CSR5HIP_SUCCESS;
+}
+
+// ---- device shims ---------------------------------------------------------------------------
+int csr5hip_device_count(int *count)
+{
+    if (!count)
+        return CSR5HIP_INVALID_ARGUMENT;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail_hip(e, "hipGetDeviceCount");
+    }
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_set_device(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_device_name(int device, char *buf, size_t buflen, double *clock_mhz)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (buf && buflen) {
+        strncpy(buf, prop.name, buflen - 1);
+        buf[buflen - 1] = 0;
+    }
+    if (clock_mhz)
+        *clock_mhz = prop.clockRate * 1e-3;
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_malloc(void **dptr, size_t bytes)
+{
+    if (!dptr)
+        return CSR5HIP_INVALID_ARGUMENT;
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 4));
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_device_free(void *dptr)
+{
+    HIP_TRY(hipFree(dptr));
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_memcpy_h2d(void *dst, const void *src, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_memcpy_d2h(void *dst, const void *src, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_memset(void *dptr, int value, size_t bytes)
+{
+    HIP_TRY(hipMemset(dptr, value, bytes));
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_synchronize(void)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_timer_start(csr5hip_handle h)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (!h->ev0) {
+        HIP_TRY(hipEventCreate(&h->ev0));
+        HIP_TRY(hipEventCreate(&h->ev1));
+    }
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_timer_stop(csr5hip_handle h, double *ms)
+{
+    if (!h || !ms || !h->ev0)
+        return CSR5HIP_INVALID_ARGUMENT;
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    float f = 0;
+    HIP_TRY(hipEventElapsedTime(&f, h->ev0, h->ev1));
+    *ms = f;
+    return CSR5HIP_SUCCESS;
+}
+
+} // extern "C"

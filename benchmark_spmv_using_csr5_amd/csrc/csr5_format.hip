@@ -1,0 +1,384 @@
+// csr5_format.hip -- CSR -> CSR5 conversion kernels for gfx950 (wave64), written from scratch.
+//
+// What is computed is fixed by the reference (bit-exact tile_ptr / tile_desc / offsets, checked against
+// goldens produced by the reference's own format code at omega = 64); HOW is ours:
+//
+//   reference step (CSR5_cuda/detail/cuda/format_cuda.h)           here
+//   ------------------------------------------------------------   --------------------------------------
+//   K1 generate_partition_pointer_s1  :21-41   thread / tile       k_tile_ptr        thread / tile
+//   K2 generate_partition_pointer_s2  :43-95   block / tile,       k_row_scan        thread / ROW: an empty row
+//      loops over the tile's rows                                    with pointer e marks tile (e-1)/T; no loop
+//   K4 generate_partition_descriptor_s1 :129-159 thread / row      (same kernel)     flag scatter, tiles < p-1 only
+//   K5 generate_partition_descriptor_s2 :161-267 warp / tile,      k_tile_desc       wave / tile: popcounts, DPP-free
+//      LDS scan + serial look-ahead loop                             shfl scan, ballot + ctz for scansum_offset
+//   K6 generate_partition_descriptor_s3 :269-300 1 block           k_offset_scan     1 block, wave-shuffle scan
+//   K7 generate_partition_descriptor_offset :362-523               k_desc_offset     wave / flagged tile
+//   K8 aosoa_transpose_kernel_smem      :525-744 block / tile,     k_transpose       block / tile, col_idx AND value
+//      two launches (col, val), 29 sigma instantiations              in one launch, runtime sigma, padded LDS
+#include "csr5_internal.h"
+
+namespace csr5 {
+
+// number of entries of a[0..size) that are <= key (the reference's
+// binary_search_right_boundary_kernel, utils_cuda.h:25-53, restated as a half-open bisection)
+__device__ __forceinline__ int upper_bound(const int32_t *__restrict__ a, int key, int size)
+{
+    int lo = 0, hi = size;
+    while (lo < hi) {
+        int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (a[mid] <= key)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: tile_ptr[t] = (last row r in [0, m] with row_ptr[r] <= min(t*T, nnz)),  t in [0, p]
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_tile_ptr(Geometry g, const int32_t *__restrict__ row_ptr,
+                                                    uint32_t *__restrict__ tile_ptr)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t > g.p)
+        return;
+    long long b = (long long)t * g.tile_elems;
+    int boundary = b > g.nnz ? g.nnz : (int)b;
+    tile_ptr[t] = (uint32_t)(upper_bound(row_ptr, boundary, g.m + 1) - 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2 + K4 fused, one thread per row r < m, reading row_ptr once:
+//  * bit flag of the row's first element e = row_ptr[r] (tiles 0..p-2 only; the last tile is
+//    processed from CSR and its descriptor stays zero, as in CSR5_avx2 format_avx2.h:98);
+//  * an EMPTY row with e > 0 lies in the row range [tile_ptr[t], tile_ptr[t+1]) of exactly one
+//    tile, t = (e-1)/T  (tile_ptr[t] is the last row with pointer <= t*T, so r > tile_ptr[t] iff
+//    e > t*T, and r < tile_ptr[t+1] iff e <= (t+1)*T); leading empty rows (e == 0) precede every
+//    tile.  That replaces the reference's per-tile row loop by one atomicOr.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_row_scan(Geometry g, const int32_t *__restrict__ row_ptr,
+                                                    uint32_t *__restrict__ tile_ptr,
+                                                    uint32_t *__restrict__ tile_desc)
+{
+    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= g.m)
+        return;
+    const int e = row_ptr[r];
+    const int e1 = row_ptr[r + 1];
+    const int T = g.tile_elems;
+    const int tile = e / T;
+    if (tile < g.p - 1) {
+        const int lane = (e / g.sigma) % OMEGA;
+        const int gbit = e % g.sigma + g.bit_all;
+        const size_t loc = (size_t)tile * OMEGA * g.num_packet + (size_t)(gbit >> 5) * OMEGA + lane;
+        atomicOr(&tile_desc[loc], 1u << (31 - (gbit & 31)));
+    }
+    if (e == e1 && e > 0)
+        atomicOr(&tile_ptr[(e - 1) / T], 0x80000000u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: one wavefront per tile t < p-1.  Lane l owns elements [l*sigma, (l+1)*sigma) of the tile.
+//   segn  = number of segments (rows) that start in the lane
+//   y_off = exclusive wave prefix of segn, minus one for lanes > 0 (index into y_local)
+//   ss    = number of directly following lanes without any flag (scansum_offset)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_tile_desc(Geometry g, const uint32_t *__restrict__ tile_ptr,
+                                                     uint32_t *__restrict__ tile_desc,
+                                                     int32_t *__restrict__ offset_ptr)
+{
+    const int lane = threadIdx.x & (OMEGA - 1);
+    const int t = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (t >= g.p - 1)
+        return;
+    const uint32_t raw = tile_ptr[t];
+    const uint32_t row_start = raw & ROW_MASK;
+    const uint32_t row_stop = tile_ptr[t + 1] & ROW_MASK;
+    if (row_start == row_stop) // fast-track tile keeps only its raw flags (format_cuda.h:187-189)
+        return;
+
+    uint32_t *d = tile_desc + (size_t)t * OMEGA * g.num_packet;
+    uint32_t w0 = d[lane];
+    // all flags of the lane, MSB first (element i -> bit 31-i); sigma <= 32 so one word holds them
+    uint32_t flags = w0 << g.bit_all;
+    if (g.num_packet > 1)
+        flags |= d[OMEGA + lane] >> (32 - g.bit_all);
+
+    const int f0 = (int)(flags >> 31) | (lane == 0);
+    const int stop = __popc(flags & 0x7FFFFFFFu);
+    const int present = f0 | (stop > 0);
+    int segn = stop - !f0 + present;
+    segn = segn > 0 ? segn : 0;
+
+    int incl = segn; // inclusive wave scan
+#pragma unroll
+    for (int d_ = 1; d_ < OMEGA; d_ <<= 1) {
+        int v = __shfl_up(incl, d_, OMEGA);
+        if (lane >= d_)
+            incl += v;
+    }
+    if ((raw >> 31) && lane == OMEGA - 1)
+        offset_ptr[t] = incl; // segments of this tile; scanned into offsets by k_offset_scan
+    const int y_off = lane ? incl - segn - 1 : 0;
+
+    const unsigned long long pmask = __ballot(present);
+    int ss = 0;
+    if (present) {
+        const unsigned long long rest = lane == OMEGA - 1 ? 0ull : pmask >> (lane + 1);
+        ss = rest ? __builtin_ctzll(rest) : OMEGA - 1 - lane;
+    }
+    w0 |= (uint32_t)y_off << (32 - g.bit_y);
+    w0 |= (uint32_t)ss << (32 - g.bit_all);
+    d[lane] = w0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6: exclusive scan of offset_ptr[0..p] in place, single workgroup (p+1 <= a few 10^5 entries).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_offset_scan(int32_t *__restrict__ a, int n)
+{
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    if (tid == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int v = i < n ? a[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int u = __shfl_up(incl, d, 64);
+            if (lane >= d)
+                incl += u;
+        }
+        if (lane == 63)
+            wave_tot[wave] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int w = 0; w < wave; w++)
+            wave_off += wave_tot[w];
+        const int carry = carry_s;
+        if (i < n)
+            a[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (tid == 1023)
+            carry_s = carry + wave_off + incl;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7: tiles whose tile_ptr carries bit 31: the k-th store slot of the tile gets the row index
+// (relative to row_start+1) of the segment that starts there.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_desc_offset(Geometry g, const int32_t *__restrict__ row_ptr,
+                                                       const uint32_t *__restrict__ tile_ptr,
+                                                       const uint32_t *__restrict__ tile_desc,
+                                                       const int32_t *__restrict__ offset_ptr,
+                                                       int32_t *__restrict__ offset)
+{
+    const int lane = threadIdx.x & (OMEGA - 1);
+    const int t = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (t >= g.p - 1)
+        return;
+    const uint32_t raw = tile_ptr[t];
+    if (!(raw >> 31))
+        return;
+    const int row_start = (int)(raw & ROW_MASK);
+    const int row_stop = (int)(tile_ptr[t + 1] & ROW_MASK);
+    const uint32_t *d = tile_desc + (size_t)t * OMEGA * g.num_packet;
+    const uint32_t w0 = d[lane];
+    uint32_t flags = w0 << g.bit_all;
+    if (g.num_packet > 1)
+        flags |= d[OMEGA + lane] >> (32 - g.bit_all);
+    if (lane == 0)
+        flags &= 0x7FFFFFFFu; // lane 0's first element never owns a store slot (format_cuda.h:391-399)
+    int slot = offset_ptr[t] + (int)(w0 >> (32 - g.bit_y));
+    const int32_t *rows = row_ptr + row_start + 1;
+    const int nrows = row_stop - row_start;
+    const int elem0 = t * g.tile_elems + lane * g.sigma;
+    while (flags) {
+        const int i = __builtin_clz(flags);
+        flags &= ~(0x80000000u >> i);
+        offset[slot++] = upper_bound(rows, elem0 + i, nrows) - 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8: in-place sigma x omega tile transpose of column_index AND value, one workgroup per tile.
+// r2c: element (lane l, step i) moves from l*sigma+i to i*omega+l; !r2c is the inverse.
+// LDS rows are padded by one element so both passes are bank-conflict free.
+// ---------------------------------------------------------------------------------------------
+template <typename VT>
+__global__ void __launch_bounds__(BLOCK) k_transpose(Geometry g, const uint32_t *__restrict__ tile_ptr,
+                                                     int32_t *__restrict__ col, VT *__restrict__ val,
+                                                     int r2c)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = blockIdx.x;
+    // fast-track tiles are not transposed; the test is on the RAW words (format_cuda.h:540)
+    if (tile_ptr[t] == tile_ptr[t + 1])
+        return;
+    const int T = g.tile_elems;
+    const int sigma = g.sigma;
+    VT *sv = reinterpret_cast<VT *>(smem);
+    int32_t *sc = reinterpret_cast<int32_t *>(smem + (size_t)sigma * (OMEGA + 1) * sizeof(VT));
+    const size_t base = (size_t)t * T;
+    for (int idx = threadIdx.x; idx < T; idx += BLOCK) {
+        int i, l;
+        if (r2c) { i = idx % sigma; l = idx / sigma; }
+        else     { l = idx & (OMEGA - 1); i = idx >> 6; }
+        sc[i * (OMEGA + 1) + l] = col[base + idx];
+        sv[i * (OMEGA + 1) + l] = val[base + idx];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < T; idx += BLOCK) {
+        int i, l;
+        if (r2c) { l = idx & (OMEGA - 1); i = idx >> 6; }
+        else     { i = idx % sigma; l = idx / sigma; }
+        col[base + idx] = sc[i * (OMEGA + 1) + l];
+        val[base + idx] = sv[i * (OMEGA + 1) + l];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused-SpMV helper (not part of the reference format): per tile t, who resolves the carries.
+//   A "run" is a maximal range of tiles h..e whose first element lies in the same row r.  All leading
+//   partials of the run, plus the closing partial of tile h-1 when r starts inside h-1, are summed
+//   into slot h and the last arriver stores y[r].
+//   carry_meta[t] bits 0..23  = expected number of arrivals for the run headed by t (0 if t is not a
+//                               run head), saturating is impossible: runs longer than 2^24-2 tiles
+//                               do not fit int32 nnz at sigma >= 1.
+//                 bit  30     = the closing segment of tile t continues into tile t+1 (goes to slot
+//                               t+1 instead of being stored)
+//                 bit  31     = unused
+//   carry_meta[p + t] (int32) = index of the run head of tile t (the slot tile t's leading partial
+//                               arrives at).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_carry_meta(Geometry g, const int32_t *__restrict__ row_ptr,
+                                                      const uint32_t *__restrict__ tile_ptr,
+                                                      uint32_t *__restrict__ carry_meta)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= g.p)
+        return;
+    const int T = g.tile_elems;
+    const int r = (int)(tile_ptr[t] & ROW_MASK);
+    uint32_t meta = 0;
+    const bool head = t == 0 || (int)(tile_ptr[t - 1] & ROW_MASK) != r;
+    if (head) {
+        int32_t *head_of = reinterpret_cast<int32_t *>(carry_meta + g.p);
+        int e = t;
+        head_of[t] = t;
+        while (e + 1 < g.p && (int)(tile_ptr[e + 1] & ROW_MASK) == r) {
+            e++;
+            head_of[e] = t;
+        }
+        uint32_t expected = (uint32_t)(e - t + 1);
+        if ((long long)row_ptr[r] != (long long)t * T)
+            expected += 1; // row r starts inside tile t-1, whose closing segment also arrives
+        meta |= expected;
+    }
+    if (t + 1 < g.p) {
+        const int rn = (int)(tile_ptr[t + 1] & ROW_MASK);
+        // the closing segment of tile t belongs to row rn iff rn starts before (t+1)*T
+        if ((long long)row_ptr[rn] != (long long)(t + 1) * T)
+            meta |= 1u << 30;
+    }
+    carry_meta[t] = meta;
+}
+
+__global__ void k_warmup(int *out)
+{
+    __shared__ int s[OMEGA];
+    s[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    int v = 0;
+    for (int i = 0; i < 50; i++)
+        v += s[(threadIdx.x + i) & (OMEGA - 1)];
+    if (v == -1)
+        out[0] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
+
+hipError_t launch_tile_ptr(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_tile_ptr, dim3(div_up(g.p + 1, BLOCK)), dim3(BLOCK), 0, s, g, d.row_ptr,
+                       d.tile_ptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_row_scan(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+{
+    if (g.m <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_row_scan, dim3(div_up(g.m, BLOCK)), dim3(BLOCK), 0, s, g, d.row_ptr,
+                       d.tile_ptr, d.tile_desc);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_desc(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+{
+    if (g.p <= 1)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_tile_desc, dim3(div_up(g.p - 1, WAVES_PER_BLOCK)), dim3(BLOCK), 0, s, g,
+                       d.tile_ptr, d.tile_desc, d.offset_ptr);
+    return hipGetLastError();
+}
+
+hipError_t launch_offset_scan(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_offset_scan, dim3(1), dim3(1024), 0, s, d.offset_ptr, g.p + 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_desc_offset(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+{
+    if (g.p <= 1)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_desc_offset, dim3(div_up(g.p - 1, WAVES_PER_BLOCK)), dim3(BLOCK), 0, s, g,
+                       d.row_ptr, d.tile_ptr, d.tile_desc, d.offset_ptr, d.offset);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c,
+                            hipStream_t s)
+{
+    if (g.p <= 1)
+        return hipSuccess;
+    const size_t vsz = value_type == CSR5HIP_F64 ? 8 : 4;
+    const size_t lds = (size_t)g.sigma * (OMEGA + 1) * (vsz + 4);
+    if (value_type == CSR5HIP_F64)
+        hipLaunchKernelGGL(k_transpose<double>, dim3(g.p - 1), dim3(BLOCK), lds, s, g, d.tile_ptr,
+                           d.col, (double *)d.val, r2c ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_transpose<float>, dim3(g.p - 1), dim3(BLOCK), lds, s, g, d.tile_ptr,
+                           d.col, (float *)d.val, r2c ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+{
+    if (g.p <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_carry_meta, dim3(div_up(g.p, BLOCK)), dim3(BLOCK), 0, s, g, d.row_ptr,
+                       d.tile_ptr, d.carry_meta);
+    return hipGetLastError();
+}
+
+hipError_t launch_warmup(hipStream_t s)
+{
+    hipLaunchKernelGGL(k_warmup, dim3(4000), dim3(OMEGA), 0, s, (int *)nullptr);
+    return hipGetLastError();
+}
+
+} // namespace csr5

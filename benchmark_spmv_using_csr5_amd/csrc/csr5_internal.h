@@ -1,0 +1,73 @@
+// csr5_internal.h -- shared declarations of libcsr5hip.so (gfx950 only; not a public header).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "csr5hip.h"
+
+namespace csr5 {
+
+constexpr int OMEGA = CSR5HIP_OMEGA;          // one wavefront per tile
+constexpr int WAVES_PER_BLOCK = 4;            // 256-thread workgroups
+constexpr int BLOCK = OMEGA * WAVES_PER_BLOCK;
+constexpr int BIT_SS = 6;                     // bits of scansum_offset at omega = 64
+constexpr uint32_t ROW_MASK = 0x7FFFFFFFu;    // tile_ptr bit 31 = "tile has empty rows"
+constexpr int NUM_XCD = 8;
+
+// bits of y_offset for a given sigma: smallest b >= 1 with 2^b >= omega*sigma
+// (anonymouslib_cuda.h:121-124)
+constexpr int bit_y_of(int sigma)
+{
+    int base = 2, b = 1;
+    while (base < OMEGA * sigma) { base *= 2; b++; }
+    return b;
+}
+constexpr int num_packet_of(int sigma) { return (bit_y_of(sigma) + BIT_SS + sigma + 31) / 32; }
+
+// Geometry of one converted matrix; passed by value to every kernel.
+struct Geometry {
+    int m, n, nnz;
+    int sigma;
+    int bit_y, bit_all, num_packet;
+    int p;            // number of tiles, the last one (p-1) is the CSR tail
+    int tile_elems;   // omega * sigma
+    int tail_start;   // first row of the tail tile
+};
+
+// Device arrays of the CSR5 format plus our own launch helpers.
+struct DeviceArrays {
+    const int32_t *row_ptr;
+    int32_t *col;
+    void *val;
+    uint32_t *tile_ptr;     // [p+1]
+    uint32_t *tile_desc;    // [p*omega*num_packet]
+    int32_t *offset_ptr;    // [p+1]
+    int32_t *offset;        // [num_offsets]
+    void *calibrator;       // [p] of vT: leading partial of every tile (tail = slot p-1)
+    // fused mode only (not part of the reference format): per-run accumulator and arrival counter
+    void *carry_acc;        // [p] of vT, all zero between launches
+    uint32_t *carry_cnt;    // [p], all zero between launches
+    uint32_t *carry_meta;   // [p] per tile: see csr5_spmv.hip
+};
+
+// ---- conversion (csr5_format.hip) ----
+hipError_t launch_tile_ptr(const Geometry &g, const DeviceArrays &d, hipStream_t s);
+hipError_t launch_row_scan(const Geometry &g, const DeviceArrays &d, hipStream_t s);
+hipError_t launch_tile_desc(const Geometry &g, const DeviceArrays &d, hipStream_t s);
+hipError_t launch_offset_scan(const Geometry &g, const DeviceArrays &d, hipStream_t s);
+hipError_t launch_desc_offset(const Geometry &g, const DeviceArrays &d, hipStream_t s);
+hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c,
+                            hipStream_t s);
+hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream_t s);
+hipError_t launch_warmup(hipStream_t s);
+
+// ---- SpMV (csr5_spmv.hip) ----
+struct SpmvOptions {
+    int mode;        // CSR5HIP_OPT_SPMV_MODE
+    int xcd_remap;   // CSR5HIP_OPT_XCD_REMAP
+};
+hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
+                       void *y, const SpmvOptions &opt, hipStream_t s);
+
+} // namespace csr5

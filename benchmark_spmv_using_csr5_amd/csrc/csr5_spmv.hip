@@ -1,0 +1,346 @@
+// csr5_spmv.hip -- CSR5 SpMV for gfx950 (wave64), written from scratch.
+//
+// Reference decomposition (CSR5_cuda/detail/cuda/csr5_spmv_cuda.h):
+//   K9  spmv_csr5_compute_kernel        :275-311   warp / tile, calibrator[tile]
+//   K10 spmv_csr5_calibrate_kernel      :313-382   y[tile_ptr[t]] += calibrator[t], atomics at block edges
+//   K11 spmv_csr5_tail_partition_kernel :384-419   one 32-thread block per tail ROW
+// i.e. three dependent launches per SpMV and a y that the caller must have zeroed.
+//
+// Here (one wavefront = one tile, omega = 64):
+//   two-pass mode : k_spmv<.., false>  tiles AND the CSR tail in ONE launch (tail rows are handled by extra
+//                   workgroups of the same grid), then k_calibrate resolves the carries in tile order
+//                   (bit-reproducible, overwrite semantics, y need not be zeroed).
+//   fused mode    : k_spmv<.., true>   single launch.  Every cross-tile partial "arrives" at the slot of the
+//                   first tile of its row run through a device-scope atomic add + arrival counter; the
+//                   last arriver stores y and re-arms the slot.  No spinning, no launch boundary.
+// Lane-local work walks the bit flags held in ONE 32-bit register (sigma <= 32), the cross-lane step
+// is a flag-propagating backward segmented scan over the 64 lanes (no prefix-sum difference, so no
+// cancellation), tile_ptr words are scalar loads, column_index/value loads are fully coalesced
+// 256-B / 512-B wave accesses thanks to the tile transpose.
+#include "csr5_internal.h"
+
+#include <type_traits>
+
+namespace csr5 {
+
+template <typename VT>
+__device__ __forceinline__ VT wave_sum(VT v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d, OMEGA);
+    return v;
+}
+
+// ---- fused-mode carry protocol ------------------------------------------------------------------
+// Slot h (= first tile of a run of tiles that begin inside the same row r) collects every partial of
+// row r that is cut by a tile boundary.  All accesses to acc/cnt are device-scope atomics, so they
+// are performed at the memory side and are coherent across the 8 XCD L2s.  The RETURNING add on acc
+// is waited for (its result feeds an asm barrier) before the counter is bumped, so when the counter
+// reaches `expected` every add has been performed; the last arriver swaps the total out (re-arming
+// the slot for the next launch) and is the only writer of y[r].
+template <typename VT>
+__device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, const uint32_t *meta,
+                                             const uint32_t *tile_ptr, int slot, VT v, VT *y)
+{
+    VT old = __hip_atomic_fetch_add(&acc[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // order: the add must have been performed before the arrival is counted
+    asm volatile("" ::"v"(old) : "memory");
+    const uint32_t arrived =
+        __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const uint32_t expected = meta[slot] & 0x00FFFFFFu;
+    if (arrived == expected) {
+        using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
+        const bits_t raw = __hip_atomic_exchange(reinterpret_cast<bits_t *>(&acc[slot]), (bits_t)0,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        VT total;
+        __builtin_memcpy(&total, &raw, sizeof(VT));
+        __hip_atomic_store(&cnt[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y[tile_ptr[slot] & ROW_MASK] = total;
+    }
+}
+
+// ---- CSR tail tile: rows tail_start..m-1, non-zeros from (p-1)*T, untransposed -------------------
+// One thread per row; rows longer than 16 are summed by the whole wave (the tail holds < T non-zeros
+// in total, but may span any number of - mostly empty - rows).  The first row's partial is a carry.
+template <typename VT, bool FUSED>
+__device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__restrict__ row_ptr,
+                                          const int32_t *__restrict__ col,
+                                          const VT *__restrict__ val, const VT *__restrict__ x,
+                                          VT *__restrict__ calibrator, VT *__restrict__ y,
+                                          int tail_block, VT *acc, uint32_t *cnt,
+                                          const uint32_t *meta, const int32_t *head,
+                                          const uint32_t *tile_ptr)
+{
+    const int lane = threadIdx.x & (OMEGA - 1);
+    const int r = g.tail_start + tail_block * BLOCK + (int)threadIdx.x;
+    const int first_tail = (g.p - 1) * g.tile_elems;
+    const bool valid = r < g.m;
+    int a = 0, b = 0;
+    if (valid) {
+        a = r == g.tail_start ? first_tail : row_ptr[r];
+        b = row_ptr[r + 1];
+    }
+    const bool longrow = valid && (b - a) > 16;
+    VT sum = 0;
+    if (valid && !longrow)
+        for (int k = a; k < b; k++)
+            sum += val[k] * x[col[k]];
+    unsigned long long todo = __ballot(longrow);
+    while (todo) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int aa = __shfl(a, src, OMEGA);
+        const int bb = __shfl(b, src, OMEGA);
+        VT s = 0;
+        for (int k = aa + lane; k < bb; k += OMEGA)
+            s += val[k] * x[col[k]];
+        s = wave_sum(s);
+        if (lane == src)
+            sum = s;
+    }
+    if (!valid)
+        return;
+    if (r == g.tail_start) {
+        if constexpr (FUSED)
+            carry_arrive(acc, cnt, meta, tile_ptr, head[g.p - 1], sum, y);
+        else
+            calibrator[g.p - 1] = sum;
+    } else {
+        y[r] = sum;
+    }
+}
+
+// ---- tiles 0..p-2 ------------------------------------------------------------------------------
+// SIGMA > 0: compile-time sigma (loads hoisted into registers, flag walk fully unrolled).
+// SIGMA == 0: run-time sigma (any 1..32), same code shape, used for sigma < 4 and as a cross-check.
+template <typename VT, int SIGMA, bool FUSED>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+       const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
+       const uint32_t *__restrict__ tile_desc, const int32_t *__restrict__ offset_ptr,
+       const int32_t *__restrict__ offset, VT *__restrict__ calibrator, VT *__restrict__ y,
+       int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint32_t *meta,
+       const int32_t *head)
+{
+    int blk = blockIdx.x;
+    if (blk >= tile_blocks) {
+        tail_rows<VT, FUSED>(g, row_ptr, col, val, x, calibrator, y, blk - tile_blocks, acc, cnt,
+                             meta, head, tile_ptr);
+        return;
+    }
+    if (xcd_remap) {
+        // workgroup b runs on XCD b % 8 (observed dispatch order; used for L2 locality only):
+        // give every XCD one contiguous range of tiles instead of every 8th workgroup.
+        const int q = tile_blocks / NUM_XCD, rem = tile_blocks % NUM_XCD;
+        const int xcd = blk % NUM_XCD;
+        blk = xcd * q + (xcd < rem ? xcd : rem) + blk / NUM_XCD;
+    }
+    const int lane = threadIdx.x & (OMEGA - 1);
+    const int t = __builtin_amdgcn_readfirstlane(blk * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6));
+    if (t >= g.p - 1)
+        return;
+
+    const int sigma = SIGMA > 0 ? SIGMA : g.sigma;
+    const int bit_y = SIGMA > 0 ? bit_y_of(SIGMA > 0 ? SIGMA : 1) : g.bit_y;
+    const int bit_all = bit_y + BIT_SS;
+    const int num_packet = SIGMA > 0 ? num_packet_of(SIGMA > 0 ? SIGMA : 1) : g.num_packet;
+    const int T = OMEGA * sigma;
+
+    const uint32_t rs_raw = tile_ptr[t];
+    const uint32_t row_stop = tile_ptr[t + 1] & ROW_MASK;
+    const size_t base = (size_t)t * T + lane;
+    const int32_t *ct = col + base;
+    const VT *vt = val + base;
+
+    // products of this lane's sigma elements (coalesced: lane stride 1 at every step)
+    constexpr int NREG = SIGMA > 0 ? SIGMA : 1;
+    VT prod[NREG];
+    if constexpr (SIGMA > 0) {
+        int32_t c[NREG];
+        VT v[NREG];
+#pragma unroll
+        for (int i = 0; i < SIGMA; i++) {
+            c[i] = ct[i * OMEGA];
+            v[i] = vt[i * OMEGA];
+        }
+#pragma unroll
+        for (int i = 0; i < SIGMA; i++)
+            prod[i] = v[i] * x[c[i]];
+    }
+    auto product = [&](int i) -> VT {
+        if constexpr (SIGMA > 0)
+            return prod[i];
+        else
+            return vt[i * OMEGA] * x[ct[i * OMEGA]];
+    };
+
+    if (rs_raw == row_stop) {
+        // fast track: the whole tile lies inside one row (csr5_spmv_cuda.h:59-90)
+        VT s = 0;
+#pragma unroll
+        for (int i = 0; i < sigma; i++)
+            s += product(i);
+        s = wave_sum(s);
+        if (lane == 0) {
+            if constexpr (FUSED)
+                carry_arrive(acc, cnt, meta, tile_ptr, head[t], s, y);
+            else
+                calibrator[t] = s;
+        }
+        return;
+    }
+
+    const bool empty_rows = rs_raw >> 31;
+    const int row_start = (int)(rs_raw & ROW_MASK);
+    VT *y_local = y + row_start + 1;
+    const int32_t *off_local = empty_rows ? offset + offset_ptr[t] : nullptr;
+
+    const uint32_t *d = tile_desc + (size_t)t * OMEGA * num_packet;
+    const uint32_t w0 = d[lane];
+    uint32_t flags = w0 << bit_all; // element i -> bit 31-i
+    if (num_packet > 1)
+        flags |= d[OMEGA + lane] >> (32 - bit_all);
+    int y_off = (int)(w0 >> (32 - bit_y));
+
+    const bool f0 = (flags >> 31) | (lane == 0);
+    bool direct = f0 && lane != 0;
+    VT sum = product(0);
+    VT first_sum = 0;
+#pragma unroll
+    for (int i = 1; i < sigma; i++) {
+        if ((flags >> (31 - i)) & 1u) {
+            if (direct)
+                y_local[empty_rows ? off_local[y_off] : y_off] = sum;
+            else
+                first_sum = sum;
+            y_off += direct;
+            direct = true;
+            sum = 0;
+        }
+        sum += product(i);
+    }
+    if (!direct)
+        first_sum = sum;
+
+    // cross-lane step: every lane that owns a flag adds the leading partials of the lanes behind it,
+    // up to and including the next lane that owns a flag:  S[l] = R[l+1],
+    // R[j] = lead[j] + (present[j] ? 0 : R[j+1])  -- backward segmented scan, 6 shuffle steps.
+    const bool present = f0 | ((flags & 0x7FFFFFFFu) != 0);
+    const unsigned long long pmask = __ballot(present);
+    VT R = f0 ? (VT)0 : first_sum;
+    if (pmask != ~0ull) {
+        const unsigned long long ahead = pmask >> lane;
+        const int dist = ahead ? __builtin_ctzll(ahead) : OMEGA - 1 - lane;
+#pragma unroll
+        for (int k = 1; k < OMEGA; k <<= 1) {
+            const VT up = __shfl_down(R, k, OMEGA);
+            if (dist >= k)
+                R += up;
+        }
+    }
+    VT S = __shfl_down(R, 1, OMEGA);
+    if (lane == OMEGA - 1)
+        S = 0;
+    if (present)
+        sum += S;
+
+    const int last_present = 63 - __builtin_clzll(pmask);
+    bool closing_is_carry = false;
+    if constexpr (FUSED)
+        closing_is_carry = (meta[t] >> 30) & 1u;
+
+    if (direct) {
+        if (FUSED && closing_is_carry && lane == last_present)
+            carry_arrive(acc, cnt, meta, tile_ptr, t + 1, sum, y);
+        else
+            y_local[empty_rows ? off_local[y_off] : y_off] = sum;
+    }
+    if (lane == 0) {
+        const VT leading = direct ? first_sum : sum;
+        if constexpr (FUSED)
+            carry_arrive(acc, cnt, meta, tile_ptr, head[t], leading, y);
+        else
+            calibrator[t] = leading;
+    }
+}
+
+// ---- two-pass mode, second pass: resolve carries in tile order ------------------------------------
+// One thread per run head; the first carry of a row that begins exactly on a tile boundary stores,
+// every other carry adds (CSR5_avx2 csr5_spmv_avx2.h:42-49,284-291 semantics), in increasing tile
+// order so the result is bit-reproducible.
+template <typename VT>
+__global__ void __launch_bounds__(BLOCK)
+k_calibrate(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ tile_ptr,
+            const VT *__restrict__ calibrator, VT *__restrict__ y)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= g.p)
+        return;
+    const int r = (int)(tile_ptr[t] & ROW_MASK);
+    if (t > 0 && (int)(tile_ptr[t - 1] & ROW_MASK) == r)
+        return;
+    if (r >= g.m)
+        return;
+    VT v = calibrator[t];
+    if ((long long)row_ptr[r] != (long long)t * g.tile_elems)
+        v = y[r] + v;
+    for (int k = t + 1; k < g.p && (int)(tile_ptr[k] & ROW_MASK) == r; k++)
+        v += calibrator[k];
+    y[r] = v;
+}
+
+// ---- dispatch ------------------------------------------------------------------------------------
+template <typename VT, int SIGMA, bool FUSED>
+static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
+                             const SpmvOptions &opt, hipStream_t s)
+{
+    const int tile_blocks = g.p > 1 ? (g.p - 1 + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK : 0;
+    const int tail_rows_n = g.m - g.tail_start;
+    const int tail_blocks = tail_rows_n > 0 ? (tail_rows_n + BLOCK - 1) / BLOCK : 0;
+    if (tile_blocks + tail_blocks == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), 0, s,
+                       g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x, d.tile_ptr,
+                       d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, tile_blocks,
+                       opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt, d.carry_meta,
+                       (const int32_t *)(d.carry_meta + g.p));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || FUSED)
+        return e;
+    hipLaunchKernelGGL(k_calibrate<VT>, dim3((g.p + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, g,
+                       d.row_ptr, d.tile_ptr, (const VT *)d.calibrator, (VT *)y);
+    return hipGetLastError();
+}
+
+template <typename VT, bool FUSED>
+static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
+                               const SpmvOptions &opt, hipStream_t s)
+{
+    switch (g.sigma) {
+#define CSR5_CASE(S) \
+    case S: return launch_one<VT, S, FUSED>(g, d, x, y, opt, s);
+        CSR5_CASE(4) CSR5_CASE(5) CSR5_CASE(6) CSR5_CASE(7) CSR5_CASE(8) CSR5_CASE(9) CSR5_CASE(10)
+        CSR5_CASE(11) CSR5_CASE(12) CSR5_CASE(13) CSR5_CASE(14) CSR5_CASE(15) CSR5_CASE(16)
+        CSR5_CASE(17) CSR5_CASE(18) CSR5_CASE(19) CSR5_CASE(20) CSR5_CASE(21) CSR5_CASE(22)
+        CSR5_CASE(23) CSR5_CASE(24) CSR5_CASE(25) CSR5_CASE(26) CSR5_CASE(27) CSR5_CASE(28)
+        CSR5_CASE(29) CSR5_CASE(30) CSR5_CASE(31) CSR5_CASE(32)
+#undef CSR5_CASE
+    default: return launch_one<VT, 0, FUSED>(g, d, x, y, opt, s);
+    }
+}
+
+hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
+                       void *y, const SpmvOptions &opt, hipStream_t s)
+{
+    if (g.p <= 0)
+        return hipSuccess;
+    const bool fused = opt.mode == 1;
+    if (value_type == CSR5HIP_F64)
+        return fused ? launch_sigma<double, true>(g, d, x, y, opt, s)
+                     : launch_sigma<double, false>(g, d, x, y, opt, s);
+    return fused ? launch_sigma<float, true>(g, d, x, y, opt, s)
+                 : launch_sigma<float, false>(g, d, x, y, opt, s);
+}
+
+} // namespace csr5

@@ -1,0 +1,156 @@
+"""Python mirror of the reference's ``anonymouslibHandle<int, unsigned int, VALUE_TYPE>``.
+
+Same member names, argument meaning, state machine and integer return codes as
+CSR5_cuda/anonymouslib_cuda.h:11-53; every call goes straight through the C ABI of libcsr5hip.so
+(include/csr5hip.h).  Arguments are *device* arrays owned by the caller -- here ``torch`` CUDA tensors
+(torch is plumbing for device memory and streams only) or raw integer device pointers.  ``asCSR5``
+permutes the caller's ``col_idx`` / ``val`` tensors in place, exactly as the reference does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+ANONYMOUSLIB_SUCCESS = _capi.SUCCESS
+ANONYMOUSLIB_UNSUPPORTED_CSR5_OMEGA = _capi.UNSUPPORTED_CSR5_OMEGA
+ANONYMOUSLIB_CSR_TO_CSR5_FAILED = _capi.CSR_TO_CSR5_FAILED
+ANONYMOUSLIB_UNSUPPORTED_CSR_SPMV = _capi.UNSUPPORTED_CSR_SPMV
+ANONYMOUSLIB_UNSUPPORTED_VALUE_TYPE = _capi.UNSUPPORTED_VALUE_TYPE
+ANONYMOUSLIB_FORMAT_CSR = _capi.FORMAT_CSR
+ANONYMOUSLIB_FORMAT_CSR5 = _capi.FORMAT_CSR5
+ANONYMOUSLIB_CSR5_OMEGA = _capi.OMEGA
+ANONYMOUSLIB_AUTO_TUNED_SIGMA = _capi.AUTO_TUNED_SIGMA
+
+SPMV_TWO_PASS = 0
+SPMV_FUSED = 1
+
+
+def _ptr(t) -> int:
+    if t is None:
+        return 0
+    if isinstance(t, int):
+        return t
+    return int(t.data_ptr())
+
+
+def _value_type(dtype) -> int:
+    name = str(dtype)
+    if name.endswith("float64"):
+        return _capi.F64
+    if name.endswith("float32"):
+        return _capi.F32
+    raise TypeError(f"unsupported VALUE_TYPE {dtype}: only float64 and float32 "
+                    "(README.md:71 of the reference)")
+
+
+class anonymouslibHandle:
+    """``A = anonymouslibHandle(m, n, dtype)``; then ``inputCSR / setX / setSigma / asCSR5 / spmv /
+    destroy`` as in CSR5_cuda/main.cu:59-104."""
+
+    def __init__(self, m: int, n: int, dtype="float64", stream=None):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        self._vt = _value_type(dtype)
+        err = self._lib.csr5hip_create(C.byref(self._h), int(m), int(n), self._vt)
+        if err:
+            raise RuntimeError(f"csr5hip_create -> {err}")
+        self._keep = {}  # borrowed tensors, kept alive while the handle points at them
+        if stream is not None:
+            self.setStream(stream)
+
+    # -- reference API ------------------------------------------------------------------------
+    def warmup(self) -> int:
+        return self._lib.csr5hip_warmup(self._h)
+
+    def inputCSR(self, nnz: int, csr_row_pointer, csr_column_index, csr_value) -> int:
+        self._keep.update(row_ptr=csr_row_pointer, col=csr_column_index, val=csr_value)
+        return self._lib.csr5hip_input_csr(self._h, int(nnz), _ptr(csr_row_pointer),
+                                           _ptr(csr_column_index), _ptr(csr_value))
+
+    def setX(self, x) -> int:
+        self._keep.update(x=x)
+        return self._lib.csr5hip_set_x(self._h, _ptr(x))
+
+    def setSigma(self, sigma: int) -> int:
+        return self._lib.csr5hip_set_sigma(self._h, int(sigma))
+
+    def asCSR5(self) -> int:
+        return self._lib.csr5hip_as_csr5(self._h)
+
+    def asCSR(self) -> int:
+        return self._lib.csr5hip_as_csr(self._h)
+
+    def spmv(self, alpha, y) -> int:
+        return self._lib.csr5hip_spmv(self._h, float(alpha), _ptr(y))
+
+    def destroy(self) -> int:
+        return self._lib.csr5hip_destroy(self._h)
+
+    # -- additions (documented in include/csr5hip.h) ---------------------------------------------
+    def spmv_repeat(self, alpha, y, count: int) -> int:
+        return self._lib.csr5hip_spmv_repeat(self._h, float(alpha), _ptr(y), int(count))
+
+    def setStream(self, stream) -> int:
+        raw = getattr(stream, "cuda_stream", stream)
+        return self._lib.csr5hip_set_stream(self._h, C.c_void_p(int(raw) if raw else None))
+
+    def setOption(self, option: int, value: int) -> int:
+        return self._lib.csr5hip_set_option(self._h, int(option), int(value))
+
+    def setSpmvMode(self, mode: int) -> int:
+        return self.setOption(_capi.OPT_SPMV_MODE, mode)
+
+    def info(self) -> _capi.Csr5Info:
+        info = _capi.Csr5Info()
+        err = self._lib.csr5hip_get_info(self._h, C.byref(info))
+        if err:
+            raise RuntimeError(f"csr5hip_get_info -> {err}")
+        return info
+
+    def timer_start(self) -> int:
+        return self._lib.csr5hip_timer_start(self._h)
+
+    def timer_stop(self) -> float:
+        ms = C.c_double(0.0)
+        err = self._lib.csr5hip_timer_stop(self._h, C.byref(ms))
+        if err:
+            raise RuntimeError(f"csr5hip_timer_stop -> {err}: {_capi.last_error()}")
+        return ms.value
+
+    def _d2h(self, dptr, count: int, dtype) -> np.ndarray:
+        out = np.empty(count, dtype=dtype)
+        if count:
+            err = self._lib.csr5hip_memcpy_d2h(out.ctypes.data, dptr, out.nbytes)
+            if err:
+                raise RuntimeError(f"csr5hip_memcpy_d2h -> {err}: {_capi.last_error()}")
+        return out
+
+    def csr5_arrays(self) -> dict:
+        """Host copies of the CSR5 auxiliary arrays (for parity tests)."""
+        i = self.info()
+        if i.format != _capi.FORMAT_CSR5:
+            raise RuntimeError("matrix is not in CSR5 format")
+        return dict(
+            sigma=i.sigma, bit_y=i.bit_y_offset, bit_ss=i.bit_scansum_offset,
+            num_packet=i.num_packet, p=i.p, tail_start=i.tail_partition_start,
+            num_offsets=i.num_offsets,
+            tile_ptr=self._d2h(i.d_tile_ptr, i.p + 1, np.uint32),
+            tile_desc=self._d2h(i.d_tile_desc, i.p * i.omega * i.num_packet, np.uint32),
+            offset_ptr=self._d2h(i.d_offset_ptr, i.p + 1, np.int32),
+            offset=self._d2h(i.d_offset, i.num_offsets, np.int32),
+        )
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.csr5hip_free(self._h)
+            self._h = C.c_void_p()
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,130 @@
+/*
+ * csr5hip.h -- C ABI of libcsr5hip.so: CSR -> CSR5 conversion and CSR5 SpMV on MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the reference's `anonymouslibHandle<iT, uiT, vT>` class template
+ * (CSR5_cuda/anonymouslib_cuda.h:11-53, CSR5_avx2/anonymouslib_avx2.h:11-52).  Every entry point below
+ * names the reference member it replaces.  Semantics follow the CUDA variant of the reference: all
+ * matrix/vector pointers are DEVICE pointers that the caller allocates, fills and owns; the handle
+ * borrows them and allocates only the CSR5 auxiliary arrays (anonymouslib_cuda.h:142-151,188).
+ * `include/anonymouslib_hip.h` re-creates the C++ class template on top of this ABI.
+ *
+ * Fixed instantiation: iT = int32_t, uiT = uint32_t (the only one the reference ever uses,
+ * CSR5_cuda/main.cu:59), vT = double or float chosen at create time.  omega = 64 = one wavefront.
+ *
+ * No torch / HIP types appear in the signatures: streams are passed as `void*` (a hipStream_t).
+ */
+#ifndef CSR5HIP_H
+#define CSR5HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* detail/common.h:13-22 (same numeric values) */
+#define CSR5HIP_SUCCESS                   0
+#define CSR5HIP_UNKOWN_FORMAT            (-1)
+#define CSR5HIP_UNSUPPORTED_CSR5_OMEGA   (-2)
+#define CSR5HIP_CSR_TO_CSR5_FAILED       (-3)
+#define CSR5HIP_UNSUPPORTED_CSR_SPMV     (-4)
+#define CSR5HIP_UNSUPPORTED_VALUE_TYPE   (-5)
+/* additions: the reference aborts the process on runtime failures (checkCudaErrors) */
+#define CSR5HIP_HIP_ERROR                (-100)
+#define CSR5HIP_INVALID_ARGUMENT         (-101)
+
+#define CSR5HIP_FORMAT_CSR   0
+#define CSR5HIP_FORMAT_CSR5  1
+
+#define CSR5HIP_OMEGA             64   /* ANONYMOUSLIB_CSR5_OMEGA (detail/cuda/common_cuda.h:11): lanes per tile */
+#define CSR5HIP_AUTO_TUNED_SIGMA (-1)  /* ANONYMOUSLIB_AUTO_TUNED_SIGMA (detail/cuda/common_cuda.h:15) */
+#define CSR5HIP_MIN_SIGMA          1
+#define CSR5HIP_MAX_SIGMA         32   /* the reference instantiates sigma = 4..32 (csr5_spmv_cuda.h:445-540) */
+
+typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
+
+/* csr5hip_set_option keys */
+#define CSR5HIP_OPT_SPMV_MODE   1  /* 0 = two-pass (tiles+tail, then calibrate; bit-reproducible) [default]
+                                      1 = fused single launch (carries resolved in-kernel by the last
+                                          arriving tile through device-scope atomics) */
+#define CSR5HIP_OPT_XCD_REMAP   2  /* 1 = contiguous tile ranges per XCD (default), 0 = round robin */
+
+typedef struct csr5hip_handle_s *csr5hip_handle;
+
+/* Host-visible snapshot of the handle's private state (anonymouslib_cuda.h:27-52). */
+typedef struct csr5hip_info {
+    int format;                 /* _format */
+    int m, n, nnz;              /* _m, _n, _nnz */
+    int value_type;
+    int omega;                  /* 64 */
+    int sigma;                  /* _csr5_sigma */
+    int bit_y_offset;           /* _bit_y_offset */
+    int bit_scansum_offset;     /* _bit_scansum_offset */
+    int num_packet;             /* _num_packet */
+    int p;                      /* _p */
+    int tail_partition_start;   /* _tail_partition_start */
+    int num_offsets;            /* _num_offsets */
+    const uint32_t *d_tile_ptr;    /* _csr5_partition_pointer                  [p+1]                  */
+    const uint32_t *d_tile_desc;   /* _csr5_partition_descriptor               [p*omega*num_packet]   */
+    const int32_t  *d_offset_ptr;  /* _csr5_partition_descriptor_offset_pointer [p+1]                 */
+    const int32_t  *d_offset;      /* _csr5_partition_descriptor_offset        [num_offsets]          */
+    double t_malloc_ms, t_tile_ptr_ms, t_tile_desc_ms, t_transpose_ms; /* asCSR5 phase timers (:211-214) */
+} csr5hip_info;
+
+/* anonymouslibHandle(m, n) -- anonymouslib_cuda.h:15.  Uses the current HIP device. */
+int csr5hip_create(csr5hip_handle *out, int m, int n, int value_type);
+/* Releases the C object (the C++ class has no destructor; callers pair destroy()+scope exit). */
+int csr5hip_free(csr5hip_handle h);
+/* Stream on which conversion and SpMV are enqueued (the reference uses the default stream). */
+int csr5hip_set_stream(csr5hip_handle h, void *hip_stream);
+
+/* warmup() -- anonymouslib_cuda.h:55-59 / format_cuda.h:7-19 */
+int csr5hip_warmup(csr5hip_handle h);
+/* inputCSR(nnz, row_ptr, col_idx, val) -- anonymouslib_cuda.h:61-76; device pointers, borrowed */
+int csr5hip_input_csr(csr5hip_handle h, int nnz, int32_t *d_row_ptr, int32_t *d_col_idx, void *d_val);
+/* setX(x) -- anonymouslib_cuda.h:222-260; device pointer, borrowed */
+int csr5hip_set_x(csr5hip_handle h, const void *d_x);
+/* setSigma(sigma | ANONYMOUSLIB_AUTO_TUNED_SIGMA) -- anonymouslib_cuda.h:294-318 */
+int csr5hip_set_sigma(csr5hip_handle h, int sigma);
+/* asCSR5() -- anonymouslib_cuda.h:105-220: tile_ptr, tile_desc(+offsets), IN-PLACE tile transpose */
+int csr5hip_as_csr5(csr5hip_handle h);
+/* asCSR() -- anonymouslib_cuda.h:78-102: inverse transpose, drop the CSR5 arrays */
+int csr5hip_as_csr(csr5hip_handle h);
+/* spmv(alpha, y) -- anonymouslib_cuda.h:262-284.  Asynchronous on the handle's stream.  As in every
+ * reference backend `alpha` is accepted and NOT applied (csr5_spmv_cuda.h:22): y = A*x.
+ * Every row that owns a non-zero, and every row >= tail_partition_start, is overwritten; other
+ * (empty) rows are left untouched.  Unlike the CUDA variant y need not be zeroed by the caller. */
+int csr5hip_spmv(csr5hip_handle h, double alpha, void *d_y);
+/* `count` back-to-back spmv() calls replayed from one captured hipGraph (the reference CLI's timed
+ * loop, CSR5_cuda/main.cu:96-99, without per-launch host cost). */
+int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count);
+/* destroy() -- anonymouslib_cuda.h:286-291 (== asCSR) */
+int csr5hip_destroy(csr5hip_handle h);
+
+int csr5hip_set_option(csr5hip_handle h, int option, int value);
+int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info);
+/* sigma that setSigma(AUTO) would pick for (m, nnz, value_type) on gfx950 */
+int csr5hip_auto_sigma(int m, int nnz, int value_type);
+const char *csr5hip_last_error(void);
+const char *csr5hip_version(void);
+
+/* ---- device shims so that a plain g++ host program (the ./spmv CLI, CSR5_cuda/main.cu:17-117) can
+ *      allocate and move the caller-owned arrays without including HIP headers ---- */
+int csr5hip_device_count(int *count);
+int csr5hip_set_device(int device);
+int csr5hip_device_name(int device, char *buf, size_t buflen, double *clock_mhz);
+int csr5hip_malloc(void **dptr, size_t bytes);
+int csr5hip_device_free(void *dptr);
+int csr5hip_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int csr5hip_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int csr5hip_memset(void *dptr, int value, size_t bytes);
+int csr5hip_synchronize(void);
+/* event pair on the handle's stream: elapsed device time in ms between the two calls */
+int csr5hip_timer_start(csr5hip_handle h);
+int csr5hip_timer_stop(csr5hip_handle h, double *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSR5HIP_H */

@@ -1,0 +1,222 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): tile_ptr / tile_desc / offsets BIT-EXACT against the reference format
+algorithm at omega = 64; y bit-exact on the reference CLI's integer data, and within 1e-6 relative
+for fp64 on real data (the tolerance is written in each test).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from benchmark_spmv_using_csr5_amd import matrices as M  # noqa: E402
+from benchmark_spmv_using_csr5_amd import handle as H  # noqa: E402
+from tests import zoo  # noqa: E402
+
+DEV = "cuda:0"
+SIGMAS = [4, 5, 7, 12, 16, 17, 24, 32]
+Y_POISON = 777.0
+
+
+def _device_csr(mat, val, dtype):
+    rp = torch.from_numpy(mat.row_ptr.astype(np.int32)).to(DEV)
+    ci = torch.from_numpy(mat.col.astype(np.int32)).to(DEV)
+    va = torch.from_numpy(val.astype(dtype)).to(DEV)
+    return rp, ci, va
+
+
+def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1):
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    rp, ci, va = _device_csr(mat, val, dtype)
+    xd = torch.from_numpy(x.astype(dtype)).to(DEV)
+    yd = torch.full((mat.m,), y0, dtype=tdt, device=DEV)
+    A = H.anonymouslibHandle(mat.m, mat.n, dtype=np.dtype(dtype).name)
+    assert A.inputCSR(mat.nnz, rp, ci, va) == 0
+    assert A.setX(xd) == 0
+    assert A.setSigma(sigma) == 0
+    assert A.setSpmvMode(mode) == 0
+    assert A.spmv(1.0, yd) == H.ANONYMOUSLIB_UNSUPPORTED_CSR_SPMV  # still CSR (anonymouslib_cuda.h:268-271)
+    assert A.asCSR5() == 0
+    arrays = A.csr5_arrays()
+    col_t = ci.cpu().numpy().copy()
+    val_t = va.cpu().numpy().copy()
+    ys = []
+    for _ in range(repeat):
+        yd.fill_(y0)
+        assert A.spmv(1.0, yd) == 0
+        torch.cuda.synchronize()
+        ys.append(yd.cpu().numpy().copy())
+    assert A.destroy() == 0
+    torch.cuda.synchronize()
+    # destroy() == asCSR(): the caller's arrays are back in CSR order (anonymouslib_cuda.h:78-102)
+    assert np.array_equal(ci.cpu().numpy(), mat.col)
+    assert np.array_equal(va.cpu().numpy(), val.astype(dtype))
+    A.close()
+    return arrays, col_t, val_t, ys
+
+
+def _check_format(arrays, col_t, val_t, fmt):
+    """Comparison rules of SURVEY.md section 8(c)."""
+    p = fmt.p
+    assert (arrays["sigma"], arrays["bit_y"], arrays["bit_ss"], arrays["num_packet"], arrays["p"]) == \
+        (fmt.sigma, fmt.bit_y, fmt.bit_ss, fmt.num_packet, fmt.p)
+    if p == 0:
+        return
+    assert arrays["tail_start"] == fmt.tail_start
+    assert arrays["num_offsets"] == fmt.num_offsets
+    a, b = arrays["tile_ptr"].copy(), fmt.tile_ptr.copy()
+    a[p - 1] &= 0x7FFFFFFF  # bit 31 of the last entry: the AVX2 oracle reads past row_ptr there
+    b[p - 1] &= 0x7FFFFFFF
+    assert np.array_equal(a, b), "tile_ptr"
+    n = (p - 1) * fmt.omega * fmt.num_packet
+    assert np.array_equal(arrays["tile_desc"][:n], fmt.tile_desc[:n]), "tile_desc"
+    assert np.array_equal(arrays["offset_ptr"], fmt.offset_ptr), "offset_ptr"
+    written = fmt.offset != -1
+    assert np.array_equal(arrays["offset"][written], fmt.offset[written]), "offset"
+    assert np.array_equal(col_t, fmt.col), "transposed column_index"
+    assert np.array_equal(val_t, fmt.val), "transposed value"
+
+
+def _expected_y(oracle, fmt, mat, x, y0):
+    return oracle.spmv(fmt, mat.row_ptr, x, y0=np.full(mat.m, y0, dtype=fmt.val.dtype))
+
+
+@pytest.mark.parametrize("mode", [H.SPMV_TWO_PASS, H.SPMV_FUSED])
+@pytest.mark.parametrize("sigma", SIGMAS)
+def test_zoo_integer_data_bit_exact(oracle, sigma, mode):
+    """Reference CLI data (rand()%10, main.cu:336-347): every partial sum is exact, so format AND y
+    must be bit-identical to the oracle, including which rows are left untouched."""
+    for mat in zoo.small_zoo():
+        val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=5, mode="int")
+        fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+        arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode)
+        _check_format(arrays, col_t, val_t, fmt)
+        exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+        assert np.array_equal(ys[0], exp), (mat.name, sigma, mode, np.flatnonzero(ys[0] != exp)[:8])
+        # and against the reference CLI's own check, the scalar CSR loop (main.cu:351-363)
+        ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+        nonempty = np.diff(mat.row_ptr) > 0
+        assert np.array_equal(ys[0][nonempty], ref[nonempty]), (mat.name, sigma)
+
+
+@pytest.mark.parametrize("mode", [H.SPMV_TWO_PASS, H.SPMV_FUSED])
+@pytest.mark.parametrize("sigma", [4, 16, 24])
+def test_real_data_fp64_tolerance(oracle, sigma, mode):
+    """fp64 on real-valued data: |y - y_oracle| <= 1e-6 * |y_oracle| on positive data (no
+    cancellation), and <= 1e-12 * sum|a_ij x_j| on signed data."""
+    for mat in zoo.small_zoo():
+        for fill in ("pos", "real"):
+            val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=9, mode=fill)
+            fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+            _, _, _, ys = _run(mat, val, x, sigma, mode, repeat=2)
+            exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+            scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
+            for y in ys:  # second call: the handle re-arms itself, y need not be zeroed
+                if fill == "pos":
+                    assert np.all(np.abs(y - exp) <= 1e-6 * np.abs(exp)), (mat.name, sigma, mode)
+                assert np.all(np.abs(y - exp) <= 1e-12 * np.maximum(scale, 1.0)), (mat.name, sigma, mode)
+            if mode == H.SPMV_TWO_PASS:
+                assert np.array_equal(ys[0], ys[1]), "two-pass mode is bit-reproducible"
+
+
+@pytest.mark.parametrize("mode", [H.SPMV_TWO_PASS, H.SPMV_FUSED])
+def test_fp32_path(oracle, mode):
+    """fp32 instantiation (README.md:71): exact on integer data while row sums < 2^24, and within
+    1e-5 * sum|a x| of the fp32 oracle on real data."""
+    for mat in zoo.small_zoo():
+        for sigma in (4, 16, 20):
+            val, x = M.fill_values(mat.nnz, mat.n, np.float32, seed=3, mode="int")
+            fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+            arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, dtype=np.float32)
+            _check_format(arrays, col_t, val_t, fmt)
+            exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+            assert np.array_equal(ys[0], exp), (mat.name, sigma, mode)
+        val, x = M.fill_values(mat.nnz, mat.n, np.float32, seed=4, mode="real")
+        fmt = oracle.convert(64, 16, mat.m, mat.row_ptr, mat.col, val)
+        _, _, _, ys = _run(mat, val, x, 16, mode, dtype=np.float32)
+        exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+        scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
+        assert np.all(np.abs(ys[0] - exp) <= 1e-5 * np.maximum(scale, 1.0)), mat.name
+
+
+def test_runtime_sigma_kernel_and_small_sigma(oracle):
+    """sigma = 1..3 run on the run-time-sigma kernel (the reference's switch has no such cases)."""
+    for mat in zoo.small_zoo()[:8]:
+        val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=6, mode="int")
+        for sigma in (1, 2, 3):
+            fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+            arrays, col_t, val_t, ys = _run(mat, val, x, sigma, H.SPMV_TWO_PASS)
+            _check_format(arrays, col_t, val_t, fmt)
+            assert np.array_equal(ys[0], _expected_y(oracle, fmt, mat, x, Y_POISON)), (mat.name, sigma)
+
+
+def test_empty_matrix_and_state_machine():
+    mat = zoo.empty_matrix()
+    rp, ci, va = _device_csr(mat, mat.val, np.float64)
+    xd = torch.ones(mat.n, dtype=torch.float64, device=DEV)
+    yd = torch.full((mat.m,), 3.0, dtype=torch.float64, device=DEV)
+    A = H.anonymouslibHandle(mat.m, mat.n)
+    assert A.asCSR5() == -1  # _format not set before inputCSR
+    assert A.inputCSR(0, rp, ci, va) == 0
+    assert A.setX(xd) == 0
+    assert A.setSigma(H.ANONYMOUSLIB_AUTO_TUNED_SIGMA) == 0
+    assert A.asCSR() == 0  # no-op on CSR
+    assert A.asCSR5() == 0
+    assert A.asCSR5() == 0  # no-op on CSR5
+    assert A.spmv(1.0, yd) == 0
+    torch.cuda.synchronize()
+    assert torch.all(yd == 3.0)  # nothing to write
+    assert A.destroy() == 0
+    assert A.setSigma(0) == -101 and A.setSigma(33) == -101
+    A.close()
+
+
+def test_auto_sigma_and_repeat_graph(oracle):
+    mat = M.scircuit_like(scale=0.1)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=8, mode="int")
+    rp, ci, va = _device_csr(mat, val, np.float64)
+    xd = torch.from_numpy(x).to(DEV)
+    yd = torch.zeros(mat.m, dtype=torch.float64, device=DEV)
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    for mode in (H.SPMV_TWO_PASS, H.SPMV_FUSED):
+        A = H.anonymouslibHandle(mat.m, mat.n)
+        A.inputCSR(mat.nnz, rp, ci, va)
+        A.setX(xd)
+        assert A.setSigma(H.ANONYMOUSLIB_AUTO_TUNED_SIGMA) == 0
+        A.setSpmvMode(mode)
+        assert A.asCSR5() == 0
+        assert 4 <= A.info().sigma <= 32
+        yd.fill_(-1.0)
+        assert A.spmv_repeat(1.0, yd, 25) == 0  # 25 captured launches replayed from one hipGraph
+        assert A.spmv_repeat(1.0, yd, 25) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), ref)
+        A.destroy()
+        A.close()
+
+
+def test_full_size_scircuit_properties(oracle):
+    """BASELINE config sizes: size-independent properties -- equality with the scalar CSR loop on
+    integer data (exact), linearity in x, and asCSR5/asCSR round trip."""
+    mat = M.scircuit_like()
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=10, mode="int")
+    _, x2 = M.fill_values(mat.nnz, mat.n, np.float64, seed=11, mode="int")
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    ref2 = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x2)
+    for mode in (H.SPMV_TWO_PASS, H.SPMV_FUSED):
+        for sigma in (H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, 16):
+            _, _, _, ys = _run(mat, val, x, sigma, mode, y0=0.0)
+            assert np.array_equal(ys[0], ref)
+            _, _, _, ys12 = _run(mat, val, x + x2, sigma, mode, y0=0.0)
+            assert np.array_equal(ys12[0], ref + ref2)  # linearity, exact on integer data
+
+
+def test_full_size_webbase_properties(oracle):
+    mat = M.webbase_like()
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=12, mode="int")
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    for mode in (H.SPMV_TWO_PASS, H.SPMV_FUSED):
+        _, _, _, ys = _run(mat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, mode, y0=0.0)
+        assert np.array_equal(ys[0], ref)
