@@ -257,7 +257,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
     HIP_TRY(h->b_calibrator.reserve(p1 * h->vsize()));
     HIP_TRY(h->b_acc.reserve(p1 * h->vsize()));
     HIP_TRY(h->b_cnt.reserve(p1 * 4));
-    HIP_TRY(h->b_meta.reserve(2 * p1 * 4));
+    HIP_TRY(h->b_meta.reserve(p1 * 16));
     h->d.tile_ptr = (uint32_t *)h->b_tile_ptr.ptr;
     h->d.tile_desc = (uint32_t *)h->b_tile_desc.ptr;
     h->d.offset_ptr = (int32_t *)h->b_offset_ptr.ptr;

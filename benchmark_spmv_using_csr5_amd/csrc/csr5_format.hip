@@ -247,50 +247,82 @@ __global__ void __launch_bounds__(BLOCK) k_transpose(Geometry g, const uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused-SpMV helper (not part of the reference format): per tile t, who resolves the carries.
-//   A "run" is a maximal range of tiles h..e whose first element lies in the same row r.  All leading
-//   partials of the run, plus the closing partial of tile h-1 when r starts inside h-1, are summed
-//   into slot h and the last arriver stores y[r].
-//   carry_meta[t] bits 0..23  = expected number of arrivals for the run headed by t (0 if t is not a
-//                               run head), saturating is impossible: runs longer than 2^24-2 tiles
-//                               do not fit int32 nnz at sigma >= 1.
-//                 bit  30     = the closing segment of tile t continues into tile t+1 (goes to slot
-//                               t+1 instead of being stored)
-//                 bit  31     = unused
-//   carry_meta[p + t] (int32) = index of the run head of tile t (the slot tile t's leading partial
-//                               arrives at).
+// Fused-SpMV helper (not part of the reference format): who resolves the partial sums that a tile
+// boundary cuts.  One uint4 per tile t (tail = tile p-1):
+//   .x bits 0..23 : fallback protocol only -- number of arrivals expected at slot t (t = run head)
+//      bit 28 LEAD_SKIP  : the leading partial of tile t is recomputed by tile t-1; do not emit it
+//      bit 29 CLOSE_LOCAL: the closing segment of tile t continues for .z <= 64 elements into tile
+//                          t+1 and ends there; tile t reads those elements itself and stores y
+//      bit 30 CLOSE_CARRY: the closing segment of tile t continues into tile t+1
+//   .y : run head of tile t = slot at which the leading partial of tile t arrives (fallback protocol)
+//   .z : number of elements of tile t+1 that belong to the closing row of tile t (CLOSE_LOCAL)
+// A "run" is a maximal range of tiles h..e whose first element lies in the same row r.  If r starts
+// inside tile h-1, ends inside tile h and spills at most 64 elements ("short spill", the common case
+// for short rows), tile h-1 owns y[r] outright and nothing is communicated.  Otherwise every partial
+// of r arrives at slot h and the last arriver stores y[r] (csr5_spmv.hip carry_arrive).
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK) k_carry_meta(Geometry g, const int32_t *__restrict__ row_ptr,
                                                       const uint32_t *__restrict__ tile_ptr,
-                                                      uint32_t *__restrict__ carry_meta)
+                                                      uint4 *__restrict__ carry_meta)
 {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= g.p)
         return;
-    const int T = g.tile_elems;
+    const long long T = g.tile_elems;
+    // is tile k the head of a short-spill run?  (needs k >= 1)
+    auto short_spill = [&](int k, int *len) -> bool {
+        if (k < 1 || k >= g.p)
+            return false;
+        const int r = (int)(tile_ptr[k] & ROW_MASK);
+        if ((int)(tile_ptr[k - 1] & ROW_MASK) == r)
+            return false; // not a run head
+        if ((long long)row_ptr[r] == (long long)k * T)
+            return false; // row starts on the boundary: nothing spills
+        if (k + 1 < g.p && (int)(tile_ptr[k + 1] & ROW_MASK) == r)
+            return false; // row runs on into tile k+1
+        const long long L = (long long)row_ptr[r + 1] - (long long)k * T;
+        if (L > OMEGA)
+            return false;
+        *len = (int)L;
+        return true;
+    };
     const int r = (int)(tile_ptr[t] & ROW_MASK);
-    uint32_t meta = 0;
+    uint4 meta = make_uint4(0u, (unsigned)t, 0u, 0u);
+    int len = 0;
     const bool head = t == 0 || (int)(tile_ptr[t - 1] & ROW_MASK) != r;
-    if (head) {
-        int32_t *head_of = reinterpret_cast<int32_t *>(carry_meta + g.p);
+    if (short_spill(t, &len)) {
+        meta.x |= 1u << 28;
+    } else if (head && r < g.m) {
         int e = t;
-        head_of[t] = t;
         while (e + 1 < g.p && (int)(tile_ptr[e + 1] & ROW_MASK) == r) {
             e++;
-            head_of[e] = t;
+            reinterpret_cast<unsigned *>(&carry_meta[e])[1] = (unsigned)t; // .y of the run members
         }
-        uint32_t expected = (uint32_t)(e - t + 1);
+        unsigned expected = (unsigned)(e - t + 1);
         if ((long long)row_ptr[r] != (long long)t * T)
             expected += 1; // row r starts inside tile t-1, whose closing segment also arrives
-        meta |= expected;
+        meta.x |= expected;
     }
     if (t + 1 < g.p) {
         const int rn = (int)(tile_ptr[t + 1] & ROW_MASK);
         // the closing segment of tile t belongs to row rn iff rn starts before (t+1)*T
-        if ((long long)row_ptr[rn] != (long long)(t + 1) * T)
-            meta |= 1u << 30;
+        if (rn != r && (long long)row_ptr[rn] != (long long)(t + 1) * T) {
+            meta.x |= 1u << 30;
+            if (short_spill(t + 1, &len)) {
+                meta.x |= 1u << 29;
+                meta.z = (unsigned)len;
+            }
+        }
     }
-    carry_meta[t] = meta;
+    // .y of non-head run members is written by their head's thread; everything else by this one
+    if (head) {
+        carry_meta[t] = meta;
+    } else {
+        unsigned *w = reinterpret_cast<unsigned *>(&carry_meta[t]);
+        w[0] = meta.x;
+        w[2] = meta.z;
+        w[3] = 0u;
+    }
 }
 
 __global__ void k_warmup(int *out)
@@ -371,7 +403,7 @@ hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream
     if (g.p <= 0)
         return hipSuccess;
     hipLaunchKernelGGL(k_carry_meta, dim3(div_up(g.p, BLOCK)), dim3(BLOCK), 0, s, g, d.row_ptr,
-                       d.tile_ptr, d.carry_meta);
+                       d.tile_ptr, reinterpret_cast<uint4 *>(d.carry_meta));
     return hipGetLastError();
 }
 

@@ -48,7 +48,7 @@ struct DeviceArrays {
     // fused mode only (not part of the reference format): per-run accumulator and arrival counter
     void *carry_acc;        // [p] of vT, all zero between launches
     uint32_t *carry_cnt;    // [p], all zero between launches
-    uint32_t *carry_meta;   // [p] per tile: see csr5_spmv.hip
+    uint32_t *carry_meta;   // [p] x uint4 per tile: see k_carry_meta in csr5_format.hip
 };
 
 // ---- conversion (csr5_format.hip) ----

@@ -10,9 +10,12 @@
 //   two-pass mode : k_spmv<.., false>  tiles AND the CSR tail in ONE launch (tail rows are handled by extra
 //                   workgroups of the same grid), then k_calibrate resolves the carries in tile order
 //                   (bit-reproducible, overwrite semantics, y need not be zeroed).
-//   fused mode    : k_spmv<.., true>   single launch.  Every cross-tile partial "arrives" at the slot of the
-//                   first tile of its row run through a device-scope atomic add + arrival counter; the
-//                   last arriver stores y and re-arms the slot.  No spinning, no launch boundary.
+//   fused mode    : k_spmv<.., true>   single launch, no launch boundary, no spinning.  A row that starts in
+//                   tile t and spills <= 64 elements into tile t+1 (the common case) is finished by tile t
+//                   itself, which re-reads those few elements: nothing is communicated.  Longer rows fall
+//                   back to an arrival protocol: every partial "arrives" at the slot of the first tile of
+//                   the row's run (device-scope atomic add + arrival counter); the last arriver stores y
+//                   and re-arms the slot.
 // Lane-local work walks the bit flags held in ONE 32-bit register (sigma <= 32), the cross-lane step
 // is a flag-propagating backward segmented scan over the 64 lanes (no prefix-sum difference, so no
 // cancellation), tile_ptr words are scalar loads, column_index/value loads are fully coalesced
@@ -40,7 +43,7 @@ __device__ __forceinline__ VT wave_sum(VT v)
 // reaches `expected` every add has been performed; the last arriver swaps the total out (re-arming
 // the slot for the next launch) and is the only writer of y[r].
 template <typename VT>
-__device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, const uint32_t *meta,
+__device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, const uint4 *meta,
                                              const uint32_t *tile_ptr, int slot, VT v, VT *y)
 {
     VT old = __hip_atomic_fetch_add(&acc[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -48,7 +51,7 @@ __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, const uint3
     asm volatile("" ::"v"(old) : "memory");
     const uint32_t arrived =
         __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const uint32_t expected = meta[slot] & 0x00FFFFFFu;
+    const uint32_t expected = meta[slot].x & 0x00FFFFFFu;
     if (arrived == expected) {
         using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
         const bits_t raw = __hip_atomic_exchange(reinterpret_cast<bits_t *>(&acc[slot]), (bits_t)0,
@@ -69,8 +72,7 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
                                           const VT *__restrict__ val, const VT *__restrict__ x,
                                           VT *__restrict__ calibrator, VT *__restrict__ y,
                                           int tail_block, VT *acc, uint32_t *cnt,
-                                          const uint32_t *meta, const int32_t *head,
-                                          const uint32_t *tile_ptr)
+                                          const uint4 *meta, const uint32_t *tile_ptr)
 {
     const int lane = threadIdx.x & (OMEGA - 1);
     const int r = g.tail_start + tail_block * BLOCK + (int)threadIdx.x;
@@ -102,10 +104,13 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
     if (!valid)
         return;
     if (r == g.tail_start) {
-        if constexpr (FUSED)
-            carry_arrive(acc, cnt, meta, tile_ptr, head[g.p - 1], sum, y);
-        else
+        if constexpr (FUSED) {
+            const uint4 mt = meta[g.p - 1];
+            if (!((mt.x >> 28) & 1u)) // else tile p-2 already owns this row (short spill)
+                carry_arrive(acc, cnt, meta, tile_ptr, (int)mt.y, sum, y);
+        } else {
             calibrator[g.p - 1] = sum;
+        }
     } else {
         y[r] = sum;
     }
@@ -120,13 +125,12 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
        const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
        const uint32_t *__restrict__ tile_desc, const int32_t *__restrict__ offset_ptr,
        const int32_t *__restrict__ offset, VT *__restrict__ calibrator, VT *__restrict__ y,
-       int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint32_t *meta,
-       const int32_t *head)
+       int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *meta)
 {
     int blk = blockIdx.x;
     if (blk >= tile_blocks) {
         tail_rows<VT, FUSED>(g, row_ptr, col, val, x, calibrator, y, blk - tile_blocks, acc, cnt,
-                             meta, head, tile_ptr);
+                             meta, tile_ptr);
         return;
     }
     if (xcd_remap) {
@@ -152,6 +156,24 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     const size_t base = (size_t)t * T + lane;
     const int32_t *ct = col + base;
     const VT *vt = val + base;
+
+    // fused mode: short spill of this tile's closing row into tile t+1 -- fetch those <= 64
+    // elements now so that their latency overlaps the tile's own loads
+    uint4 mt = make_uint4(0u, 0u, 0u, 0u);
+    VT lead_next = 0;
+    if constexpr (FUSED) {
+        mt = meta[t];
+        if ((mt.x >> 29) & 1u) {
+            const int L = (int)mt.z;
+            if (lane < L) {
+                // tile t+1 is either a transposed tile (element j at (j % sigma)*omega + j / sigma)
+                // or the untransposed CSR tail
+                const size_t nb = (size_t)(t + 1) * T;
+                const size_t pos = (t + 1 == g.p - 1) ? nb + lane : nb + (size_t)(lane % sigma) * OMEGA + lane / sigma;
+                lead_next = val[pos] * x[col[pos]];
+            }
+        }
+    }
 
     // products of this lane's sigma elements (coalesced: lane stride 1 at every step)
     constexpr int NREG = SIGMA > 0 ? SIGMA : 1;
@@ -184,7 +206,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         s = wave_sum(s);
         if (lane == 0) {
             if constexpr (FUSED)
-                carry_arrive(acc, cnt, meta, tile_ptr, head[t], s, y);
+                carry_arrive(acc, cnt, meta, tile_ptr, (int)mt.y, s, y);
             else
                 calibrator[t] = s;
         }
@@ -245,23 +267,29 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     if (present)
         sum += S;
 
-    const int last_present = 63 - __builtin_clzll(pmask);
-    bool closing_is_carry = false;
-    if constexpr (FUSED)
-        closing_is_carry = (meta[t] >> 30) & 1u;
-
-    if (direct) {
-        if (FUSED && closing_is_carry && lane == last_present)
-            carry_arrive(acc, cnt, meta, tile_ptr, t + 1, sum, y);
-        else
+    if constexpr (FUSED) {
+        const bool close_carry = (mt.x >> 30) & 1u;
+        const bool close_local = (mt.x >> 29) & 1u;
+        const bool lead_skip = (mt.x >> 28) & 1u;
+        const int last_present = 63 - __builtin_clzll(pmask);
+        if (close_local) { // wave-uniform: finish the closing row with its short spill into tile t+1
+            const VT spill = wave_sum(lead_next);
+            if (lane == last_present)
+                sum += spill;
+        }
+        if (direct) {
+            if (close_carry && !close_local && lane == last_present)
+                carry_arrive(acc, cnt, meta, tile_ptr, t + 1, sum, y);
+            else
+                y_local[empty_rows ? off_local[y_off] : y_off] = sum;
+        }
+        if (lane == 0 && !lead_skip)
+            carry_arrive(acc, cnt, meta, tile_ptr, (int)mt.y, direct ? first_sum : sum, y);
+    } else {
+        if (direct)
             y_local[empty_rows ? off_local[y_off] : y_off] = sum;
-    }
-    if (lane == 0) {
-        const VT leading = direct ? first_sum : sum;
-        if constexpr (FUSED)
-            carry_arrive(acc, cnt, meta, tile_ptr, head[t], leading, y);
-        else
-            calibrator[t] = leading;
+        if (lane == 0)
+            calibrator[t] = direct ? first_sum : sum;
     }
 }
 
@@ -303,8 +331,8 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
     hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), 0, s,
                        g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x, d.tile_ptr,
                        d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, tile_blocks,
-                       opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt, d.carry_meta,
-                       (const int32_t *)(d.carry_meta + g.p));
+                       opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt,
+                       reinterpret_cast<const uint4 *>(d.carry_meta));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || FUSED)
         return e;

@@ -1,0 +1,304 @@
+// ./spmv <file.mtx> -- the reference benchmark CLI (CSR5_cuda/main.cu, CSR5_avx2/main.cpp) on top of
+// libcsr5hip.so.  Plain host C++ (g++), no HIP headers: device memory goes through the C-ABI shims.
+//
+// Contract kept from the reference (SURVEY.md section 8b "CLI contract"):
+//   * argv[1] is a Matrix Market coordinate file; exit codes -1 cannot open, -2 bad banner,
+//     -3 complex, -4 bad size line (main.cu:135-157);
+//   * symmetric/hermitian files are expanded, CSR keeps file order inside a row, duplicates kept
+//     (main.cu:252-321); the file's VALUES ARE DISCARDED and matrix and x are filled with rand() % 10
+//     (main.cu:330-347) so that every partial sum is exact;
+//   * protocol: 1 correctness run, 50 warm-up runs, NUM_RUN timed runs (main.cu:79-101), y zeroed once;
+//   * same stdout lines in the same order; check |y_ref - y| <= 0.01 |y_ref| per row (main.cu:366-384).
+// Additions: CSR5_SEED=<n> fixes the rand() seed (default stays time(NULL)); CSR5_SIGMA=<n> overrides
+// the auto-tuned sigma; CSR5_MODE=0|1 picks two-pass/fused SpMV; two extra report lines (hipGraph replay
+// time and algorithmic-bytes roofline fraction) are printed after the reference's lines.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "anonymouslib_hip.h"
+
+using namespace std;
+
+#ifndef VALUE_TYPE
+#define VALUE_TYPE double
+#endif
+#ifndef NUM_RUN
+#define NUM_RUN 1000
+#endif
+
+#define DEV_CHECK(call)                                                                            \
+    do {                                                                                           \
+        int e_ = (call);                                                                           \
+        if (e_ != 0) {                                                                             \
+            cerr << #call << " failed (" << e_ << "): " << csr5hip_last_error() << endl;           \
+            exit(1);                                                                               \
+        }                                                                                          \
+    } while (0)
+
+struct Banner {
+    bool pattern, integer, real, complex_, symmetric;
+};
+
+// "%%MatrixMarket matrix coordinate <real|integer|pattern|complex> <general|symmetric|...>"
+static bool parse_banner(FILE *f, Banner &b)
+{
+    char line[1100];
+    if (!fgets(line, sizeof line, f))
+        return false;
+    char tag[64], obj[64], fmt[64], field[64], symm[64];
+    if (sscanf(line, "%63s %63s %63s %63s %63s", tag, obj, fmt, field, symm) != 5)
+        return false;
+    for (char *p = obj; *p; ++p) *p = tolower(*p);
+    for (char *p = fmt; *p; ++p) *p = tolower(*p);
+    for (char *p = field; *p; ++p) *p = tolower(*p);
+    for (char *p = symm; *p; ++p) *p = tolower(*p);
+    if (strcmp(tag, "%%MatrixMarket") || strcmp(obj, "matrix") || strcmp(fmt, "coordinate"))
+        return false;
+    b.pattern = !strcmp(field, "pattern");
+    b.integer = !strcmp(field, "integer");
+    b.real = !strcmp(field, "real");
+    b.complex_ = !strcmp(field, "complex");
+    if (!(b.pattern || b.integer || b.real || b.complex_))
+        return false;
+    b.symmetric = !strcmp(symm, "symmetric") || !strcmp(symm, "hermitian");
+    return true;
+}
+
+static bool parse_size(FILE *f, int &m, int &n, int &nz)
+{
+    char line[1100];
+    while (fgets(line, sizeof line, f)) {
+        if (line[0] == '%')
+            continue;
+        if (sscanf(line, "%d %d %d", &m, &n, &nz) == 3)
+            return true;
+        bool blank = true;
+        for (char *p = line; *p; ++p)
+            if (!isspace(*p)) blank = false;
+        if (!blank)
+            return false;
+    }
+    return false;
+}
+
+static int call_anonymouslib(int m, int n, int nnzA, int *csrRowPtrA, int *csrColIdxA,
+                             VALUE_TYPE *csrValA, VALUE_TYPE *x, VALUE_TYPE *y, VALUE_TYPE alpha)
+{
+    int err = 0;
+    const int device_id = 0;
+    DEV_CHECK(csr5hip_set_device(device_id));
+    char name[256];
+    double mhz = 0;
+    DEV_CHECK(csr5hip_device_name(device_id, name, sizeof name, &mhz));
+    cout << "Device [" << device_id << "] " << name << ", " << " @ " << mhz << "MHz. " << endl;
+
+    const double gb = getB<int, VALUE_TYPE>(m, nnzA);
+    const double gflop = getFLOP<int>(nnzA);
+
+    int *d_csrRowPtrA, *d_csrColIdxA;
+    VALUE_TYPE *d_csrValA, *d_x, *d_y;
+    DEV_CHECK(csr5hip_malloc((void **)&d_csrRowPtrA, (size_t)(m + 1) * sizeof(int)));
+    DEV_CHECK(csr5hip_malloc((void **)&d_csrColIdxA, (size_t)nnzA * sizeof(int)));
+    DEV_CHECK(csr5hip_malloc((void **)&d_csrValA, (size_t)nnzA * sizeof(VALUE_TYPE)));
+    DEV_CHECK(csr5hip_memcpy_h2d(d_csrRowPtrA, csrRowPtrA, (size_t)(m + 1) * sizeof(int)));
+    DEV_CHECK(csr5hip_memcpy_h2d(d_csrColIdxA, csrColIdxA, (size_t)nnzA * sizeof(int)));
+    DEV_CHECK(csr5hip_memcpy_h2d(d_csrValA, csrValA, (size_t)nnzA * sizeof(VALUE_TYPE)));
+    DEV_CHECK(csr5hip_malloc((void **)&d_x, (size_t)n * sizeof(VALUE_TYPE)));
+    DEV_CHECK(csr5hip_memcpy_h2d(d_x, x, (size_t)n * sizeof(VALUE_TYPE)));
+    DEV_CHECK(csr5hip_malloc((void **)&d_y, (size_t)m * sizeof(VALUE_TYPE)));
+    DEV_CHECK(csr5hip_memset(d_y, 0, (size_t)m * sizeof(VALUE_TYPE)));
+
+    anonymouslibHandle<int, unsigned int, VALUE_TYPE> A(m, n);
+    err = A.inputCSR(nnzA, d_csrRowPtrA, d_csrColIdxA, d_csrValA);
+    err = A.setX(d_x); // once is enough
+    const char *sig = getenv("CSR5_SIGMA");
+    A.setSigma(sig ? atoi(sig) : ANONYMOUSLIB_AUTO_TUNED_SIGMA);
+    const char *mode = getenv("CSR5_MODE");
+    if (mode)
+        A.setOption(CSR5HIP_OPT_SPMV_MODE, atoi(mode));
+
+    A.warmup();
+
+    anonymouslib_timer asCSR5_timer;
+    asCSR5_timer.start();
+    err = A.asCSR5();
+    cout << "CSR->CSR5 time = " << asCSR5_timer.stop() << " ms." << endl;
+    if (err != ANONYMOUSLIB_SUCCESS)
+        cerr << "asCSR5 err = " << err << " " << csr5hip_last_error() << endl;
+
+    // correctness run
+    err = A.spmv(alpha, d_y);
+    DEV_CHECK(csr5hip_memcpy_d2h(y, d_y, (size_t)m * sizeof(VALUE_TYPE)));
+
+    if (NUM_RUN) {
+        for (int i = 0; i < 50; i++)
+            err = A.spmv(alpha, d_y);
+    }
+    DEV_CHECK(csr5hip_synchronize());
+
+    anonymouslib_timer CSR5Spmv_timer;
+    CSR5Spmv_timer.start();
+    for (int i = 0; i < NUM_RUN; i++)
+        err = A.spmv(alpha, d_y);
+    DEV_CHECK(csr5hip_synchronize());
+    const double CSR5Spmv_time = NUM_RUN ? CSR5Spmv_timer.stop() / (double)NUM_RUN : 0.0;
+
+    if (NUM_RUN) {
+        cout << "CSR5-based SpMV time = " << CSR5Spmv_time
+             << " ms. Bandwidth = " << gb / (1.0e+6 * CSR5Spmv_time)
+             << " GB/s. GFlops = " << gflop / (1.0e+6 * CSR5Spmv_time) << " GFlops." << endl;
+
+        // additions: the same NUM_RUN launches replayed from one hipGraph, device-timed
+        A.spmv_repeat(alpha, d_y, NUM_RUN); // instantiate + warm
+        DEV_CHECK(csr5hip_synchronize());
+        double ms = 0;
+        DEV_CHECK(csr5hip_timer_start(A.native()));
+        A.spmv_repeat(alpha, d_y, NUM_RUN);
+        DEV_CHECK(csr5hip_timer_stop(A.native(), &ms));
+        const double t = ms / NUM_RUN;
+        const double b_alg = (double)nnzA * (sizeof(int) + sizeof(VALUE_TYPE)) + 4.0 * (m + 1) +
+                             (double)sizeof(VALUE_TYPE) * ((double)n + m);
+        cout << "CSR5-based SpMV time (hipGraph replay) = " << t
+             << " ms. GFlops = " << gflop / (1.0e+6 * t) << " GFlops." << endl;
+        cout << "Algorithmic bytes = " << b_alg * 1e-6 << " MB. Achieved = " << b_alg / (1.0e+6 * t)
+             << " GB/s = " << 100.0 * b_alg / (1.0e+6 * t) / 8000.0 << " % of the 8 TB/s HBM3E roof." << endl;
+    }
+
+    A.destroy();
+    csr5hip_device_free(d_csrRowPtrA);
+    csr5hip_device_free(d_csrColIdxA);
+    csr5hip_device_free(d_csrValA);
+    csr5hip_device_free(d_x);
+    csr5hip_device_free(d_y);
+    return err;
+}
+
+int main(int argc, char **argv)
+{
+    cout << "------------------------------------------------------" << endl;
+    const char *precision;
+    if (sizeof(VALUE_TYPE) == 4)
+        precision = "32-bit Single Precision";
+    else if (sizeof(VALUE_TYPE) == 8)
+        precision = "64-bit Double Precision";
+    else {
+        cout << "Wrong precision. Program exit!" << endl;
+        return 0;
+    }
+    cout << "PRECISION = " << precision << endl;
+    cout << "------------------------------------------------------" << endl;
+
+    if (argc < 2) { // the reference dereferences an unset pointer here; fail cleanly instead
+        cout << "usage: ./spmv <matrix.mtx>" << endl;
+        return -1;
+    }
+    const char *filename = argv[1];
+    cout << "--------------" << filename << "--------------" << endl;
+
+    FILE *f = fopen(filename, "r");
+    if (!f)
+        return -1;
+    Banner banner;
+    if (!parse_banner(f, banner)) {
+        cout << "Could not process Matrix Market banner." << endl;
+        return -2;
+    }
+    if (banner.complex_) {
+        cout << "Sorry, data type 'COMPLEX' is not supported. " << endl;
+        return -3;
+    }
+    int m, n, nnz_file;
+    if (!parse_size(f, m, n, nnz_file))
+        return -4;
+
+    // coordinate entries, 1-based in the file
+    vector<int> ri(nnz_file), ci(nnz_file);
+    vector<int> counter(m + 1, 0);
+    for (int k = 0; k < nnz_file; k++) {
+        int i = 0, j = 0, iv;
+        double fv;
+        if (banner.real)         fscanf(f, "%d %d %lg\n", &i, &j, &fv);
+        else if (banner.integer) fscanf(f, "%d %d %d\n", &i, &j, &iv);
+        else                     fscanf(f, "%d %d\n", &i, &j);
+        ri[k] = i - 1;
+        ci[k] = j - 1;
+        counter[ri[k]]++;
+    }
+    fclose(f);
+    if (banner.symmetric)
+        for (int k = 0; k < nnz_file; k++)
+            if (ri[k] != ci[k])
+                counter[ci[k]]++;
+
+    // counting sort by row: file order inside each row, mirrored entry right after its original
+    vector<int> rowptr(m + 1, 0);
+    for (int r = 0; r < m; r++)
+        rowptr[r + 1] = rowptr[r] + counter[r];
+    const int nnzA = rowptr[m];
+    vector<int> fill(rowptr.begin(), rowptr.end() - 1);
+    int *csrRowPtrA = (int *)malloc((size_t)(m + 1) * sizeof(int));
+    memcpy(csrRowPtrA, rowptr.data(), (size_t)(m + 1) * sizeof(int));
+    int *csrColIdxA = (int *)malloc((size_t)(nnzA > 0 ? nnzA : 1) * sizeof(int));
+    VALUE_TYPE *csrValA = (VALUE_TYPE *)malloc((size_t)(nnzA > 0 ? nnzA : 1) * sizeof(VALUE_TYPE));
+    for (int k = 0; k < nnz_file; k++) {
+        csrColIdxA[fill[ri[k]]++] = ci[k];
+        if (banner.symmetric && ri[k] != ci[k])
+            csrColIdxA[fill[ci[k]]++] = ri[k];
+    }
+
+    const char *seed_env = getenv("CSR5_SEED");
+    srand(seed_env ? (unsigned)strtoul(seed_env, 0, 10) : (unsigned)time(NULL));
+    for (int k = 0; k < nnzA; k++)
+        csrValA[k] = rand() % 10;
+
+    cout << " ( " << m << ", " << n << " ) nnz = " << nnzA << endl;
+
+    VALUE_TYPE *x = (VALUE_TYPE *)malloc((size_t)n * sizeof(VALUE_TYPE));
+    for (int k = 0; k < n; k++)
+        x[k] = rand() % 10;
+    VALUE_TYPE *y = (VALUE_TYPE *)malloc((size_t)m * sizeof(VALUE_TYPE));
+    VALUE_TYPE *y_ref = (VALUE_TYPE *)malloc((size_t)m * sizeof(VALUE_TYPE));
+
+    const double gb = getB<int, VALUE_TYPE>(m, nnzA);
+    const double gflop = getFLOP<int>(nnzA);
+    const VALUE_TYPE alpha = 1.0;
+
+    // scalar CSR loop on one host core: the reference result
+    anonymouslib_timer ref_timer;
+    ref_timer.start();
+    for (int i = 0; i < m; i++) {
+        VALUE_TYPE sum = 0;
+        for (int j = csrRowPtrA[i]; j < csrRowPtrA[i + 1]; j++)
+            sum += x[csrColIdxA[j]] * csrValA[j] * alpha;
+        y_ref[i] = sum;
+    }
+    const double ref_time = ref_timer.stop();
+    cout << "cpu sequential time = " << ref_time << " ms. Bandwidth = " << gb / (1.0e+6 * ref_time)
+         << " GB/s. GFlops = " << gflop / (1.0e+6 * ref_time) << " GFlops." << endl << endl;
+
+    call_anonymouslib(m, n, nnzA, csrRowPtrA, csrColIdxA, csrValA, x, y, alpha);
+
+    int error_count = 0;
+    for (int i = 0; i < m; i++)
+        if (fabs((double)y_ref[i] - (double)y[i]) > 0.01 * fabs((double)y_ref[i]))
+            error_count++;
+    if (error_count == 0)
+        cout << "Check... PASS!" << endl;
+    else
+        cout << "Check... NO PASS! #Error = " << error_count << " out of " << m << " entries." << endl;
+    cout << "------------------------------------------------------" << endl;
+
+    free(csrRowPtrA);
+    free(csrColIdxA);
+    free(csrValA);
+    free(x);
+    free(y);
+    free(y_ref);
+    return 0;
+}

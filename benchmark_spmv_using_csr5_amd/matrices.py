@@ -245,3 +245,50 @@ def write_mtx(path: str, mat: CsrMatrix, field: str = "real", symmetric: bool = 
                 f.write(f"{r + 1} {c + 1} {int(v)}\n")
             else:
                 f.write(f"{r + 1} {c + 1} {float(v)!r}\n")
+
+
+# ---------------------------------------------------------------------------------------------
+# Device-side R-MAT (torch is plumbing here: RNG, sort and prefix sum on the GPU) for scales that
+# numpy cannot generate in bench time (scale 24 = 268 M non-zeros).
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class DeviceCsr:
+    m: int
+    n: int
+    nnz: int
+    row_ptr: object  # torch.int32[m+1] on the device
+    col: object      # torch.int32[nnz] on the device
+    name: str = "rmat(device)"
+
+
+def rmat_device(scale: int, edge_factor: int, seed: int, rank: int, world: int, device, dtype=None,
+                abcd=(0.57, 0.19, 0.19, 0.05)) -> DeviceCsr:
+    """One row block per rank (weak scaling): every rank owns a 2^scale-row R-MAT block whose
+    columns are spread over the world * 2^scale global columns."""
+    import torch
+
+    n_local = 1 << scale
+    ne = n_local * edge_factor
+    g = torch.Generator(device=device).manual_seed(seed + 1009 * rank)
+    a, b, c, _ = abcd
+    rows = torch.zeros(ne, dtype=torch.int64, device=device)
+    cols = torch.zeros(ne, dtype=torch.int64, device=device)
+    for _lvl in range(scale):
+        r = torch.rand(ne, generator=g, device=device)
+        rbit = (r >= (a + b)).to(torch.int64)
+        cbit = (((r >= a) & (r < a + b)) | (r >= a + b + c)).to(torch.int64)
+        rows = (rows << 1) | rbit
+        cols = (cols << 1) | cbit
+        del r, rbit, cbit
+    if world > 1:
+        blk = torch.randint(0, world, (ne,), generator=g, device=device, dtype=torch.int64)
+        cols = cols + blk * n_local
+        del blk
+    rows, order = torch.sort(rows, stable=True)
+    cols = cols[order].to(torch.int32)
+    del order
+    counts = torch.bincount(rows, minlength=n_local)
+    row_ptr = torch.zeros(n_local + 1, dtype=torch.int64, device=device)
+    row_ptr[1:] = torch.cumsum(counts, 0)
+    return DeviceCsr(n_local, n_local * world, int(ne), row_ptr.to(torch.int32), cols.contiguous(),
+                     f"rmat{scale}(synthetic)")
