@@ -57,7 +57,10 @@ def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device):
         scale = int(workload[4:] or 20)
         return M.rmat_device(scale, 16, seed, rank, world, device), f"R-MAT scale {scale} EF16 (synthetic)"
     gen = {"scircuit": M.scircuit_like, "webbase": M.webbase_like, "nd24k": M.nd24k_like}[workload]
-    mat = gen(seed=seed + 101 * rank, dtype=dtype)
+    kw = {}
+    if workload == "scircuit" and os.environ.get("CSR5_BENCH_ROWCAP"):  # experiment knob, not a config
+        kw["row_cap"] = int(os.environ["CSR5_BENCH_ROWCAP"])
+    mat = gen(seed=seed + 101 * rank, dtype=dtype, **kw)
     if world > 1:  # spread the block's columns over the global column space of all blocks
         rng = np.random.default_rng(seed + 7 * rank)
         shift = rng.integers(0, world, size=mat.nnz, dtype=np.int64) * mat.n

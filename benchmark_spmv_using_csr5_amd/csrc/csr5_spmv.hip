@@ -26,13 +26,43 @@
 
 namespace csr5 {
 
+// ---- cross-lane helpers on DPP (data-parallel primitives: lane moves folded into VALU operands, no LDS
+//      crossbar round trip as with ds_bpermute).  A 64-bit value moves as two 32-bit halves. -------------
+template <int CTRL, int ROW_MASK_ = 0xF, int BANK_MASK_ = 0xF>
+__device__ __forceinline__ float dpp_move(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL,
+                                                                 ROW_MASK_, BANK_MASK_, false));
+}
+template <int CTRL, int ROW_MASK_ = 0xF, int BANK_MASK_ = 0xF>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK_, BANK_MASK_, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK_, BANK_MASK_, false);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+// lanes masked off by row/bank masks or shifted in from outside a row read 0 (old = 0, bound_ctrl off)
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHL1 = 0x130;
+
+// sum over the 64 lanes, result in every lane (6 DPP steps + one readlane broadcast)
 template <typename VT>
 __device__ __forceinline__ VT wave_sum(VT v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1)
-        v += __shfl_xor(v, d, OMEGA);
-    return v;
+    v += dpp_move<DPP_ROW_SHR1>(v);                 // pairs
+    v += dpp_move<DPP_ROW_SHR2>(v);                 // quads
+    v += dpp_move<DPP_ROW_SHR4>(v);                 // 8
+    v += dpp_move<DPP_ROW_SHR8>(v);                 // lane 15 of every row holds the row sum
+    v += dpp_move<DPP_ROW_BCAST15, 0xA>(v);         // rows 1,3 += row 0,2 totals
+    v += dpp_move<DPP_ROW_BCAST31, 0xC>(v);         // rows 2,3 += lane 31 total -> lane 63 = wave sum
+    return __shfl(v, OMEGA - 1, OMEGA);             // v_readlane broadcast
+}
+// value of lane l+1 (lane 63 receives 0)
+template <typename VT>
+__device__ __forceinline__ VT lane_above(VT v)
+{
+    return dpp_move<DPP_WAVE_SHL1>(v);
 }
 
 // ---- fused-mode carry protocol ------------------------------------------------------------------
@@ -64,30 +94,56 @@ __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, const uint4
 }
 
 // ---- CSR tail tile: rows tail_start..m-1, non-zeros from (p-1)*T, untransposed -------------------
-// One thread per row; rows longer than 16 are summed by the whole wave (the tail holds < T non-zeros
-// in total, but may span any number of - mostly empty - rows).  The first row's partial is a carry.
+// The tail holds E <= T <= 2048 non-zeros but may span any number of (mostly empty) rows.  Every tail
+// workgroup owns 256 consecutive rows.  Latency shape = a tile's: ONE round trip fetches all E
+// column/value pairs and the workgroup's row pointers, a second one gathers x; products go to LDS and
+// each thread then sums its own row from LDS (rows longer than 32 are summed by the whole wave).
+// The first row's partial is a carry.
+constexpr int TAIL_MAX = OMEGA * CSR5HIP_MAX_SIGMA; // 2048
+
 template <typename VT, bool FUSED>
 __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__restrict__ row_ptr,
                                           const int32_t *__restrict__ col,
                                           const VT *__restrict__ val, const VT *__restrict__ x,
                                           VT *__restrict__ calibrator, VT *__restrict__ y,
                                           int tail_block, VT *acc, uint32_t *cnt,
-                                          const uint4 *meta, const uint32_t *tile_ptr)
+                                          const uint4 *meta, const uint32_t *tile_ptr, VT *sprod)
 {
-    const int lane = threadIdx.x & (OMEGA - 1);
-    const int r = g.tail_start + tail_block * BLOCK + (int)threadIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & (OMEGA - 1);
     const int first_tail = (g.p - 1) * g.tile_elems;
+    const int E = g.nnz - first_tail;
+    constexpr int PER = TAIL_MAX / BLOCK; // 8
+    int32_t c[PER];
+    VT v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int e = tid + k * BLOCK;
+        const int idx = first_tail + (e < E ? e : 0);
+        c[k] = col[idx];
+        v[k] = val[idx];
+    }
+    const int r = g.tail_start + tail_block * BLOCK + tid;
     const bool valid = r < g.m;
     int a = 0, b = 0;
     if (valid) {
-        a = r == g.tail_start ? first_tail : row_ptr[r];
+        a = row_ptr[r];
         b = row_ptr[r + 1];
     }
-    const bool longrow = valid && (b - a) > 16;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int e = tid + k * BLOCK;
+        if (e < E)
+            sprod[e] = v[k] * x[c[k]];
+    }
+    __syncthreads();
+    a = (r == g.tail_start ? first_tail : a) - first_tail;
+    b -= first_tail;
+    const bool longrow = valid && (b - a) > 32;
     VT sum = 0;
     if (valid && !longrow)
         for (int k = a; k < b; k++)
-            sum += val[k] * x[col[k]];
+            sum += sprod[k];
     unsigned long long todo = __ballot(longrow);
     while (todo) {
         const int src = __builtin_ctzll(todo);
@@ -96,7 +152,7 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
         const int bb = __shfl(b, src, OMEGA);
         VT s = 0;
         for (int k = aa + lane; k < bb; k += OMEGA)
-            s += val[k] * x[col[k]];
+            s += sprod[k];
         s = wave_sum(s);
         if (lane == src)
             sum = s;
@@ -125,12 +181,13 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
        const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
        const uint32_t *__restrict__ tile_desc, const int32_t *__restrict__ offset_ptr,
        const int32_t *__restrict__ offset, VT *__restrict__ calibrator, VT *__restrict__ y,
-       int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *meta)
+       int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta)
 {
     int blk = blockIdx.x;
     if (blk >= tile_blocks) {
+        __shared__ VT sprod[TAIL_MAX];
         tail_rows<VT, FUSED>(g, row_ptr, col, val, x, calibrator, y, blk - tile_blocks, acc, cnt,
-                             meta, tile_ptr);
+                             meta, tile_ptr, sprod);
         return;
     }
     if (xcd_remap) {
@@ -151,33 +208,42 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     const int num_packet = SIGMA > 0 ? num_packet_of(SIGMA > 0 ? SIGMA : 1) : g.num_packet;
     const int T = OMEGA * sigma;
 
-    const uint32_t rs_raw = tile_ptr[t];
-    const uint32_t row_stop = tile_ptr[t + 1] & ROW_MASK;
+    // ---- issue every independent load of the tile first: tile_ptr pair, carry meta, descriptor
+    //      words, the short-spill elements of tile t+1 and the sigma column/value pairs.  No wait
+    //      and no data-dependent branch sits between them, so one memory round trip covers all
+    //      of them and a second one covers the x gathers.
     const size_t base = (size_t)t * T + lane;
     const int32_t *ct = col + base;
     const VT *vt = val + base;
-
-    // fused mode: short spill of this tile's closing row into tile t+1 -- fetch those <= 64
-    // elements now so that their latency overlaps the tile's own loads
+    const uint32_t *d = tile_desc + (size_t)t * OMEGA * num_packet;
+    // The wave-uniform words (tile_ptr pair, carry meta) deliberately go through the VECTOR memory
+    // path: vector loads return in order, so they share the tile loads' round trip, whereas scalar
+    // loads would force an s_waitcnt lgkmcnt(0) (they return out of order) in front of the tile loads.
+    // `vz` is an opaque per-lane zero that keeps the compiler from scalarising these loads.
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    const uint32_t tp0 = tile_ptr[t + vz];
+    const uint32_t tp1 = tile_ptr[t + 1 + vz];
     uint4 mt = make_uint4(0u, 0u, 0u, 0u);
-    VT lead_next = 0;
+    int32_t spill_c = 0;
+    VT spill_v = 0;
     if constexpr (FUSED) {
-        mt = meta[t];
-        if ((mt.x >> 29) & 1u) {
-            const int L = (int)mt.z;
-            if (lane < L) {
-                // tile t+1 is either a transposed tile (element j at (j % sigma)*omega + j / sigma)
-                // or the untransposed CSR tail
-                const size_t nb = (size_t)(t + 1) * T;
-                const size_t pos = (t + 1 == g.p - 1) ? nb + lane : nb + (size_t)(lane % sigma) * OMEGA + lane / sigma;
-                lead_next = val[pos] * x[col[pos]];
-            }
-        }
+        mt = meta[t + vz];
+        // first 64 elements (CSR order) of tile t+1: a transposed tile keeps element j at
+        // (j % sigma)*omega + j / sigma, the CSR tail keeps it at j
+        const size_t nb = (size_t)(t + 1) * T;
+        size_t pos = (t + 1 == g.p - 1) ? nb + lane : nb + (size_t)(lane % sigma) * OMEGA + lane / sigma;
+        pos = pos < (size_t)g.nnz ? pos : (size_t)g.nnz - 1;
+        spill_c = col[pos];
+        spill_v = val[pos];
     }
+    const uint32_t w0 = d[lane];
+    const uint32_t w1 = num_packet > 1 ? d[OMEGA + lane] : 0u;
 
     // products of this lane's sigma elements (coalesced: lane stride 1 at every step)
     constexpr int NREG = SIGMA > 0 ? SIGMA : 1;
     VT prod[NREG];
+    VT lead_next = 0;
     if constexpr (SIGMA > 0) {
         int32_t c[NREG];
         VT v[NREG];
@@ -186,9 +252,28 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
             c[i] = ct[i * OMEGA];
             v[i] = vt[i * OMEGA];
         }
+        // everything above is in flight before anything below consumes a loaded value
+        __builtin_amdgcn_sched_barrier(0);
+        VT xv[NREG];
 #pragma unroll
         for (int i = 0; i < SIGMA; i++)
-            prod[i] = v[i] * x[c[i]];
+            xv[i] = x[c[i]];
+        if constexpr (FUSED) {
+            // the closing row of this tile spills mt.z <= 64 elements into tile t+1 and ends there:
+            // gather x for exactly those lanes; the other lanes re-read x[0] (one cache line), so the
+            // gather is unconditional and rides in the same round trip as the tile's own gathers
+            const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
+            const VT sx = x[lane < L ? spill_c : 0];
+            lead_next = lane < L ? spill_v * sx : (VT)0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < SIGMA; i++)
+            prod[i] = v[i] * xv[i];
+    } else if constexpr (FUSED) {
+        const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
+        const VT sx = x[lane < L ? spill_c : 0];
+        lead_next = lane < L ? spill_v * sx : (VT)0;
     }
     auto product = [&](int i) -> VT {
         if constexpr (SIGMA > 0)
@@ -196,6 +281,22 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         else
             return vt[i * OMEGA] * x[ct[i * OMEGA]];
     };
+
+    // Decode the descriptor and reduce the spill HERE, in the entry block, before any data-dependent
+    // branch: values that are only consumed inside a branch get their loads sunk into it by the
+    // compiler, which would serialise their round trip behind the tile's own.
+    uint32_t flags = w0 << bit_all; // element i -> bit 31-i
+    if (num_packet > 1)
+        flags |= w1 >> (32 - bit_all);
+    int y_off = (int)(w0 >> (32 - bit_y));
+    const bool f0 = (flags >> 31) | (lane == 0);
+    const bool present = f0 | ((flags & 0x7FFFFFFFu) != 0);
+    const unsigned long long pmask = __ballot(present);
+    VT spill = 0;
+    if constexpr (FUSED)
+        spill = wave_sum(lead_next);
+    const uint32_t rs_raw = __builtin_amdgcn_readfirstlane(tp0);
+    const uint32_t row_stop = __builtin_amdgcn_readfirstlane(tp1) & ROW_MASK;
 
     if (rs_raw == row_stop) {
         // fast track: the whole tile lies inside one row (csr5_spmv_cuda.h:59-90)
@@ -218,14 +319,6 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     VT *y_local = y + row_start + 1;
     const int32_t *off_local = empty_rows ? offset + offset_ptr[t] : nullptr;
 
-    const uint32_t *d = tile_desc + (size_t)t * OMEGA * num_packet;
-    const uint32_t w0 = d[lane];
-    uint32_t flags = w0 << bit_all; // element i -> bit 31-i
-    if (num_packet > 1)
-        flags |= d[OMEGA + lane] >> (32 - bit_all);
-    int y_off = (int)(w0 >> (32 - bit_y));
-
-    const bool f0 = (flags >> 31) | (lane == 0);
     bool direct = f0 && lane != 0;
     VT sum = product(0);
     VT first_sum = 0;
@@ -248,8 +341,6 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     // cross-lane step: every lane that owns a flag adds the leading partials of the lanes behind it,
     // up to and including the next lane that owns a flag:  S[l] = R[l+1],
     // R[j] = lead[j] + (present[j] ? 0 : R[j+1])  -- backward segmented scan, 6 shuffle steps.
-    const bool present = f0 | ((flags & 0x7FFFFFFFu) != 0);
-    const unsigned long long pmask = __ballot(present);
     VT R = f0 ? (VT)0 : first_sum;
     if (pmask != ~0ull) {
         const unsigned long long ahead = pmask >> lane;
@@ -261,9 +352,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
                 R += up;
         }
     }
-    VT S = __shfl_down(R, 1, OMEGA);
-    if (lane == OMEGA - 1)
-        S = 0;
+    const VT S = lane_above(R); // lane 63 gets 0
     if (present)
         sum += S;
 
@@ -272,11 +361,8 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         const bool close_local = (mt.x >> 29) & 1u;
         const bool lead_skip = (mt.x >> 28) & 1u;
         const int last_present = 63 - __builtin_clzll(pmask);
-        if (close_local) { // wave-uniform: finish the closing row with its short spill into tile t+1
-            const VT spill = wave_sum(lead_next);
-            if (lane == last_present)
-                sum += spill;
-        }
+        if (close_local && lane == last_present) // finish the closing row with its short spill
+            sum += spill;
         if (direct) {
             if (close_carry && !close_local && lane == last_present)
                 carry_arrive(acc, cnt, meta, tile_ptr, t + 1, sum, y);
