@@ -26,6 +26,23 @@
 
 namespace csr5 {
 
+// Optional per-wave timestamp probe (built only into libcsr5hip_timing.so by `make timing`; never in
+// the product library): slot k of tile t receives the 100 MHz wall clock at stage k.
+#ifdef CSR5_TIMING_PROBE
+__device__ unsigned long long *csr5_timing_buf = nullptr;
+#define CSR5_TSTAMP(tile, k)                                                                       \
+    do {                                                                                           \
+        if (csr5_timing_buf && (threadIdx.x & 63) == 0)                                            \
+            csr5_timing_buf[(size_t)(tile) * 8 + (k)] = wall_clock64();                            \
+    } while (0)
+extern "C" int csr5hip_debug_set_timing_buffer(void *dptr)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(csr5_timing_buf), &dptr, sizeof(dptr));
+}
+#else
+#define CSR5_TSTAMP(tile, k) do { } while (0)
+#endif
+
 // ---- cross-lane helpers on DPP (data-parallel primitives: lane moves folded into VALU operands, no LDS
 //      crossbar round trip as with ds_bpermute).  A 64-bit value moves as two 32-bit halves. -------------
 template <int CTRL, int ROW_MASK_ = 0xF, int BANK_MASK_ = 0xF>
@@ -130,11 +147,17 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
         a = row_ptr[r];
         b = row_ptr[r + 1];
     }
+    // unconditional gathers (out-of-range slots re-read element 0's column): one round trip, no
+    // per-gather wait; only the LDS store is predicated
+    VT xv[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        xv[k] = x[c[k]];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int e = tid + k * BLOCK;
         if (e < E)
-            sprod[e] = v[k] * x[c[k]];
+            sprod[e] = v[k] * xv[k];
     }
     __syncthreads();
     a = (r == g.tail_start ? first_tail : a) - first_tail;
@@ -202,6 +225,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     if (t >= g.p - 1)
         return;
 
+    CSR5_TSTAMP(t, 0);
     const int sigma = SIGMA > 0 ? SIGMA : g.sigma;
     const int bit_y = SIGMA > 0 ? bit_y_of(SIGMA > 0 ? SIGMA : 1) : g.bit_y;
     const int bit_all = bit_y + BIT_SS;
@@ -254,6 +278,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         }
         // everything above is in flight before anything below consumes a loaded value
         __builtin_amdgcn_sched_barrier(0);
+        CSR5_TSTAMP(t, 1);
         VT xv[NREG];
 #pragma unroll
         for (int i = 0; i < SIGMA; i++)
@@ -267,9 +292,14 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
             lead_next = lane < L ? spill_v * sx : (VT)0;
         }
         __builtin_amdgcn_sched_barrier(0);
+        CSR5_TSTAMP(t, 2);
 #pragma unroll
         for (int i = 0; i < SIGMA; i++)
             prod[i] = v[i] * xv[i];
+#ifdef CSR5_TIMING_PROBE
+        asm volatile("" ::"v"(prod[SIGMA - 1]), "v"(lead_next));
+        CSR5_TSTAMP(t, 3);
+#endif
     } else if constexpr (FUSED) {
         const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
         const VT sx = x[lane < L ? spill_c : 0];
@@ -319,6 +349,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     VT *y_local = y + row_start + 1;
     const int32_t *off_local = empty_rows ? offset + offset_ptr[t] : nullptr;
 
+    CSR5_TSTAMP(t, 4);
     bool direct = f0 && lane != 0;
     VT sum = product(0);
     VT first_sum = 0;
@@ -341,6 +372,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     // cross-lane step: every lane that owns a flag adds the leading partials of the lanes behind it,
     // up to and including the next lane that owns a flag:  S[l] = R[l+1],
     // R[j] = lead[j] + (present[j] ? 0 : R[j+1])  -- backward segmented scan, 6 shuffle steps.
+    CSR5_TSTAMP(t, 5);
     VT R = f0 ? (VT)0 : first_sum;
     if (pmask != ~0ull) {
         const unsigned long long ahead = pmask >> lane;
@@ -356,6 +388,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     if (present)
         sum += S;
 
+    CSR5_TSTAMP(t, 6);
     if constexpr (FUSED) {
         const bool close_carry = (mt.x >> 30) & 1u;
         const bool close_local = (mt.x >> 29) & 1u;
@@ -377,6 +410,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         if (lane == 0)
             calibrator[t] = direct ? first_sum : sum;
     }
+    CSR5_TSTAMP(t, 7);
 }
 
 // ---- two-pass mode, second pass: resolve carries in tile order ------------------------------------

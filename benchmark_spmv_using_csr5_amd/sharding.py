@@ -1,0 +1,127 @@
+"""1-D row-block sharding of a CSR matrix over the GPUs of one node.
+
+The reference is single-device (CSR5_cuda/main.cu:25-26 `cudaSetDevice(0)`); this is the MI355X-native
+addition named by BASELINE.json: rows are independent, so the matrix is cut into contiguous row blocks
+balanced by NON-ZEROS (split points = upper_bound(row_ptr, g*nnz/G), the same primitive the reference
+uses for tile_ptr, utils_cuda.h:25-53), every rank converts and multiplies its own block with its own
+handle, x is replicated once by an RCCL broadcast over xGMI, y stays sharded.  There is no per-iteration
+collective.  One process per GPU, `torch.distributed` (backend "nccl" == RCCL on ROCm; "gloo" in the
+CPU tests).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+
+def partition_rows_by_nnz(row_ptr: np.ndarray, parts: int) -> np.ndarray:
+    """Row split points r_0=0 <= r_1 <= ... <= r_parts=m with ~nnz/parts non-zeros per block.
+
+    r_g = (number of rows whose pointer is <= g*nnz/parts) - 1 clipped to [r_{g-1}, m], i.e. the row
+    that contains non-zero number g*nnz/parts starts the next block."""
+    row_ptr = np.asarray(row_ptr, dtype=np.int64)
+    m = row_ptr.size - 1
+    nnz = int(row_ptr[m])
+    cuts = np.zeros(parts + 1, dtype=np.int64)
+    cuts[parts] = m
+    for g in range(1, parts):
+        target = (g * nnz) // parts
+        r = int(np.searchsorted(row_ptr, target, side="right")) - 1
+        cuts[g] = min(max(r, cuts[g - 1]), m)
+    return cuts
+
+
+@dataclass
+class RowBlock:
+    """The shard one rank owns: rows [row_lo, row_hi) with a rebased row_ptr and GLOBAL columns."""
+    rank: int
+    row_lo: int
+    row_hi: int
+    n: int
+    row_ptr: np.ndarray
+    col: np.ndarray
+    val: np.ndarray
+
+    @property
+    def m(self) -> int:
+        return self.row_hi - self.row_lo
+
+    @property
+    def nnz(self) -> int:
+        return int(self.row_ptr[-1])
+
+
+def extract_row_block(row_ptr, col, val, n: int, cuts: np.ndarray, rank: int) -> RowBlock:
+    lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+    a, b = int(row_ptr[lo]), int(row_ptr[hi])
+    rp = (np.asarray(row_ptr[lo: hi + 1], dtype=np.int64) - a).astype(np.int32)
+    return RowBlock(rank, lo, hi, n, rp, np.ascontiguousarray(col[a:b]), np.ascontiguousarray(val[a:b]))
+
+
+def broadcast_x(x, src: int = 0):
+    """The ONE collective of the sharded SpMV: replicate x on every rank (n*sizeof(vT) bytes)."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(x, src=src)
+    return x
+
+
+def gather_y(y_local, cuts: np.ndarray):
+    """Collect the y shards on every rank (correctness checks only -- not part of the timed path)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    sizes = [int(cuts[r + 1] - cuts[r]) for r in range(world)]
+    width = max(sizes) if sizes else 0
+    pad = torch.zeros(width, dtype=y_local.dtype, device=y_local.device)
+    pad[: y_local.numel()] = y_local
+    out = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return torch.cat([o[:s] for o, s in zip(out, sizes)])
+
+
+class ShardedSpmv:
+    """y_shard = A[row block of this rank] * x, with x broadcast once.
+
+    `local_spmv(block, x) -> y_block` is the per-rank kernel: on the GPU box it wraps an
+    `anonymouslibHandle` (see `hip_local_spmv`); the CPU tests pass a host CSR loop."""
+
+    def __init__(self, row_ptr, col, val, n: int, rank: int, world: int):
+        self.cuts = partition_rows_by_nnz(row_ptr, world)
+        self.block = extract_row_block(row_ptr, col, val, n, self.cuts, rank)
+        self.rank, self.world = rank, world
+
+    def run(self, x, local_spmv):
+        x = broadcast_x(x, src=0)
+        return local_spmv(self.block, x)
+
+
+def hip_local_spmv(device, sigma: int = -1, mode: int = 1):
+    """Factory for ShardedSpmv.run on a GPU: converts the block to CSR5 once, returns y (device)."""
+    import torch
+
+    from . import handle as H
+
+    state = {}
+
+    def run(block: RowBlock, x):
+        if "A" not in state:
+            tdt = torch.float64 if block.val.dtype == np.float64 else torch.float32
+            rp = torch.from_numpy(block.row_ptr).to(device)
+            ci = torch.from_numpy(block.col.astype(np.int32)).to(device)
+            va = torch.from_numpy(block.val).to(device)
+            A = H.anonymouslibHandle(block.m, block.n, dtype=str(block.val.dtype))
+            assert A.inputCSR(block.nnz, rp, ci, va) == 0
+            assert A.setSigma(sigma) == 0
+            assert A.setSpmvMode(mode) == 0
+            assert A.asCSR5() == 0
+            state.update(A=A, keep=(rp, ci, va), y=torch.zeros(block.m, dtype=tdt, device=device))
+        A = state["A"]
+        assert A.setX(x) == 0
+        assert A.spmv(1.0, state["y"]) == 0
+        return state["y"]
+
+    return run
