@@ -32,6 +32,22 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def profiled_traffic(key: str):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN_traffic.json, written by scripts/collect_profiles.py: (2*FETCH_SIZE + WRITE_SIZE) KiB,
+    the factor 2 being the guide's gfx950 FETCH_SIZE correction).  Counters cannot be collected inside
+    this process, so the value is looked up for exactly this workload/dtype/sigma/mode, else None."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            entry = json.load(open(path)).get(key)
+        except Exception:
+            entry = None
+        if entry and entry.get("traffic_bytes_per_launch"):
+            return int(entry["traffic_bytes_per_launch"]), os.path.basename(path)
+    return None, None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +198,9 @@ def main():
         b_alg = M.algorithmic_bytes(m, n, nnz, vsize)  # per launch, this rank's shard
         launch_ms = ev_ms / args.steps
         achieved = b_alg / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_src = (None, None)
+        if world == 1:
+            traffic, traffic_src = profiled_traffic(f"{label}|{dtype_name}|sigma={info.sigma}|{args.mode}")
         out = {
             "metric": f"{'fp64' if dtype_name == 'f64' else 'fp32'} SpMV GFLOPS",
             "value": round(gflops, 3),
@@ -209,7 +228,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "kernel": "csr5::k_spmv",
                 "algorithmic_bytes_per_launch": b_alg,
                 "launch_us": round(launch_ms * 1e3, 3),
