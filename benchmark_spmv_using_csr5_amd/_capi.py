@@ -85,11 +85,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("CSR5HIP_LIB", LIB_PATH)  # experiment builds only (timing / ablation)
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: the CSR5 HIP extension is not built "
+            f"{path} is missing: the CSR5 HIP extension is not built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = restype

@@ -84,29 +84,51 @@ __device__ __forceinline__ VT lane_above(VT v)
 
 // ---- fused-mode carry protocol ------------------------------------------------------------------
 // Slot h (= first tile of a run of tiles that begin inside the same row r) collects every partial of
-// row r that is cut by a tile boundary.  All accesses to acc/cnt are device-scope atomics, so they
-// are performed at the memory side and are coherent across the 8 XCD L2s.  The RETURNING add on acc
-// is waited for (its result feeds an asm barrier) before the counter is bumped, so when the counter
-// reaches `expected` every add has been performed; the last arriver swaps the total out (re-arming
-// the slot for the next launch) and is the only writer of y[r].
+// row r that is cut by a tile boundary and is not covered by short-spill ownership.  `expected` =
+// number of partials that will arrive at the slot (carry_meta[h].x, known at conversion time):
+//   1  the partial IS the row (row starts on the tile boundary and ends inside the tile): plain store.
+//   2  exchange handshake, ONE returning atomic per party: each party swaps the bit-inverted value
+//      into the slot (0 = empty, the memset state); whoever gets a non-zero word back is second, adds
+//      the two partials (a+b == b+a: bit-reproducible), stores y and re-arms the slot.  (Only the
+//      all-ones NaN payload would collide with "empty"; arithmetic never produces it.)
+//   >2 rows spanning several tiles: returning device-scope atomic add into the slot, then an arrival
+//      counter; the add is waited for (its result feeds an asm barrier) before the counter is bumped,
+//      so when the counter reaches `expected` every add has been performed; the last arriver swaps
+//      the total out (re-arming the slot) and is the only writer of y[r].
+// All slot accesses are device-scope atomics: performed at the memory side, coherent across the 8 XCD
+// L2s, no dependence on dispatch order or placement, nobody ever waits for another workgroup.
 template <typename VT>
-__device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, const uint4 *meta,
-                                             const uint32_t *tile_ptr, int slot, VT v, VT *y)
+__device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, const uint32_t *tile_ptr,
+                                             int slot, uint32_t expected, VT v, VT *y)
 {
-    VT old = __hip_atomic_fetch_add(&acc[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // order: the add must have been performed before the arrival is counted
-    asm volatile("" ::"v"(old) : "memory");
-    const uint32_t arrived =
-        __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const uint32_t expected = meta[slot].x & 0x00FFFFFFu;
-    if (arrived == expected) {
-        using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
-        const bits_t raw = __hip_atomic_exchange(reinterpret_cast<bits_t *>(&acc[slot]), (bits_t)0,
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        VT total;
-        __builtin_memcpy(&total, &raw, sizeof(VT));
-        __hip_atomic_store(&cnt[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        y[tile_ptr[slot] & ROW_MASK] = total;
+#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 8)
+    asm volatile("" ::"v"(v), "s"(slot));
+    return;
+#endif
+    using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
+    VT *row_y = y + (tile_ptr[slot] & ROW_MASK);
+    if (expected == 1u) {
+        *row_y = v;
+    } else if (expected == 2u) {
+        bits_t *s = reinterpret_cast<bits_t *>(&acc[slot]);
+        const bits_t mine = ~__builtin_bit_cast(bits_t, v);
+        const bits_t other = __hip_atomic_exchange(s, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (other != 0) {
+            *row_y = v + __builtin_bit_cast(VT, (bits_t)~other);
+            __hip_atomic_store(s, (bits_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+        VT old = __hip_atomic_fetch_add(&acc[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // order: the add must have been performed before the arrival is counted
+        asm volatile("" ::"v"(old) : "memory");
+        const uint32_t arrived =
+            __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (arrived == expected) {
+            const bits_t raw = __hip_atomic_exchange(reinterpret_cast<bits_t *>(&acc[slot]), (bits_t)0,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&cnt[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *row_y = __builtin_bit_cast(VT, raw);
+        }
     }
 }
 
@@ -186,7 +208,7 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
         if constexpr (FUSED) {
             const uint4 mt = meta[g.p - 1];
             if (!((mt.x >> 28) & 1u)) // else tile p-2 already owns this row (short spill)
-                carry_arrive(acc, cnt, meta, tile_ptr, (int)mt.y, sum, y);
+                carry_arrive(acc, cnt, tile_ptr, (int)mt.y, meta[mt.y].x & 0x00FFFFFFu, sum, y);
         } else {
             calibrator[g.p - 1] = sum;
         }
@@ -206,8 +228,17 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
        const int32_t *__restrict__ offset, VT *__restrict__ calibrator, VT *__restrict__ y,
        int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta)
 {
+    // Pull EVERY kernel argument into SGPRs with the first batch of scalar loads: an argument that is
+    // first touched further down would otherwise cost its own kernarg round trip on the critical path.
+    asm volatile("" ::"s"(row_ptr), "s"(col), "s"(val), "s"(x), "s"(tile_ptr), "s"(tile_desc),
+                 "s"(offset_ptr), "s"(offset), "s"(calibrator), "s"(y), "s"(acc), "s"(cnt), "s"(meta),
+                 "s"(g.nnz), "s"(g.p), "s"(g.m), "s"(g.sigma), "s"(g.tail_start), "s"(g.tile_elems),
+                 "s"(g.bit_y), "s"(g.num_packet), "s"(tile_blocks), "s"(xcd_remap));
     int blk = blockIdx.x;
     if (blk >= tile_blocks) {
+#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 4)
+        return;
+#endif
         __shared__ VT sprod[TAIL_MAX];
         tail_rows<VT, FUSED>(g, row_ptr, col, val, x, calibrator, y, blk - tile_blocks, acc, cnt,
                              meta, tile_ptr, sprod);
@@ -249,17 +280,21 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     const uint32_t tp0 = tile_ptr[t + vz];
     const uint32_t tp1 = tile_ptr[t + 1 + vz];
     uint4 mt = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t mt_next_x = 0;
     int32_t spill_c = 0;
     VT spill_v = 0;
     if constexpr (FUSED) {
         mt = meta[t + vz];
+        mt_next_x = meta[t + 1 + vz].x; // tile t+1 <= p-1 always has a meta entry
         // first 64 elements (CSR order) of tile t+1: a transposed tile keeps element j at
         // (j % sigma)*omega + j / sigma, the CSR tail keeps it at j
         const size_t nb = (size_t)(t + 1) * T;
         size_t pos = (t + 1 == g.p - 1) ? nb + lane : nb + (size_t)(lane % sigma) * OMEGA + lane / sigma;
         pos = pos < (size_t)g.nnz ? pos : (size_t)g.nnz - 1;
+#if !(defined(CSR5_ABLATE) && (CSR5_ABLATE & 32))
         spill_c = col[pos];
         spill_v = val[pos];
+#endif
     }
     const uint32_t w0 = d[lane];
     const uint32_t w1 = num_packet > 1 ? d[OMEGA + lane] : 0u;
@@ -282,7 +317,11 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         VT xv[NREG];
 #pragma unroll
         for (int i = 0; i < SIGMA; i++)
+#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 1)
+            xv[i] = (VT)c[i]; // experiment build only: no x gather
+#else
             xv[i] = x[c[i]];
+#endif
         if constexpr (FUSED) {
             // the closing row of this tile spills mt.z <= 64 elements into tile t+1 and ends there:
             // gather x for exactly those lanes; the other lanes re-read x[0] (one cache line), so the
@@ -336,8 +375,8 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
             s += product(i);
         s = wave_sum(s);
         if (lane == 0) {
-            if constexpr (FUSED)
-                carry_arrive(acc, cnt, meta, tile_ptr, (int)mt.y, s, y);
+            if constexpr (FUSED) // member of a multi-tile run: expected count lives at the run head
+                carry_arrive(acc, cnt, tile_ptr, (int)mt.y, meta[mt.y].x & 0x00FFFFFFu, s, y);
             else
                 calibrator[t] = s;
         }
@@ -357,7 +396,11 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     for (int i = 1; i < sigma; i++) {
         if ((flags >> (31 - i)) & 1u) {
             if (direct)
+#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 2)
+                asm volatile("" ::"v"(sum), "v"(y_off)); // experiment build only: no y store
+#else
                 y_local[empty_rows ? off_local[y_off] : y_off] = sum;
+#endif
             else
                 first_sum = sum;
             y_off += direct;
@@ -398,12 +441,19 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
             sum += spill;
         if (direct) {
             if (close_carry && !close_local && lane == last_present)
-                carry_arrive(acc, cnt, meta, tile_ptr, t + 1, sum, y);
+                carry_arrive(acc, cnt, tile_ptr, t + 1, mt_next_x & 0x00FFFFFFu, sum, y);
             else
+#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 16)
+                asm volatile("" ::"v"(sum), "v"(y_off));
+#else
                 y_local[empty_rows ? off_local[y_off] : y_off] = sum;
+#endif
         }
-        if (lane == 0 && !lead_skip)
-            carry_arrive(acc, cnt, meta, tile_ptr, (int)mt.y, direct ? first_sum : sum, y);
+        if (lane == 0 && !lead_skip) {
+            const int slot = (int)mt.y;
+            const uint32_t expected = (slot == t ? mt.x : meta[slot].x) & 0x00FFFFFFu;
+            carry_arrive(acc, cnt, tile_ptr, slot, expected, direct ? first_sum : sum, y);
+        }
     } else {
         if (direct)
             y_local[empty_rows ? off_local[y_off] : y_off] = sum;
@@ -468,11 +518,15 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
     switch (g.sigma) {
 #define CSR5_CASE(S) \
     case S: return launch_one<VT, S, FUSED>(g, d, x, y, opt, s);
+#ifdef CSR5_ABLATE // experiment builds: two instantiations only
+        CSR5_CASE(5) CSR5_CASE(16)
+#else
         CSR5_CASE(4) CSR5_CASE(5) CSR5_CASE(6) CSR5_CASE(7) CSR5_CASE(8) CSR5_CASE(9) CSR5_CASE(10)
         CSR5_CASE(11) CSR5_CASE(12) CSR5_CASE(13) CSR5_CASE(14) CSR5_CASE(15) CSR5_CASE(16)
         CSR5_CASE(17) CSR5_CASE(18) CSR5_CASE(19) CSR5_CASE(20) CSR5_CASE(21) CSR5_CASE(22)
         CSR5_CASE(23) CSR5_CASE(24) CSR5_CASE(25) CSR5_CASE(26) CSR5_CASE(27) CSR5_CASE(28)
         CSR5_CASE(29) CSR5_CASE(30) CSR5_CASE(31) CSR5_CASE(32)
+#endif
 #undef CSR5_CASE
     default: return launch_one<VT, 0, FUSED>(g, d, x, y, opt, s);
     }
