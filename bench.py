@@ -58,13 +58,15 @@ def parse_args():
     ap.add_argument("--sigma", type=int, default=-1)
     ap.add_argument("--mode", default="fused", choices=["fused", "two-pass"])
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"])
+    ap.add_argument("--x-window", default="auto", choices=["auto", "off", "force"])
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--scale", type=float, default=1.0, help="size factor of the synthetic stand-in (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device):
+def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device, scale: float = 1.0):
     """Row block `rank` of a global matrix made of `world` equally sized row blocks.  Returns
     (CsrMatrix-like with device tensors or numpy arrays, global n)."""
     from benchmark_spmv_using_csr5_amd import matrices as M
@@ -73,7 +75,7 @@ def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device):
         scale = int(workload[4:] or 20)
         return M.rmat_device(scale, 16, seed, rank, world, device), f"R-MAT scale {scale} EF16 (synthetic)"
     gen = {"scircuit": M.scircuit_like, "webbase": M.webbase_like, "nd24k": M.nd24k_like}[workload]
-    kw = {}
+    kw = {} if scale == 1.0 else {"scale": scale}
     if workload == "scircuit" and os.environ.get("CSR5_BENCH_ROWCAP"):  # experiment knob, not a config
         kw["row_cap"] = int(os.environ["CSR5_BENCH_ROWCAP"])
     mat = gen(seed=seed + 101 * rank, dtype=dtype, **kw)
@@ -113,7 +115,9 @@ def main():
     t_dtype = torch.float64 if dtype_name == "f64" else torch.float32
     vsize = 8 if dtype_name == "f64" else 4
 
-    mat, label = make_shard(args.workload, rank, world, args.seed, np_dtype, dev)
+    mat, label = make_shard(args.workload, rank, world, args.seed, np_dtype, dev, args.scale)
+    if args.scale != 1.0:
+        label += f" x{args.scale:g}"
     m, n, nnz = mat.m, mat.n, mat.nnz
     if isinstance(mat.row_ptr, np.ndarray):
         val, x_host = M.fill_values(nnz, n, np_dtype, seed=args.seed + 13, mode="int")
@@ -137,6 +141,7 @@ def main():
     assert A.setX(xd) == 0
     assert A.setSigma(args.sigma) == 0
     assert A.setSpmvMode(H.SPMV_FUSED if args.mode == "fused" else H.SPMV_TWO_PASS) == 0
+    assert A.setXWindow({"off": 0, "auto": 1, "force": 2}[args.x_window]) == 0
     A.warmup()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -219,6 +224,8 @@ def main():
                             f"{'one row block per GPU, x replicated by one RCCL broadcast' if world > 1 else 'single GPU'}",
                 "m_per_gpu": m, "n": n, "nnz_per_gpu": nnz, "sigma": info.sigma, "tiles": info.p,
                 "spmv_mode": args.mode, "launch": args.launch,
+                "lds_x_window": bool(info.x_window_active), "x_window_tiles": info.x_window_tiles,
+                "x_window_cover_pct": info.x_window_cover_pct,
                 "values": "rand()%10 integers (reference CLI data, exact in fp)",
                 "csr_to_csr5_ms": round(convert_ms, 3),
             },

@@ -29,6 +29,7 @@ F64 = 0
 F32 = 1
 OPT_SPMV_MODE = 1
 OPT_XCD_REMAP = 2
+OPT_X_WINDOW = 3
 
 
 class Csr5Info(C.Structure):
@@ -39,6 +40,7 @@ class Csr5Info(C.Structure):
         ("p", C.c_int), ("tail_partition_start", C.c_int), ("num_offsets", C.c_int),
         ("d_tile_ptr", C.c_void_p), ("d_tile_desc", C.c_void_p),
         ("d_offset_ptr", C.c_void_p), ("d_offset", C.c_void_p),
+        ("x_window_tiles", C.c_int), ("x_window_active", C.c_int), ("x_window_cover_pct", C.c_int),
         ("t_malloc_ms", C.c_double), ("t_tile_ptr_ms", C.c_double),
         ("t_tile_desc_ms", C.c_double), ("t_transpose_ms", C.c_double),
     ]

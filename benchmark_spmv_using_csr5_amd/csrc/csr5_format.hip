@@ -325,6 +325,69 @@ __global__ void __launch_bounds__(BLOCK) k_carry_meta(Geometry g, const int32_t 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// x-window selection (ours, not part of the reference format).  One wavefront per tile t < p-1:
+// the MEDIAN column index of the tile's omega*sigma elements (radix select over the bits of n, one
+// ballot-free DPP-less wave reduction per bit) centres a window of XWIN_BYTES / sizeof(vT) columns; if at least
+// XWIN_MIN_COVER_PCT % of the tile's elements fall inside it, carry_meta[t].w = window start + 1
+// (0 = no window); carry_cnt[p] counts such tiles and the spare slot carry_acc[p] the non-zeros
+// they cover.  The SpMV kernel stages that slice of x
+// in LDS and serves the in-window gathers from LDS (csr5_spmv.hip, XWIN variant).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d, OMEGA);
+    return v;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_tile_window(Geometry g, const int32_t *__restrict__ col,
+                                                       uint4 *__restrict__ carry_meta,
+                                                       uint32_t *__restrict__ enabled_counter,
+                                                       uint32_t *__restrict__ covered_counter,
+                                                       int XWIN_ELEMS)
+{
+    const int lane = threadIdx.x & (OMEGA - 1);
+    const int t = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (t >= g.p - 1)
+        return;
+    const int32_t *c = col + (size_t)t * g.tile_elems + lane;
+    int top = 0;
+    while ((1 << top) < g.n && top < 31)
+        top++;
+    unsigned prefix = 0;
+    int k = g.tile_elems / 2;
+    for (int bit = top - 1; bit >= 0; bit--) {
+        int cnt = 0;
+        for (int i = 0; i < g.sigma; i++) {
+            const unsigned v = (unsigned)c[i * OMEGA];
+            cnt += ((v >> (bit + 1)) == (prefix >> (bit + 1))) && !((v >> bit) & 1u);
+        }
+        cnt = wave_sum_i32(cnt);
+        if (k >= cnt) {
+            prefix |= 1u << bit;
+            k -= cnt;
+        }
+    }
+    int lo = (int)prefix - XWIN_ELEMS / 2;
+    const int hi_limit = g.n > XWIN_ELEMS ? g.n - XWIN_ELEMS : 0;
+    lo = lo < 0 ? 0 : (lo > hi_limit ? hi_limit : lo);
+    lo &= ~3;
+    int inside = 0;
+    for (int i = 0; i < g.sigma; i++)
+        inside += (unsigned)(c[i * OMEGA] - lo) < (unsigned)XWIN_ELEMS;
+    inside = wave_sum_i32(inside);
+    if (lane == 0) {
+        const bool on = inside * 100 >= g.tile_elems * XWIN_MIN_COVER_PCT;
+        reinterpret_cast<unsigned *>(&carry_meta[t])[3] = on ? (unsigned)lo + 1u : 0u;
+        if (on) {
+            atomicAdd(enabled_counter, 1u);
+            atomicAdd(covered_counter, (unsigned)inside);
+        }
+    }
+}
+
 __global__ void k_warmup(int *out)
 {
     __shared__ int s[OMEGA];
@@ -404,6 +467,17 @@ hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream
         return hipSuccess;
     hipLaunchKernelGGL(k_carry_meta, dim3(div_up(g.p, BLOCK)), dim3(BLOCK), 0, s, g, d.row_ptr,
                        d.tile_ptr, reinterpret_cast<uint4 *>(d.carry_meta));
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int value_size, hipStream_t s)
+{
+    if (g.p <= 1)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_tile_window, dim3(div_up(g.p - 1, WAVES_PER_BLOCK)), dim3(BLOCK), 0, s, g,
+                       d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.carry_cnt + g.p,
+                       reinterpret_cast<uint32_t *>((char *)d.carry_acc + (size_t)g.p * value_size),
+                       xwin_elems(value_size));
     return hipGetLastError();
 }
 

@@ -14,6 +14,9 @@ constexpr int BLOCK = OMEGA * WAVES_PER_BLOCK;
 constexpr int BIT_SS = 6;                     // bits of scansum_offset at omega = 64
 constexpr uint32_t ROW_MASK = 0x7FFFFFFFu;    // tile_ptr bit 31 = "tile has empty rows"
 constexpr int NUM_XCD = 8;
+constexpr int XWIN_BYTES = 4096;              // x-window staged in LDS per wavefront: 1024 fp32 / 512 fp64 columns
+constexpr int xwin_elems(int value_size) { return XWIN_BYTES / value_size; }
+constexpr int XWIN_MIN_COVER_PCT = 30;        // a tile gets a window if it covers at least this share
 
 // bits of y_offset for a given sigma: smallest b >= 1 with 2^b >= omega*sigma
 // (anonymouslib_cuda.h:121-124)
@@ -60,12 +63,14 @@ hipError_t launch_desc_offset(const Geometry &g, const DeviceArrays &d, hipStrea
 hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c,
                             hipStream_t s);
 hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream_t s);
+hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int value_size, hipStream_t s);
 hipError_t launch_warmup(hipStream_t s);
 
 // ---- SpMV (csr5_spmv.hip) ----
 struct SpmvOptions {
     int mode;        // CSR5HIP_OPT_SPMV_MODE
     int xcd_remap;   // CSR5HIP_OPT_XCD_REMAP
+    int x_window;    // resolved: 1 = launch the LDS x-window variant of the fused kernel
 };
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s);

@@ -220,7 +220,7 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
 // ---- tiles 0..p-2 ------------------------------------------------------------------------------
 // SIGMA > 0: compile-time sigma (loads hoisted into registers, flag walk fully unrolled).
 // SIGMA == 0: run-time sigma (any 1..32), same code shape, used for sigma < 4 and as a cross-check.
-template <typename VT, int SIGMA, bool FUSED>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
        const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
@@ -234,14 +234,15 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
                  "s"(offset_ptr), "s"(offset), "s"(calibrator), "s"(y), "s"(acc), "s"(cnt), "s"(meta),
                  "s"(g.nnz), "s"(g.p), "s"(g.m), "s"(g.sigma), "s"(g.tail_start), "s"(g.tile_elems),
                  "s"(g.bit_y), "s"(g.num_packet), "s"(tile_blocks), "s"(xcd_remap));
+    // dynamic LDS: the tail's product buffer (T elements) or, XWIN, one x-window per wavefront
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     int blk = blockIdx.x;
     if (blk >= tile_blocks) {
 #if defined(CSR5_ABLATE) && (CSR5_ABLATE & 4)
         return;
 #endif
-        __shared__ VT sprod[TAIL_MAX];
         tail_rows<VT, FUSED>(g, row_ptr, col, val, x, calibrator, y, blk - tile_blocks, acc, cnt,
-                             meta, tile_ptr, sprod);
+                             meta, tile_ptr, reinterpret_cast<VT *>(smem));
         return;
     }
     if (xcd_remap) {
@@ -315,13 +316,43 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         __builtin_amdgcn_sched_barrier(0);
         CSR5_TSTAMP(t, 1);
         VT xv[NREG];
+        if constexpr (XWIN) {
+            constexpr int XWIN_ELEMS = xwin_elems(sizeof(VT));
+            // LDS x-window: carry_meta[t].w - 1 = first column of a XWIN_ELEMS-wide slice of x that
+            // covers most of this tile's columns (chosen at conversion, k_tile_window).  In-window lanes
+            // gather from LDS (a ds_read costs a few cycles; a divergent global gather >= 34 clk per
+            // wave instruction even on L1 hits); the others gather from memory as before and are
+            // issued FIRST, so they overlap the window fetch.
+            VT *win = reinterpret_cast<VT *>(smem) + (threadIdx.x >> 6) * XWIN_ELEMS;
+            const int wlo = (int)__builtin_amdgcn_readfirstlane(mt.w) - 1;
+            if (wlo >= 0) {
+                // stage the window: 16 coalesced wave loads -> 16 LDS stores (private to this wave)
 #pragma unroll
-        for (int i = 0; i < SIGMA; i++)
+                for (int k = 0; k < XWIN_ELEMS / OMEGA; k++) {
+                    const int j = wlo + k * OMEGA + lane;
+                    win[k * OMEGA + lane] = x[j < g.n ? j : g.n - 1];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < SIGMA; i++) {
+                    const unsigned dlt = (unsigned)(c[i] - wlo);
+                    xv[i] = dlt < (unsigned)XWIN_ELEMS ? win[dlt] : x[c[i]];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < SIGMA; i++)
+                    xv[i] = x[c[i]];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++)
 #if defined(CSR5_ABLATE) && (CSR5_ABLATE & 1)
-            xv[i] = (VT)c[i]; // experiment build only: no x gather
+                xv[i] = (VT)c[i]; // experiment build only: no x gather
 #else
-            xv[i] = x[c[i]];
+                xv[i] = x[c[i]];
 #endif
+        }
         if constexpr (FUSED) {
             // the closing row of this tile spills mt.z <= 64 elements into tile t+1 and ends there:
             // gather x for exactly those lanes; the other lanes re-read x[0] (one cache line), so the
@@ -489,7 +520,7 @@ k_calibrate(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *__r
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------
-template <typename VT, int SIGMA, bool FUSED>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN>
 static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
                              const SpmvOptions &opt, hipStream_t s)
 {
@@ -498,7 +529,10 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
     const int tail_blocks = tail_rows_n > 0 ? (tail_rows_n + BLOCK - 1) / BLOCK : 0;
     if (tile_blocks + tail_blocks == 0)
         return hipSuccess;
-    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), 0, s,
+    size_t lds = (size_t)g.tile_elems * sizeof(VT); // tail product buffer
+    if (XWIN && lds < (size_t)WAVES_PER_BLOCK * XWIN_BYTES)
+        lds = (size_t)WAVES_PER_BLOCK * XWIN_BYTES;
+    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), lds, s,
                        g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x, d.tile_ptr,
                        d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, tile_blocks,
                        opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt,
@@ -516,10 +550,14 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
                                const SpmvOptions &opt, hipStream_t s)
 {
     switch (g.sigma) {
-#define CSR5_CASE(S) \
-    case S: return launch_one<VT, S, FUSED>(g, d, x, y, opt, s);
+#define CSR5_CASE(S)                                                                               \
+    case S:                                                                                        \
+        if constexpr (FUSED)                                                                       \
+            if (opt.x_window)                                                                      \
+                return launch_one<VT, S, FUSED, true>(g, d, x, y, opt, s);                         \
+        return launch_one<VT, S, FUSED, false>(g, d, x, y, opt, s);
 #ifdef CSR5_ABLATE // experiment builds: two instantiations only
-        CSR5_CASE(5) CSR5_CASE(16)
+        CSR5_CASE(5) CSR5_CASE(8) CSR5_CASE(16) CSR5_CASE(32)
 #else
         CSR5_CASE(4) CSR5_CASE(5) CSR5_CASE(6) CSR5_CASE(7) CSR5_CASE(8) CSR5_CASE(9) CSR5_CASE(10)
         CSR5_CASE(11) CSR5_CASE(12) CSR5_CASE(13) CSR5_CASE(14) CSR5_CASE(15) CSR5_CASE(16)
@@ -528,7 +566,7 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
         CSR5_CASE(29) CSR5_CASE(30) CSR5_CASE(31) CSR5_CASE(32)
 #endif
 #undef CSR5_CASE
-    default: return launch_one<VT, 0, FUSED>(g, d, x, y, opt, s);
+    default: return launch_one<VT, 0, FUSED, false>(g, d, x, y, opt, s);
     }
 }
 

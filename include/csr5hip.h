@@ -49,6 +49,9 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       1 = fused single launch (carries resolved in-kernel by the last
                                           arriving tile through device-scope atomics) */
 #define CSR5HIP_OPT_XCD_REMAP   2  /* 1 = contiguous tile ranges per XCD (default), 0 = round robin */
+#define CSR5HIP_OPT_X_WINDOW    3  /* fused mode: stage a per-tile slice of x in LDS and gather from it.
+                                      0 = off, 1 = auto (default: on when the per-tile 4-KB windows of x
+                                      chosen at conversion cover >= 70 % of the non-zeros), 2 = force */
 
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
@@ -69,6 +72,9 @@ typedef struct csr5hip_info {
     const uint32_t *d_tile_desc;   /* _csr5_partition_descriptor               [p*omega*num_packet]   */
     const int32_t  *d_offset_ptr;  /* _csr5_partition_descriptor_offset_pointer [p+1]                 */
     const int32_t  *d_offset;      /* _csr5_partition_descriptor_offset        [num_offsets]          */
+    int x_window_tiles;            /* tiles that were given an LDS x-window at conversion (ours)      */
+    int x_window_active;           /* 1 if spmv() launches the x-window variant                        */
+    int x_window_cover_pct;        /* share of the non-zeros (tiles 0..p-2) inside their tile's window */
     double t_malloc_ms, t_tile_ptr_ms, t_tile_desc_ms, t_transpose_ms; /* asCSR5 phase timers (:211-214) */
 } csr5hip_info;
 

@@ -27,7 +27,7 @@ def _device_csr(mat, val, dtype):
     return rp, ci, va
 
 
-def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1):
+def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
@@ -37,6 +37,8 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1):
     assert A.setX(xd) == 0
     assert A.setSigma(sigma) == 0
     assert A.setSpmvMode(mode) == 0
+    if xwin is not None:
+        assert A.setXWindow(xwin) == 0
     assert A.spmv(1.0, yd) == H.ANONYMOUSLIB_UNSUPPORTED_CSR_SPMV  # still CSR (anonymouslib_cuda.h:268-271)
     assert A.asCSR5() == 0
     arrays = A.csr5_arrays()
@@ -139,6 +141,58 @@ def test_fp32_path(oracle, mode):
         exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
         scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
         assert np.all(np.abs(ys[0] - exp) <= 1e-5 * np.maximum(scale, 1.0)), mat.name
+
+
+@pytest.mark.parametrize("xwin", [0, 2])
+def test_lds_x_window_variant(oracle, xwin):
+    """The LDS x-window variant of the fused kernel (forced on / forced off) must not change a bit:
+    same products, same summation order -- on matrices with and without column locality, fp64 and
+    fp32, one- and two-packet descriptors."""
+    for mat in zoo.small_zoo():
+        for sigma, dtype in ((4, np.float64), (16, np.float64), (24, np.float64), (12, np.float32)):
+            # integer data: exact, so bit-identical to the oracle whatever the window does
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=30, mode="int")
+            fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+            arrays, col_t, val_t, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=xwin)
+            _check_format(arrays, col_t, val_t, fmt)
+            assert np.array_equal(ys[0], _expected_y(oracle, fmt, mat, x, Y_POISON)), (mat.name, sigma, xwin)
+            # real data: within tolerance (rows spanning >= 3 tiles are summed in arrival order)
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=31, mode="real")
+            fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+            _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=xwin)
+            exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+            scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
+            tol = 1e-12 if dtype == np.float64 else 1e-5
+            assert np.all(np.abs(ys[0] - exp) <= tol * np.maximum(scale, 1.0)), (mat.name, sigma, xwin)
+
+
+def test_x_window_auto_selection():
+    """Banded matrix -> windows on; uniformly random columns -> off (csr5hip_info.x_window_*)."""
+    banded = M.nd24k_like(scale=0.02, dtype=np.float64)
+    rnd = zoo.small_zoo()[5]  # half-empty, uniform columns over 5000
+    for mat, expect in ((banded, 1), (rnd, 0)):
+        val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=2, mode="int")
+        rp, ci, va = _device_csr(mat, val, np.float64)
+        xd = torch.from_numpy(x).to(DEV)
+        A = H.anonymouslibHandle(mat.m, mat.n)
+        A.inputCSR(mat.nnz, rp, ci, va)
+        A.setX(xd)
+        A.setSigma(16)
+        A.setSpmvMode(H.SPMV_FUSED)
+        assert A.asCSR5() == 0
+        info = A.info()
+        assert info.x_window_active == expect, (mat.name, info.x_window_tiles, info.p)
+        yd = torch.zeros(mat.m, dtype=torch.float64, device=DEV)
+        assert A.spmv(1.0, yd) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), oracle_csr(mat, val, x))
+        A.destroy()
+        A.close()
+
+
+def oracle_csr(mat, val, x):
+    from oracle.csr5_oracle import Oracle
+    return Oracle().csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
 
 
 def test_runtime_sigma_kernel_and_small_sigma(oracle):
