@@ -274,3 +274,41 @@ def test_full_size_webbase_properties(oracle):
     for mode in (H.SPMV_TWO_PASS, H.SPMV_FUSED):
         _, _, _, ys = _run(mat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, mode, y0=0.0)
         assert np.array_equal(ys[0], ref)
+
+
+def test_cli_drop_in(tmp_path):
+    """`./spmv file.mtx` (csrc/main.cpp on top of include/anonymouslib_hip.h): the reference CLI's stdout
+    lines in the reference's order (CSR5_cuda/main.cu:30,119-384) and its self-check."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "benchmark_spmv_using_csr5_amd", "csrc", "spmv")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    mat = M.example_matrix()
+    mat.val[:] = 1.0
+    path = tmp_path / "example.mtx"
+    M.write_mtx(str(path), mat)
+    sym = tmp_path / "sym.mtx"
+    sym.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n4 4 5\n1 1\n2 1\n3 2\n4 4\n4 1\n")
+    for p, nnz in ((path, mat.nnz), (sym, 8)):
+        env = dict(os.environ, CSR5_SEED="7")
+        out = subprocess.run([exe, str(p)], capture_output=True, text=True, env=env, timeout=300)
+        assert out.returncode == 0, out.stderr
+        text = out.stdout
+        order = ["PRECISION = 64-bit Double Precision", f"--------------{p}--------------",
+                 f" ) nnz = {nnz}", "cpu sequential time = ", "Device [0] ", "omega = 64, sigma = ",
+                 "CSR->CSR5 malloc time = ", "CSR->CSR5 tile_ptr time = ", "CSR->CSR5 tile_desc time = ",
+                 "CSR->CSR5 transpose time = ", "CSR->CSR5 time = ", "CSR5-based SpMV time = ",
+                 "Check... PASS!"]
+        pos = -1
+        for token in order:
+            nxt = text.find(token, pos + 1)
+            assert nxt > pos, (token, text)
+            pos = nxt
+    assert subprocess.run([exe, str(tmp_path / "missing.mtx")], capture_output=True).returncode == 255  # -1
+    bad = tmp_path / "bad.mtx"
+    bad.write_text("not a banner\n")
+    assert subprocess.run([exe, str(bad)], capture_output=True).returncode == 254  # -2
+    cplx = tmp_path / "c.mtx"
+    cplx.write_text("%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1.0 0.0\n")
+    assert subprocess.run([exe, str(cplx)], capture_output=True).returncode == 253  # -3
