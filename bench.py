@@ -99,13 +99,21 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # CSR5_BENCH_SHARE_GPU=1 (test hook for 1-GPU boxes): every rank uses cuda:0 and the collectives go
+    # through gloo, so the multi-rank control flow can be exercised without N GPUs.  Never set by default.
+    share_gpu = os.environ.get("CSR5_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from benchmark_spmv_using_csr5_amd import handle as H
     from benchmark_spmv_using_csr5_amd import matrices as M

@@ -312,3 +312,32 @@ def test_cli_drop_in(tmp_path):
     cplx = tmp_path / "c.mtx"
     cplx.write_text("%%MatrixMarket matrix coordinate complex general\n1 1 1\n1 1 1.0 0.0\n")
     assert subprocess.run([exe, str(cplx)], capture_output=True).returncode == 253  # -3
+
+
+def test_large_rmat_size_independent_properties():
+    """BASELINE-size check (R-MAT scale 22, 67 M non-zeros, generated on the device): on integer data
+    every mode must agree exactly with each other and with an independent device-side CSR product
+    (torch.sparse, used as a checker only); asCSR5/asCSR must round-trip the caller's arrays."""
+    mat = M.rmat_device(22, 16, seed=5, rank=0, world=1, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    val = torch.randint(0, 10, (mat.nnz,), generator=g, device=DEV).to(torch.float64)
+    x = torch.randint(0, 10, (mat.n,), generator=g, device=DEV).to(torch.float64)
+    ref = torch.sparse_csr_tensor(mat.row_ptr.to(torch.int64), mat.col.to(torch.int64), val,
+                                  size=(mat.m, mat.n)) @ x
+    col0, val0 = mat.col.clone(), val.clone()
+    nonempty = (mat.row_ptr[1:] > mat.row_ptr[:-1])
+    for mode in (H.SPMV_TWO_PASS, H.SPMV_FUSED):
+        for sigma in (H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, 7):
+            A = H.anonymouslibHandle(mat.m, mat.n)
+            assert A.inputCSR(mat.nnz, mat.row_ptr, mat.col, val) == 0
+            assert A.setX(x) == 0 and A.setSigma(sigma) == 0 and A.setSpmvMode(mode) == 0
+            assert A.asCSR5() == 0
+            y = torch.full((mat.m,), -3.0, dtype=torch.float64, device=DEV)
+            assert A.spmv(1.0, y) == 0
+            assert A.spmv(1.0, y) == 0  # second call on the same y: no zeroing needed
+            torch.cuda.synchronize()
+            assert torch.equal(y[nonempty], ref[nonempty]), (mode, sigma)
+            assert A.destroy() == 0
+            torch.cuda.synchronize()
+            assert torch.equal(mat.col, col0) and torch.equal(val, val0)
+            A.close()
