@@ -21,7 +21,3 @@ run scircuit_twopass --mode two-pass
 run nd24k_fused --workload nd24k --steps 200
 run webbase_fused --workload webbase --steps 300
 run rmat22_fused --workload rmat22 --steps 50 --warmup 5
-# FETCH_SIZE calibration on a kernel of known traffic with the same access widths (dword + dwordx2 loads)
-d=$OUT/profiles_calib; mkdir -p $d
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $d/fetch -o p -- $REPO/scripts/probes/launch_floor > $d/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $d/write -o p -- $REPO/scripts/probes/launch_floor > $d/write.log 2>&1
