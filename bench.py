@@ -60,6 +60,7 @@ def parse_args():
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"])
     ap.add_argument("--x-window", default="auto", choices=["auto", "off", "force"])
     ap.add_argument("--xcd-remap", type=int, default=1, choices=[0, 1])
+    ap.add_argument("--lds-y", default="auto", choices=["auto", "off", "force"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the synthetic stand-in (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,6 +153,7 @@ def main():
     assert A.setSpmvMode(H.SPMV_FUSED if args.mode == "fused" else H.SPMV_TWO_PASS) == 0
     assert A.setXWindow({"off": 0, "auto": 1, "force": 2}[args.x_window]) == 0
     assert A.setOption(2, args.xcd_remap) == 0  # CSR5HIP_OPT_XCD_REMAP
+    assert A.setLdsY({"off": 0, "auto": 1, "force": 2}[args.lds_y]) == 0
     A.warmup()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

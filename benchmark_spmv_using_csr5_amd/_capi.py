@@ -30,6 +30,7 @@ F32 = 1
 OPT_SPMV_MODE = 1
 OPT_XCD_REMAP = 2
 OPT_X_WINDOW = 3
+OPT_LDS_Y = 4
 
 
 class Csr5Info(C.Structure):

@@ -90,7 +90,8 @@ struct csr5hip_handle_s {
     hipStream_t stream = nullptr;
     const void *x = nullptr;
     DeviceArrays d{};
-    SpmvOptions opt{0, 1, 0};
+    SpmvOptions opt{0, 1, 0, 0};
+    int ldsy_request = 1; // CSR5HIP_OPT_LDS_Y: 0 off, 1 auto (default), 2 force
     int xwin_request = 1; // CSR5HIP_OPT_X_WINDOW: 0 off, 1 auto (default), 2 force
     int xwin_tiles = 0;   // tiles that got a window at conversion
     long long xwin_covered = 0; // non-zeros inside those windows
@@ -121,6 +122,17 @@ static int xwin_decision(const csr5hip_handle_s *h)
         return 0;
     return (long long)h->xwin_covered * 100 >=
            (long long)(h->g.p - 1) * h->g.tile_elems * XWIN_AUTO_COVER_PCT;
+}
+
+// y segments through LDS (coalesced flush): pays when a tile holds many rows.  Measured on MI355X:
+// +3..5 % at <= 16 non-zeros per row (webbase-, R-MAT-like), -4..6 % at 399 per row (nd24k-like).
+static int ldsy_decision(const csr5hip_handle_s *h)
+{
+    if (h->ldsy_request == 2)
+        return 1;
+    if (h->ldsy_request != 1 || h->g.m <= 0)
+        return 0;
+    return (long long)h->g.nnz <= 32LL * h->g.m;
 }
 
 extern "C" {
@@ -232,6 +244,13 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         break;
     case CSR5HIP_OPT_XCD_REMAP:
         h->opt.xcd_remap = value ? 1 : 0;
+        break;
+    case CSR5HIP_OPT_LDS_Y:
+        if (value < 0 || value > 2)
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->ldsy_request = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5)
+            h->opt.lds_y = ldsy_decision(h);
         break;
     case CSR5HIP_OPT_X_WINDOW:
         if (value < 0 || value > 2)
@@ -350,6 +369,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
         h->t_transpose += now_ms() - t0;
     }
     h->opt.x_window = xwin_decision(h);
+    h->opt.lds_y = ldsy_decision(h);
     h->format = CSR5HIP_FORMAT_CSR5;
     return CSR5HIP_SUCCESS;
 }

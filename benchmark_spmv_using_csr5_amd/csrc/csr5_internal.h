@@ -71,6 +71,7 @@ struct SpmvOptions {
     int mode;        // CSR5HIP_OPT_SPMV_MODE
     int xcd_remap;   // CSR5HIP_OPT_XCD_REMAP
     int x_window;    // resolved: 1 = launch the LDS x-window variant of the fused kernel
+    int lds_y;       // resolved: 1 = compact y segments through LDS before storing them
 };
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s);

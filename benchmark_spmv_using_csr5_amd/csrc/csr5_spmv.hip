@@ -140,6 +140,23 @@ __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, const uint3
 // The first row's partial is a carry.
 constexpr int TAIL_MAX = OMEGA * CSR5HIP_MAX_SIGMA; // 2048
 
+// ---- per-wavefront LDS region of the tile kernel ---------------------------------------------------
+// LDSY: the y segments of a tile (<= T = 64*sigma values) are first written to LDS at their segment index
+// and then flushed with coalesced stores (one 512-B wave store per 64 rows instead of up to sigma
+// scattered, partially masked 8-byte stores).  Used while 4 waves * T * sizeof(vT) <= 32 KiB per
+// workgroup (fp64: sigma <= 16, fp32: sigma <= 32) so occupancy is not LDS-limited.
+// The x-window (XWIN) shares the region: the window is dead once the gathers have returned.
+template <typename VT, int SIGMA, bool LDSY_REQ>
+constexpr bool use_ldsy() { return LDSY_REQ && SIGMA > 0 && (size_t)OMEGA * SIGMA * sizeof(VT) <= 8192; }
+template <typename VT, int SIGMA, bool XWIN, bool LDSY_REQ>
+constexpr int wave_lds_bytes()
+{
+    int b = use_ldsy<VT, SIGMA, LDSY_REQ>() ? OMEGA * SIGMA * (int)sizeof(VT) : 0;
+    if (XWIN && b < XWIN_BYTES)
+        b = XWIN_BYTES;
+    return (b + 15) & ~15;
+}
+
 template <typename VT, bool FUSED>
 __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__restrict__ row_ptr,
                                           const int32_t *__restrict__ col,
@@ -220,7 +237,7 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
 // ---- tiles 0..p-2 ------------------------------------------------------------------------------
 // SIGMA > 0: compile-time sigma (loads hoisted into registers, flag walk fully unrolled).
 // SIGMA == 0: run-time sigma (any 1..32), same code shape, used for sigma < 4 and as a cross-check.
-template <typename VT, int SIGMA, bool FUSED, bool XWIN>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
        const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
@@ -323,7 +340,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
             // gather from LDS (a ds_read costs a few cycles; a divergent global gather >= 34 clk per
             // wave instruction even on L1 hits); the others gather from memory as before and are
             // issued FIRST, so they overlap the window fetch.
-            VT *win = reinterpret_cast<VT *>(smem) + (threadIdx.x >> 6) * XWIN_ELEMS;
+            VT *win = reinterpret_cast<VT *>(smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>());
             const int wlo = (int)__builtin_amdgcn_readfirstlane(mt.w) - 1;
             if (wlo >= 0) {
                 // stage the window: 16 coalesced wave loads -> 16 LDS stores (private to this wave)
@@ -420,20 +437,32 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     const int32_t *off_local = empty_rows ? offset + offset_ptr[t] : nullptr;
 
     CSR5_TSTAMP(t, 4);
+    constexpr bool LDSY = use_ldsy<VT, SIGMA, LDSY_REQ>();
+    VT *seg = reinterpret_cast<VT *>(smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>());
+    // store of the segment that owns slot `idx` of this tile's row range
+    auto put = [&](int idx, VT v) {
+        if constexpr (LDSY)
+            seg[idx] = v;
+        else
+            y_local[empty_rows ? off_local[idx] : idx] = v;
+    };
     bool direct = f0 && lane != 0;
     VT sum = product(0);
     VT first_sum = 0;
+    int stored_hi = 0; // 1 + highest slot this lane has stored
 #pragma unroll
     for (int i = 1; i < sigma; i++) {
         if ((flags >> (31 - i)) & 1u) {
-            if (direct)
+            if (direct) {
 #if defined(CSR5_ABLATE) && (CSR5_ABLATE & 2)
                 asm volatile("" ::"v"(sum), "v"(y_off)); // experiment build only: no y store
 #else
-                y_local[empty_rows ? off_local[y_off] : y_off] = sum;
+                put(y_off, sum);
 #endif
-            else
+                stored_hi = y_off + 1;
+            } else {
                 first_sum = sum;
+            }
             y_off += direct;
             direct = true;
             sum = 0;
@@ -463,31 +492,45 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         sum += S;
 
     CSR5_TSTAMP(t, 6);
+    const int last_present = 63 - __builtin_clzll(pmask);
+    bool closing_to_protocol = false; // this lane's last segment goes to the arrival protocol
     if constexpr (FUSED) {
         const bool close_carry = (mt.x >> 30) & 1u;
         const bool close_local = (mt.x >> 29) & 1u;
-        const bool lead_skip = (mt.x >> 28) & 1u;
-        const int last_present = 63 - __builtin_clzll(pmask);
         if (close_local && lane == last_present) // finish the closing row with its short spill
             sum += spill;
-        if (direct) {
-            if (close_carry && !close_local && lane == last_present)
-                carry_arrive(acc, cnt, tile_ptr, t + 1, mt_next_x & 0x00FFFFFFu, sum, y);
-            else
+        closing_to_protocol = direct && close_carry && !close_local && lane == last_present;
+    }
+    if (direct && !closing_to_protocol) {
 #if defined(CSR5_ABLATE) && (CSR5_ABLATE & 16)
-                asm volatile("" ::"v"(sum), "v"(y_off));
+        asm volatile("" ::"v"(sum), "v"(y_off));
 #else
-                y_local[empty_rows ? off_local[y_off] : y_off] = sum;
+        put(y_off, sum);
 #endif
+        stored_hi = y_off + 1;
+    }
+    if constexpr (LDSY) {
+        // flush: slots 0..nseg-1 are exactly the rows that start in this tile (minus a carried closing
+        // row); slot indices grow with the lane, so the highest storing lane knows nseg
+        const unsigned long long smask = __ballot(stored_hi != 0);
+        if (smask) {
+            const int nseg = __shfl(stored_hi, 63 - __builtin_clzll(smask), OMEGA);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int j = lane; j < nseg; j += OMEGA)
+                y_local[empty_rows ? off_local[j] : j] = seg[j];
         }
+    }
+    if constexpr (FUSED) {
+        const bool lead_skip = (mt.x >> 28) & 1u;
+        if (closing_to_protocol)
+            carry_arrive(acc, cnt, tile_ptr, t + 1, mt_next_x & 0x00FFFFFFu, sum, y);
         if (lane == 0 && !lead_skip) {
             const int slot = (int)mt.y;
             const uint32_t expected = (slot == t ? mt.x : meta[slot].x) & 0x00FFFFFFu;
             carry_arrive(acc, cnt, tile_ptr, slot, expected, direct ? first_sum : sum, y);
         }
     } else {
-        if (direct)
-            y_local[empty_rows ? off_local[y_off] : y_off] = sum;
         if (lane == 0)
             calibrator[t] = direct ? first_sum : sum;
     }
@@ -520,7 +563,7 @@ k_calibrate(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *__r
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------
-template <typename VT, int SIGMA, bool FUSED, bool XWIN>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ>
 static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
                              const SpmvOptions &opt, hipStream_t s)
 {
@@ -529,10 +572,10 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
     const int tail_blocks = tail_rows_n > 0 ? (tail_rows_n + BLOCK - 1) / BLOCK : 0;
     if (tile_blocks + tail_blocks == 0)
         return hipSuccess;
-    size_t lds = (size_t)g.tile_elems * sizeof(VT); // tail product buffer
-    if (XWIN && lds < (size_t)WAVES_PER_BLOCK * XWIN_BYTES)
-        lds = (size_t)WAVES_PER_BLOCK * XWIN_BYTES;
-    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), lds, s,
+    size_t lds = (size_t)g.tile_elems * sizeof(VT); // tail product buffer (tail workgroups)
+    if (lds < (size_t)WAVES_PER_BLOCK * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>())
+        lds = (size_t)WAVES_PER_BLOCK * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>();
+    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN, LDSY_REQ>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), lds, s,
                        g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x, d.tile_ptr,
                        d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, tile_blocks,
                        opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt,
@@ -554,8 +597,10 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
     case S:                                                                                        \
         if constexpr (FUSED)                                                                       \
             if (opt.x_window)                                                                      \
-                return launch_one<VT, S, FUSED, true>(g, d, x, y, opt, s);                         \
-        return launch_one<VT, S, FUSED, false>(g, d, x, y, opt, s);
+                return opt.lds_y ? launch_one<VT, S, FUSED, true, true>(g, d, x, y, opt, s)        \
+                                 : launch_one<VT, S, FUSED, true, false>(g, d, x, y, opt, s);      \
+        return opt.lds_y ? launch_one<VT, S, FUSED, false, true>(g, d, x, y, opt, s)               \
+                         : launch_one<VT, S, FUSED, false, false>(g, d, x, y, opt, s);
 #ifdef CSR5_ABLATE // experiment builds: two instantiations only
         CSR5_CASE(5) CSR5_CASE(8) CSR5_CASE(16) CSR5_CASE(32)
 #else
@@ -566,7 +611,7 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
         CSR5_CASE(29) CSR5_CASE(30) CSR5_CASE(31) CSR5_CASE(32)
 #endif
 #undef CSR5_CASE
-    default: return launch_one<VT, 0, FUSED, false>(g, d, x, y, opt, s);
+    default: return launch_one<VT, 0, FUSED, false, false>(g, d, x, y, opt, s);
     }
 }
 

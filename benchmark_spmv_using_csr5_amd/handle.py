@@ -107,6 +107,10 @@ class anonymouslibHandle:
         """0 = off, 1 = auto (default), 2 = force the LDS x-window variant of the fused kernel."""
         return self.setOption(_capi.OPT_X_WINDOW, value)
 
+    def setLdsY(self, value: int) -> int:
+        """0 = off, 1 = auto (default), 2 = force the LDS compaction of a tile's y segments."""
+        return self.setOption(_capi.OPT_LDS_Y, value)
+
     def info(self) -> _capi.Csr5Info:
         info = _capi.Csr5Info()
         err = self._lib.csr5hip_get_info(self._h, C.byref(info))

@@ -53,6 +53,10 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       0 = off, 1 = auto (default: on when the per-tile 4-KB windows of x
                                       chosen at conversion cover >= 70 % of the non-zeros), 2 = force */
 
+#define CSR5HIP_OPT_LDS_Y       4  /* compact a tile's y segments in LDS and flush them with coalesced
+                                      stores: 0 = off, 1 = auto (default: on at <= 32 non-zeros per row),
+                                      2 = force (applies while 64*sigma*sizeof(vT) <= 8 KiB) */
+
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
 /* Host-visible snapshot of the handle's private state (anonymouslib_cuda.h:27-52). */

@@ -1,12 +1,11 @@
 #!/bin/bash
-# quick loop: parity tests, then bench lines for both modes on the headline workload
+# quick loop: parity tests, then bench lines for the main workloads
+one() { python bench.py --no-cpu-baseline "$@" 2>&1 | tail -1 | python scripts/benchline.py; }
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -15
-for mode in fused two-pass; do
-  python bench.py --mode $mode --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$mode','sigma',d['config']['sigma'],'GFLOPS',d['value'],'us/step',round(d['ms_per_step']*1e3,3),'frac',d['roofline']['frac'])"
-done
-for s in 4 6 8 10 12 16 20; do
-  python bench.py --mode fused --sigma $s --no-cpu-baseline --steps 500 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('fused sigma',d['config']['sigma'],'GFLOPS',d['value'],'us',d['roofline']['launch_us'],'frac',d['roofline']['frac'])"
-done
-python bench.py --workload webbase --no-cpu-baseline --steps 300 2>&1 | tail -1 | cut -c1-400
-python bench.py --workload nd24k --no-cpu-baseline --steps 200 2>&1 | tail -1 | cut -c1-400
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
+one --steps 1000; one --steps 1000 --mode two-pass
+for s in 4 8 16; do one --steps 1000 --sigma $s; done
+one --workload webbase --steps 300
+one --workload nd24k --steps 200; one --workload nd24k --steps 200 --lds-y force
+one --workload nd24k --dtype f64 --steps 100
+one --workload rmat22 --steps 30 --warmup 3

@@ -27,7 +27,7 @@ def _device_csr(mat, val, dtype):
     return rp, ci, va
 
 
-def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None):
+def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
@@ -39,6 +39,8 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
     assert A.setSpmvMode(mode) == 0
     if xwin is not None:
         assert A.setXWindow(xwin) == 0
+    if ldsy is not None:
+        assert A.setLdsY(ldsy) == 0
     assert A.spmv(1.0, yd) == H.ANONYMOUSLIB_UNSUPPORTED_CSR_SPMV  # still CSR (anonymouslib_cuda.h:268-271)
     assert A.asCSR5() == 0
     arrays = A.csr5_arrays()
@@ -143,8 +145,9 @@ def test_fp32_path(oracle, mode):
         assert np.all(np.abs(ys[0] - exp) <= 1e-5 * np.maximum(scale, 1.0)), mat.name
 
 
+@pytest.mark.parametrize("ldsy", [0, 2])
 @pytest.mark.parametrize("xwin", [0, 2])
-def test_lds_x_window_variant(oracle, xwin):
+def test_lds_x_window_variant(oracle, xwin, ldsy):
     """The LDS x-window variant of the fused kernel (forced on / forced off) must not change a bit:
     same products, same summation order -- on matrices with and without column locality, fp64 and
     fp32, one- and two-packet descriptors."""
@@ -153,17 +156,29 @@ def test_lds_x_window_variant(oracle, xwin):
             # integer data: exact, so bit-identical to the oracle whatever the window does
             val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=30, mode="int")
             fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
-            arrays, col_t, val_t, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=xwin)
+            arrays, col_t, val_t, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=xwin, ldsy=ldsy)
             _check_format(arrays, col_t, val_t, fmt)
             assert np.array_equal(ys[0], _expected_y(oracle, fmt, mat, x, Y_POISON)), (mat.name, sigma, xwin)
             # real data: within tolerance (rows spanning >= 3 tiles are summed in arrival order)
             val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=31, mode="real")
             fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
-            _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=xwin)
+            _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=xwin, ldsy=ldsy)
             exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
             scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
             tol = 1e-12 if dtype == np.float64 else 1e-5
             assert np.all(np.abs(ys[0] - exp) <= tol * np.maximum(scale, 1.0)), (mat.name, sigma, xwin)
+
+
+@pytest.mark.parametrize("ldsy", [0, 2])
+def test_two_pass_lds_y_on_off(oracle, ldsy):
+    for mat in zoo.small_zoo():
+        for sigma in (4, 16, 32):
+            val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=41, mode="real")
+            fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+            _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_TWO_PASS, ldsy=ldsy)
+            exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+            scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
+            assert np.all(np.abs(ys[0] - exp) <= 1e-12 * np.maximum(scale, 1.0)), (mat.name, sigma, ldsy)
 
 
 def test_x_window_auto_selection():
