@@ -9,7 +9,10 @@
 namespace csr5 {
 
 constexpr int OMEGA = CSR5HIP_OMEGA;          // one wavefront per tile
-constexpr int WAVES_PER_BLOCK = 4;            // 256-thread workgroups
+#ifndef CSR5_WAVES_PER_BLOCK
+#define CSR5_WAVES_PER_BLOCK 2
+#endif
+constexpr int WAVES_PER_BLOCK = CSR5_WAVES_PER_BLOCK; // 128-thread workgroups: measured best on MI355X (2 vs 4 waves: +5 % nd24k-like, +0..7 % scircuit-like)
 constexpr int BLOCK = OMEGA * WAVES_PER_BLOCK;
 constexpr int BIT_SS = 6;                     // bits of scansum_offset at omega = 64
 constexpr uint32_t ROW_MASK = 0x7FFFFFFFu;    // tile_ptr bit 31 = "tile has empty rows"

@@ -143,8 +143,8 @@ constexpr int TAIL_MAX = OMEGA * CSR5HIP_MAX_SIGMA; // 2048
 // ---- per-wavefront LDS region of the tile kernel ---------------------------------------------------
 // LDSY: the y segments of a tile (<= T = 64*sigma values) are first written to LDS at their segment index
 // and then flushed with coalesced stores (one 512-B wave store per 64 rows instead of up to sigma
-// scattered, partially masked 8-byte stores).  Used while 4 waves * T * sizeof(vT) <= 32 KiB per
-// workgroup (fp64: sigma <= 16, fp32: sigma <= 32) so occupancy is not LDS-limited.
+// scattered, partially masked 8-byte stores).  Used while T * sizeof(vT) <= 8 KiB per wavefront
+// (fp64: sigma <= 16, fp32: sigma <= 32) so occupancy is not LDS-limited.
 // The x-window (XWIN) shares the region: the window is dead once the gathers have returned.
 template <typename VT, int SIGMA, bool LDSY_REQ>
 constexpr bool use_ldsy() { return LDSY_REQ && SIGMA > 0 && (size_t)OMEGA * SIGMA * sizeof(VT) <= 8192; }
@@ -601,8 +601,8 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
                                  : launch_one<VT, S, FUSED, true, false>(g, d, x, y, opt, s);      \
         return opt.lds_y ? launch_one<VT, S, FUSED, false, true>(g, d, x, y, opt, s)               \
                          : launch_one<VT, S, FUSED, false, false>(g, d, x, y, opt, s);
-#ifdef CSR5_ABLATE // experiment builds: two instantiations only
-        CSR5_CASE(5) CSR5_CASE(8) CSR5_CASE(16) CSR5_CASE(32)
+#if defined(CSR5_ABLATE) || defined(CSR5_FEW_SIGMAS) // experiment builds: few instantiations only
+        CSR5_CASE(4) CSR5_CASE(5) CSR5_CASE(8) CSR5_CASE(12) CSR5_CASE(16) CSR5_CASE(20) CSR5_CASE(32)
 #else
         CSR5_CASE(4) CSR5_CASE(5) CSR5_CASE(6) CSR5_CASE(7) CSR5_CASE(8) CSR5_CASE(9) CSR5_CASE(10)
         CSR5_CASE(11) CSR5_CASE(12) CSR5_CASE(13) CSR5_CASE(14) CSR5_CASE(15) CSR5_CASE(16)
