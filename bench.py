@@ -61,6 +61,9 @@ def parse_args():
     ap.add_argument("--x-window", default="auto", choices=["auto", "off", "force"])
     ap.add_argument("--xcd-remap", type=int, default=1, choices=[0, 1])
     ap.add_argument("--lds-y", default="auto", choices=["auto", "off", "force"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = one fixed-size row block per GPU (default); strong = ONE global matrix "
+                         "cut into nnz-balanced row blocks (BASELINE config: rmat24 over 8 GPUs)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the synthetic stand-in (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -68,18 +71,26 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device, scale: float = 1.0):
+def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device, scale: float = 1.0,
+               strong: bool = False):
     """Row block `rank` of a global matrix made of `world` equally sized row blocks.  Returns
     (CsrMatrix-like with device tensors or numpy arrays, global n)."""
     from benchmark_spmv_using_csr5_amd import matrices as M
 
     if workload.startswith("rmat"):
         scale = int(workload[4:] or 20)
-        return M.rmat_device(scale, 16, seed, rank, world, device), f"R-MAT scale {scale} EF16 (synthetic)"
+        return (M.rmat_device(scale, 16, seed, rank, world, device, strong=strong),
+                f"R-MAT scale {scale} EF16 (synthetic)")
     gen = {"scircuit": M.scircuit_like, "webbase": M.webbase_like, "nd24k": M.nd24k_like}[workload]
     kw = {} if scale == 1.0 else {"scale": scale}
     if workload == "scircuit" and os.environ.get("CSR5_BENCH_ROWCAP"):  # experiment knob, not a config
         kw["row_cap"] = int(os.environ["CSR5_BENCH_ROWCAP"])
+    if strong and world > 1:  # one global matrix, nnz-balanced row blocks (sharding.py)
+        from benchmark_spmv_using_csr5_amd import sharding as S
+        full = gen(seed=seed, dtype=dtype, **kw)
+        blk = S.extract_row_block(full.row_ptr, full.col, full.val, full.n,
+                                  S.partition_rows_by_nnz(full.row_ptr, world), rank)
+        return M.CsrMatrix(blk.m, blk.n, blk.row_ptr, blk.col, blk.val, full.name), full.name
     mat = gen(seed=seed + 101 * rank, dtype=dtype, **kw)
     if world > 1:  # spread the block's columns over the global column space of all blocks
         rng = np.random.default_rng(seed + 7 * rank)
@@ -125,7 +136,8 @@ def main():
     t_dtype = torch.float64 if dtype_name == "f64" else torch.float32
     vsize = 8 if dtype_name == "f64" else 4
 
-    mat, label = make_shard(args.workload, rank, world, args.seed, np_dtype, dev, args.scale)
+    mat, label = make_shard(args.workload, rank, world, args.seed, np_dtype, dev, args.scale,
+                            strong=args.scaling == "strong")
     if args.scale != 1.0:
         label += f" x{args.scale:g}"
     m, n, nnz = mat.m, mat.n, mat.nnz
@@ -227,7 +239,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 6),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": dtype_name,
             "data": "synthetic",

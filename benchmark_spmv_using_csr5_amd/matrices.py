@@ -262,10 +262,24 @@ class DeviceCsr:
 
 
 def rmat_device(scale: int, edge_factor: int, seed: int, rank: int, world: int, device, dtype=None,
-                abcd=(0.57, 0.19, 0.19, 0.05)) -> DeviceCsr:
-    """One row block per rank (weak scaling): every rank owns a 2^scale-row R-MAT block whose
-    columns are spread over the world * 2^scale global columns."""
+                abcd=(0.57, 0.19, 0.19, 0.05), strong: bool = False) -> DeviceCsr:
+    """weak (default): one row block per rank, every rank owns a 2^scale-row R-MAT block whose columns
+    are spread over the world * 2^scale global columns.
+    strong: ONE global 2^scale R-MAT (same seed on every rank), cut into `world` nnz-balanced row
+    blocks (sharding.partition_rows_by_nnz); the rank keeps its block with global columns."""
     import torch
+
+    if strong and world > 1:
+        from .sharding import partition_rows_by_nnz
+        full = rmat_device(scale, edge_factor, seed, 0, 1, device, abcd=abcd)
+        cuts = partition_rows_by_nnz(full.row_ptr.cpu().numpy(), world)
+        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+        a, b = int(full.row_ptr[lo]), int(full.row_ptr[hi])
+        row_ptr = (full.row_ptr[lo: hi + 1] - a).to(torch.int32).contiguous()
+        col = full.col[a:b].clone()
+        n = full.n
+        del full
+        return DeviceCsr(hi - lo, n, b - a, row_ptr, col, f"rmat{scale}(synthetic) rows {lo}:{hi}")
 
     n_local = 1 << scale
     ne = n_local * edge_factor
