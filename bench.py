@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=50)    # reference warm-up count (main.cu:85-89)
     ap.add_argument("--workload", default="scircuit")
     ap.add_argument("--dtype", default=None, choices=[None, "f64", "f32"])
-    ap.add_argument("--sigma", type=int, default=-1)
+    ap.add_argument("--sigma", default="-1", help="-1 = auto rule (default), N = fixed, 'tuned' = measured autotune")
     ap.add_argument("--mode", default="fused", choices=["fused", "two-pass"])
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"])
     ap.add_argument("--x-window", default="auto", choices=["auto", "off", "force"])
@@ -161,13 +161,18 @@ def main():
     A = H.anonymouslibHandle(m, n, dtype="float64" if dtype_name == "f64" else "float32")
     assert A.inputCSR(nnz, rp, ci, va) == 0
     assert A.setX(xd) == 0
-    assert A.setSigma(args.sigma) == 0
+    tuned = args.sigma == "tuned"
+    assert A.setSigma(-1 if tuned else int(args.sigma)) == 0
     assert A.setSpmvMode(H.SPMV_FUSED if args.mode == "fused" else H.SPMV_TWO_PASS) == 0
     assert A.setXWindow({"off": 0, "auto": 1, "force": 2}[args.x_window]) == 0
     assert A.setOption(2, args.xcd_remap) == 0  # CSR5HIP_OPT_XCD_REMAP
     assert A.setLdsY({"off": 0, "auto": 1, "force": 2}[args.lds_y]) == 0
     A.warmup()
     torch.cuda.synchronize()
+    if tuned:  # setup, outside every timed region (like asCSR5)
+        err, _, _ = A.autotuneSigma(yd)
+        assert err == 0, f"autotune -> {err}"
+        assert A.asCSR() == 0
     t0 = time.perf_counter()
     err = A.asCSR5()
     torch.cuda.synchronize()

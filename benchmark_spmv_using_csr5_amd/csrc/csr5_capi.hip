@@ -452,6 +452,65 @@ int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count)
     return CSR5HIP_SUCCESS;
 }
 
+// Measured sigma selection: what the reference's per-architecture
+// (r, s, t, u) tables (anonymouslib_cuda.h:297-313, anonymouslib_opencl.h:341-357) approximate, done on
+// the matrix itself.  For every candidate sigma: CSR -> CSR5, a few warm SpMVs, then `reps` SpMVs
+// replayed from one hipGraph and timed with HIP events; the fastest sigma stays converted.
+int csr5hip_autotune_sigma(csr5hip_handle h, void *d_y, int *best_sigma, double *best_us)
+{
+    if (!h || !d_y)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (h->format != CSR5HIP_FORMAT_CSR && h->format != CSR5HIP_FORMAT_CSR5)
+        return CSR5HIP_UNKOWN_FORMAT;
+    if (!h->x)
+        return CSR5HIP_INVALID_ARGUMENT;
+    int rc = csr5hip_as_csr(h);
+    if (rc != CSR5HIP_SUCCESS)
+        return rc;
+    static const int candidates[] = {4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
+    int best = 0;
+    double best_ms = 1e300;
+    for (int sigma : candidates) {
+        if ((long long)OMEGA * sigma > (long long)h->g.nnz && sigma != 4)
+            continue; // fewer non-zeros than one tile: nothing to choose
+        h->sigma_request = sigma;
+        rc = csr5hip_as_csr5(h);
+        if (rc != CSR5HIP_SUCCESS)
+            return rc;
+        for (int i = 0; i < 3 && rc == CSR5HIP_SUCCESS; i++)
+            rc = csr5hip_spmv(h, 1.0, d_y);
+        // size the timed batch to ~0.5 ms from one timed probe launch
+        double probe_ms = 0;
+        if (rc == CSR5HIP_SUCCESS) rc = csr5hip_timer_start(h);
+        if (rc == CSR5HIP_SUCCESS) rc = csr5hip_spmv(h, 1.0, d_y);
+        if (rc == CSR5HIP_SUCCESS) rc = csr5hip_timer_stop(h, &probe_ms);
+        int reps = probe_ms > 0 ? (int)(0.5 / probe_ms) : 50;
+        reps = reps < 5 ? 5 : (reps > 200 ? 200 : reps);
+        double ms = 0;
+        if (rc == CSR5HIP_SUCCESS) rc = csr5hip_spmv_repeat(h, 1.0, d_y, reps); // instantiate + warm
+        if (rc == CSR5HIP_SUCCESS) rc = csr5hip_timer_start(h);
+        if (rc == CSR5HIP_SUCCESS) rc = csr5hip_spmv_repeat(h, 1.0, d_y, reps);
+        if (rc == CSR5HIP_SUCCESS) rc = csr5hip_timer_stop(h, &ms);
+        if (rc != CSR5HIP_SUCCESS)
+            return rc;
+        ms /= reps;
+        if (ms < best_ms) {
+            best_ms = ms;
+            best = sigma;
+        }
+        rc = csr5hip_as_csr(h);
+        if (rc != CSR5HIP_SUCCESS)
+            return rc;
+    }
+    if (!best)
+        best = csr5hip_auto_sigma(h->g.m, h->g.nnz, h->value_type);
+    h->sigma_request = best;
+    rc = csr5hip_as_csr5(h);
+    if (best_sigma) *best_sigma = best;
+    if (best_us) *best_us = best_ms * 1e3;
+    return rc;
+}
+
 int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
 {
     if (!h || !info)

@@ -9,8 +9,8 @@
 //     (main.cu:330-347) so that every partial sum is exact;
 //   * protocol: 1 correctness run, 50 warm-up runs, NUM_RUN timed runs (main.cu:79-101), y zeroed once;
 //   * same stdout lines in the same order; check |y_ref - y| <= 0.01 |y_ref| per row (main.cu:366-384).
-// Additions: CSR5_SEED=<n> fixes the rand() seed (default stays time(NULL)); CSR5_SIGMA=<n> overrides
-// the auto-tuned sigma; CSR5_MODE=0|1 picks two-pass/fused SpMV; two extra report lines (hipGraph replay
+// Additions: CSR5_SEED=<n> fixes the rand() seed (default stays time(NULL)); CSR5_SIGMA=<n>|tuned overrides
+// the rule-based sigma (tuned = measured selection); CSR5_MODE=0|1 picks two-pass/fused SpMV; two extra report lines (hipGraph replay
 // time and algorithmic-bytes roofline fraction) are printed after the reference's lines.
 #include <cmath>
 #include <cstdio>
@@ -118,12 +118,23 @@ static int call_anonymouslib(int m, int n, int nnzA, int *csrRowPtrA, int *csrCo
     err = A.inputCSR(nnzA, d_csrRowPtrA, d_csrColIdxA, d_csrValA);
     err = A.setX(d_x); // once is enough
     const char *sig = getenv("CSR5_SIGMA");
-    A.setSigma(sig ? atoi(sig) : ANONYMOUSLIB_AUTO_TUNED_SIGMA);
+    const bool tune = sig && !strcmp(sig, "tuned");
+    A.setSigma(sig && !tune ? atoi(sig) : ANONYMOUSLIB_AUTO_TUNED_SIGMA);
     const char *mode = getenv("CSR5_MODE");
     if (mode)
         A.setOption(CSR5HIP_OPT_SPMV_MODE, atoi(mode));
 
     A.warmup();
+    if (tune) { // measured sigma selection (not in the reference): try every candidate, keep the fastest
+        int best = 0;
+        double us = 0;
+        A.setQuiet(true);
+        A.autotuneSigma(d_y, &best, &us);
+        A.asCSR();
+        A.setQuiet(false);
+        DEV_CHECK(csr5hip_memset(d_y, 0, (size_t)m * sizeof(VALUE_TYPE)));
+        cout << "autotuned sigma = " << best << " (" << us << " us per SpMV)" << endl;
+    }
 
     anonymouslib_timer asCSR5_timer;
     asCSR5_timer.start();

@@ -93,6 +93,12 @@ class anonymouslibHandle:
     def spmv_repeat(self, alpha, y, count: int) -> int:
         return self._lib.csr5hip_spmv_repeat(self._h, float(alpha), _ptr(y), int(count))
 
+    def autotuneSigma(self, y):
+        """Measured sigma selection: returns (err, sigma, us_per_spmv); leaves the matrix in CSR5."""
+        sigma, us = C.c_int(0), C.c_double(0.0)
+        err = self._lib.csr5hip_autotune_sigma(self._h, _ptr(y), C.byref(sigma), C.byref(us))
+        return err, sigma.value, us.value
+
     def setStream(self, stream) -> int:
         raw = getattr(stream, "cuda_stream", stream)
         return self._lib.csr5hip_set_stream(self._h, C.c_void_p(int(raw) if raw else None))

@@ -125,6 +125,10 @@ public:
     {
         return _h ? csr5hip_spmv_repeat(_h, (double)alpha, (void *)y, count) : _err;
     }
+    int autotuneSigma(ANONYMOUSLIB_VT *y, int *sigma = 0, double *us = 0)
+    {
+        return _h ? csr5hip_autotune_sigma(_h, (void *)y, sigma, us) : _err;
+    }
     int setOption(int option, int value) { return _h ? csr5hip_set_option(_h, option, value) : _err; }
     void setQuiet(bool q) { _quiet = q; }
     csr5hip_handle native() const { return _h; }

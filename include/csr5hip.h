@@ -112,6 +112,11 @@ int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count);
 /* destroy() -- anonymouslib_cuda.h:286-291 (== asCSR) */
 int csr5hip_destroy(csr5hip_handle h);
 
+/* Measured sigma selection (what ANONYMOUSLIB_AUTO_TUNED_SIGMA's per-architecture tables approximate,
+ * anonymouslib_cuda.h:297-313): converts with each candidate sigma, times a hipGraph batch of SpMVs into
+ * d_y and leaves the matrix in CSR5 with the fastest one.  Call after inputCSR + setX; d_y is overwritten. */
+int csr5hip_autotune_sigma(csr5hip_handle h, void *d_y, int *best_sigma, double *best_us);
+
 int csr5hip_set_option(csr5hip_handle h, int option, int value);
 int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info);
 /* sigma that setSigma(AUTO) would pick for (m, nnz, value_type) on gfx950 */

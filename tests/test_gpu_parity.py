@@ -356,3 +356,31 @@ def test_large_rmat_size_independent_properties():
             torch.cuda.synchronize()
             assert torch.equal(mat.col, col0) and torch.equal(val, val0)
             A.close()
+
+
+def test_autotune_sigma(oracle):
+    """Measured sigma selection: returns a supported sigma, leaves the handle in
+    CSR5, and the result is still exact."""
+    for mat in (M.scircuit_like(scale=0.2), M.nd24k_like(scale=0.02, dtype=np.float64), zoo.small_zoo()[2]):
+        val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=17, mode="int")
+        rp, ci, va = _device_csr(mat, val, np.float64)
+        xd = torch.from_numpy(x).to(DEV)
+        yd = torch.zeros(mat.m, dtype=torch.float64, device=DEV)
+        A = H.anonymouslibHandle(mat.m, mat.n)
+        A.inputCSR(mat.nnz, rp, ci, va)
+        A.setX(xd)
+        A.setSpmvMode(H.SPMV_FUSED)
+        err, sigma, us = A.autotuneSigma(yd)
+        assert err == 0 and sigma in (4, 5, 6, 8, 10, 12, 16, 20, 24, 32) and us > 0
+        info = A.info()
+        assert info.format == H.ANONYMOUSLIB_FORMAT_CSR5 and info.sigma == sigma
+        yd.fill_(5.0)
+        assert A.spmv(1.0, yd) == 0
+        torch.cuda.synchronize()
+        ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+        nonempty = np.diff(mat.row_ptr) > 0
+        assert np.array_equal(yd.cpu().numpy()[nonempty], ref[nonempty])
+        assert A.destroy() == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(ci.cpu().numpy(), mat.col)
+        A.close()
