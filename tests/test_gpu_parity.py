@@ -384,3 +384,45 @@ def test_autotune_sigma(oracle):
         torch.cuda.synchronize()
         assert np.array_equal(ci.cpu().numpy(), mat.col)
         A.close()
+
+
+def test_seeded_fuzz_against_oracle(oracle):
+    """Seeded fuzz: random shapes, row-length laws (incl. bursts of empty rows and hub rows), sigma, SpMV
+    mode, LDS options and dtype; integer data, so format and y must be bit-identical to the oracle."""
+    rng = np.random.default_rng(20260928)
+    for case in range(60):
+        m = int(rng.integers(1, 4000))
+        n = int(rng.integers(1, 6000))
+        law = case % 5
+        if law == 0:
+            lens = rng.integers(0, 12, size=m)
+        elif law == 1:
+            lens = np.floor(rng.pareto(1.3, size=m) * 2).astype(np.int64)
+        elif law == 2:
+            lens = rng.integers(0, 3, size=m) * (rng.random(m) < 0.3)
+            lens[rng.integers(0, m)] = int(rng.integers(500, 20000))
+        elif law == 3:
+            lens = np.where(rng.random(m) < 0.5, 0, rng.integers(1, 200, size=m))
+        else:
+            lens = np.full(m, int(rng.integers(1, 130)))
+        lens = np.minimum(lens, 30000)
+        if lens.sum() == 0:
+            lens[0] = 1
+        band = float(rng.choice([0.0, 0.5, 1.0]))
+        mat = M.csr_from_row_lengths(lens, n, rng, band=band, name=f"fuzz{case}")
+        dtype = np.float64 if case % 3 else np.float32
+        val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=1000 + case, mode="int")
+        if dtype == np.float32:  # keep every partial sum below 2^24 so fp32 stays exact
+            val = (val % 3).astype(np.float32)
+            x = (x % 3).astype(np.float32)
+        sigma = int(rng.choice([1, 2, 4, 5, 8, 11, 16, 17, 24, 32]))
+        mode = int(rng.integers(0, 2))
+        xwin = int(rng.choice([0, 2])) if mode == H.SPMV_FUSED else None
+        ldsy = int(rng.choice([0, 2]))
+        fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+        arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, dtype=dtype, xwin=xwin, ldsy=ldsy, repeat=2)
+        _check_format(arrays, col_t, val_t, fmt)
+        exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+        for y in ys:
+            assert np.array_equal(y, exp), (case, m, n, sigma, mode, xwin, ldsy, dtype,
+                                            np.flatnonzero(y != exp)[:5])
