@@ -90,7 +90,7 @@ struct csr5hip_handle_s {
     hipStream_t stream = nullptr;
     const void *x = nullptr;
     DeviceArrays d{};
-    SpmvOptions opt{0, 1, 0, 0};
+    SpmvOptions opt{1, 1, 0, 0}; // fused single-launch SpMV, XCD-contiguous tile ranges
     int ldsy_request = 1; // CSR5HIP_OPT_LDS_Y: 0 off, 1 auto (default), 2 force
     int xwin_request = 1; // CSR5HIP_OPT_X_WINDOW: 0 off, 1 auto (default), 2 force
     int xwin_tiles = 0;   // tiles that got a window at conversion

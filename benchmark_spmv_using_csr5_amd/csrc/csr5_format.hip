@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(BLOCK) k_transpose(Geometry g, const uint32_t 
 // Fused-SpMV helper (not part of the reference format): who resolves the partial sums that a tile
 // boundary cuts.  One uint4 per tile t (tail = tile p-1):
 //   .x bits 0..23 : fallback protocol only -- number of arrivals expected at slot t (t = run head)
+//      bit 27 HAS_CLOSING: (run heads) the closing segment of tile t-1 is one of the arrivals
 //      bit 28 LEAD_SKIP  : the leading partial of tile t is recomputed by tile t-1; do not emit it
 //      bit 29 CLOSE_LOCAL: the closing segment of tile t continues for .z <= 64 elements into tile
 //                          t+1 and ends there; tile t reads those elements itself and stores y
@@ -299,8 +300,10 @@ __global__ void __launch_bounds__(BLOCK) k_carry_meta(Geometry g, const int32_t 
             reinterpret_cast<unsigned *>(&carry_meta[e])[1] = (unsigned)t; // .y of the run members
         }
         unsigned expected = (unsigned)(e - t + 1);
-        if ((long long)row_ptr[r] != (long long)t * T)
+        if ((long long)row_ptr[r] != (long long)t * T) {
             expected += 1; // row r starts inside tile t-1, whose closing segment also arrives
+            meta.x |= 1u << 27;
+        }
         meta.x |= expected;
     }
     if (t + 1 < g.p) {

@@ -91,21 +91,24 @@ __device__ __forceinline__ VT lane_above(VT v)
 //      into the slot (0 = empty, the memset state); whoever gets a non-zero word back is second, adds
 //      the two partials (a+b == b+a: bit-reproducible), stores y and re-arms the slot.  (Only the
 //      all-ones NaN payload would collide with "empty"; arithmetic never produces it.)
-//   >2 rows spanning several tiles: returning device-scope atomic add into the slot, then an arrival
-//      counter; the add is waited for (its result feeds an asm barrier) before the counter is bumped,
-//      so when the counter reaches `expected` every add has been performed; the last arriver swaps
-//      the total out (re-arming the slot) and is the only writer of y[r].
+//   >2 rows spanning several tiles: every party parks its partial in its OWN word (leading partial of
+//      tile t -> calibrator[t], closing partial of tile h-1 -> acc[h]) with a write-through agent-scope
+//      store, drains it (s_waitcnt vmcnt(0)), then bumps the arrival counter.  The last arriver reads the
+//      words back with agent-scope loads and adds them IN TILE ORDER -- the same association as the
+//      two-pass k_calibrate, so the result is bit-reproducible -- stores y and re-arms the counter.
 // All slot accesses are device-scope atomics: performed at the memory side, coherent across the 8 XCD
 // L2s, no dependence on dispatch order or placement, nobody ever waits for another workgroup.
 template <typename VT>
-__device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, const uint32_t *tile_ptr,
-                                             int slot, uint32_t expected, VT v, VT *y)
+__device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, VT *calibrator,
+                                             const uint32_t *tile_ptr, int slot, uint32_t meta_x,
+                                             int my_tile, bool is_closing, VT v, VT *y)
 {
 #if defined(CSR5_ABLATE) && (CSR5_ABLATE & 8)
     asm volatile("" ::"v"(v), "s"(slot));
     return;
 #endif
     using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
+    const uint32_t expected = meta_x & 0x00FFFFFFu;
     VT *row_y = y + (tile_ptr[slot] & ROW_MASK);
     if (expected == 1u) {
         *row_y = v;
@@ -118,16 +121,27 @@ __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, const uint3
             __hip_atomic_store(s, (bits_t)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
-        VT old = __hip_atomic_fetch_add(&acc[slot], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // order: the add must have been performed before the arrival is counted
-        asm volatile("" ::"v"(old) : "memory");
+        // park this party's partial in its own word, write-through, and drain it before arriving
+        bits_t *mine = reinterpret_cast<bits_t *>(is_closing ? &acc[slot] : &calibrator[my_tile]);
+        __hip_atomic_store(mine, __builtin_bit_cast(bits_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t arrived =
             __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         if (arrived == expected) {
-            const bits_t raw = __hip_atomic_exchange(reinterpret_cast<bits_t *>(&acc[slot]), (bits_t)0,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool has_closing = (meta_x >> 27) & 1u;
+            const int len = (int)expected - (has_closing ? 1 : 0);
+            VT total = 0;
+            if (has_closing)
+                total = __builtin_bit_cast(VT, __hip_atomic_load(reinterpret_cast<bits_t *>(&acc[slot]),
+                                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            for (int k = 0; k < len; k++) {
+                const VT c = __builtin_bit_cast(
+                    VT, __hip_atomic_load(reinterpret_cast<bits_t *>(&calibrator[slot + k]), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT));
+                total = (k == 0 && !has_closing) ? c : total + c;
+            }
             __hip_atomic_store(&cnt[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *row_y = __builtin_bit_cast(VT, raw);
+            *row_y = total;
         }
     }
 }
@@ -225,7 +239,7 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
         if constexpr (FUSED) {
             const uint4 mt = meta[g.p - 1];
             if (!((mt.x >> 28) & 1u)) // else tile p-2 already owns this row (short spill)
-                carry_arrive(acc, cnt, tile_ptr, (int)mt.y, meta[mt.y].x & 0x00FFFFFFu, sum, y);
+                carry_arrive(acc, cnt, calibrator, tile_ptr, (int)mt.y, meta[mt.y].x, g.p - 1, false, sum, y);
         } else {
             calibrator[g.p - 1] = sum;
         }
@@ -424,7 +438,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         s = wave_sum(s);
         if (lane == 0) {
             if constexpr (FUSED) // member of a multi-tile run: expected count lives at the run head
-                carry_arrive(acc, cnt, tile_ptr, (int)mt.y, meta[mt.y].x & 0x00FFFFFFu, s, y);
+                carry_arrive(acc, cnt, calibrator, tile_ptr, (int)mt.y, meta[mt.y].x, t, false, s, y);
             else
                 calibrator[t] = s;
         }
@@ -524,11 +538,11 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     if constexpr (FUSED) {
         const bool lead_skip = (mt.x >> 28) & 1u;
         if (closing_to_protocol)
-            carry_arrive(acc, cnt, tile_ptr, t + 1, mt_next_x & 0x00FFFFFFu, sum, y);
+            carry_arrive(acc, cnt, calibrator, tile_ptr, t + 1, mt_next_x, t, true, sum, y);
         if (lane == 0 && !lead_skip) {
             const int slot = (int)mt.y;
-            const uint32_t expected = (slot == t ? mt.x : meta[slot].x) & 0x00FFFFFFu;
-            carry_arrive(acc, cnt, tile_ptr, slot, expected, direct ? first_sum : sum, y);
+            const uint32_t head_meta = slot == t ? mt.x : meta[slot].x;
+            carry_arrive(acc, cnt, calibrator, tile_ptr, slot, head_meta, t, false, direct ? first_sum : sum, y);
         }
     } else {
         if (lane == 0)

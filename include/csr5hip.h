@@ -45,9 +45,11 @@ extern "C" {
 typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
 
 /* csr5hip_set_option keys */
-#define CSR5HIP_OPT_SPMV_MODE   1  /* 0 = two-pass (tiles+tail, then calibrate; bit-reproducible) [default]
-                                      1 = fused single launch (carries resolved in-kernel by the last
-                                          arriving tile through device-scope atomics) */
+#define CSR5HIP_OPT_SPMV_MODE   1  /* 0 = two-pass (tiles+tail, then calibrate; same summation order as the
+                                          reference's three-kernel scheme)
+                                      1 = fused single launch [default] (cut rows are finished by the owning
+                                          tile or, for long rows, by the last arriving tile; no second launch).
+                                      Both modes are bit-reproducible run to run. */
 #define CSR5HIP_OPT_XCD_REMAP   2  /* 1 = contiguous tile ranges per XCD (default), 0 = round robin */
 #define CSR5HIP_OPT_X_WINDOW    3  /* fused mode: stage a per-tile slice of x in LDS and gather from it.
                                       0 = off, 1 = auto (default: on when the per-tile 4-KB windows of x
