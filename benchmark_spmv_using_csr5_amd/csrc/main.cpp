@@ -11,7 +11,8 @@
 //   * same stdout lines in the same order; check |y_ref - y| <= 0.01 |y_ref| per row (main.cu:366-384).
 // Additions: CSR5_SEED=<n> fixes the rand() seed (default stays time(NULL)); CSR5_SIGMA=<n>|tuned overrides
 // the rule-based sigma (tuned = measured selection); CSR5_MODE=0|1 picks two-pass/fused SpMV; two extra report lines (hipGraph replay
-// time and algorithmic-bytes roofline fraction) are printed after the reference's lines.
+// time and algorithmic-bytes roofline fraction) are printed after the reference's lines; CSR5_RESULTS=<csv>
+// appends "file,GFlops,GB/s,roof fraction,m,nnz,sigma,tiles,us" per run (the avx512 backend's results.csv, extended).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -86,6 +87,8 @@ static bool parse_size(FILE *f, int &m, int &n, int &nz)
     }
     return false;
 }
+
+static const char *g_filename = "";
 
 static int call_anonymouslib(int m, int n, int nnzA, int *csrRowPtrA, int *csrColIdxA,
                              VALUE_TYPE *csrValA, VALUE_TYPE *x, VALUE_TYPE *y, VALUE_TYPE alpha)
@@ -179,6 +182,20 @@ static int call_anonymouslib(int m, int n, int nnzA, int *csrRowPtrA, int *csrCo
              << " ms. GFlops = " << gflop / (1.0e+6 * t) << " GFlops." << endl;
         cout << "Algorithmic bytes = " << b_alg * 1e-6 << " MB. Achieved = " << b_alg / (1.0e+6 * t)
              << " GB/s = " << 100.0 * b_alg / (1.0e+6 * t) / 8000.0 << " % of the 8 TB/s HBM3E roof." << endl;
+
+        // batch harness (CSR5_avx512/main.cpp:105-110 appends "file,GFlops" to
+        // results.csv): CSR5_RESULTS=<path> appends one line per run with the roofline columns added
+        if (const char *res = getenv("CSR5_RESULTS")) {
+            csr5hip_info info;
+            csr5hip_get_info(A.native(), &info);
+            if (FILE *fout = fopen(res, "a")) {
+                fprintf(fout, "%s,%f,%f,%f,%d,%d,%d,%d,%f\n", g_filename, gflop / (1.0e+6 * t),
+                        b_alg / (1.0e+6 * t), b_alg / (1.0e+6 * t) / 8000.0, m, nnzA, info.sigma, info.p, t * 1e3);
+                fclose(fout);
+            } else {
+                cout << "Writing results fails." << endl;
+            }
+        }
     }
 
     A.destroy();
@@ -210,6 +227,7 @@ int main(int argc, char **argv)
         return -1;
     }
     const char *filename = argv[1];
+    g_filename = filename;
     cout << "--------------" << filename << "--------------" << endl;
 
     FILE *f = fopen(filename, "r");

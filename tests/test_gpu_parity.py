@@ -305,7 +305,7 @@ def test_cli_drop_in(tmp_path):
     sym = tmp_path / "sym.mtx"
     sym.write_text("%%MatrixMarket matrix coordinate pattern symmetric\n4 4 5\n1 1\n2 1\n3 2\n4 4\n4 1\n")
     for p, nnz in ((path, mat.nnz), (sym, 8)):
-        env = dict(os.environ, CSR5_SEED="7")
+        env = dict(os.environ, CSR5_SEED="7", CSR5_RESULTS=str(tmp_path / "results.csv"))
         out = subprocess.run([exe, str(p)], capture_output=True, text=True, env=env, timeout=300)
         assert out.returncode == 0, out.stderr
         text = out.stdout
@@ -319,6 +319,8 @@ def test_cli_drop_in(tmp_path):
             nxt = text.find(token, pos + 1)
             assert nxt > pos, (token, text)
             pos = nxt
+    rows = (tmp_path / "results.csv").read_text().strip().splitlines()
+    assert len(rows) == 2 and rows[0].startswith(str(path) + ",") and len(rows[0].split(",")) == 9
     assert subprocess.run([exe, str(tmp_path / "missing.mtx")], capture_output=True).returncode == 255  # -1
     bad = tmp_path / "bad.mtx"
     bad.write_text("not a banner\n")
