@@ -340,6 +340,9 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         VT v[NREG];
 #pragma unroll
         for (int i = 0; i < SIGMA; i++) {
+            // plain loads on purpose: a non-temporal hint on the streams helps only when the matrix is far
+            // larger than the 256-MiB Infinity Cache (R-MAT 22: +5 %) and costs 18-25 % when it is not
+            // (R-MAT 20, nd24k-like), because repeated SpMVs then re-stream from HBM
             c[i] = ct[i * OMEGA];
             v[i] = vt[i * OMEGA];
         }
