@@ -329,13 +329,14 @@ __global__ void __launch_bounds__(BLOCK) k_carry_meta(Geometry g, const int32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// x-window selection (ours, not part of the reference format).  One wavefront per tile t < p-1:
-// the MEDIAN column index of the tile's omega*sigma elements (radix select over the bits of n, one
-// ballot-free DPP-less wave reduction per bit) centres a window of XWIN_BYTES / sizeof(vT) columns; if at least
-// XWIN_MIN_COVER_PCT % of the tile's elements fall inside it, carry_meta[t].w = window start + 1
-// (0 = no window); carry_cnt[p] counts such tiles and the spare slot carry_acc[p] the non-zeros
-// they cover.  The SpMV kernel stages that slice of x
-// in LDS and serves the in-window gathers from LDS (csr5_spmv.hip, XWIN variant).
+// x-window selection (ours, not part of the reference format).  One wavefront per tile t < p-1.
+// Candidates = the 64 column indices of the tile's first step (one per lane, a uniform sample of the
+// tile).  Each candidate centres a window of XWIN_BYTES / sizeof(vT) columns and is scored by how many
+// of the 64 samples fall inside it (64 readlane broadcasts); the best-scoring candidate is then
+// verified against ALL omega*sigma elements.  If at least XWIN_MIN_COVER_PCT % of them fall inside,
+// carry_meta[t].w = window start + 1 (0 = no window); carry_cnt[p] counts such tiles and the spare slot
+// carry_acc[p] the non-zeros they cover.  The SpMV kernel stages that slice of x in LDS and serves the
+// in-window gathers from LDS (csr5_spmv.hip, XWIN variant).  Two passes over the tile's columns.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wave_sum_i32(int v)
 {
@@ -356,27 +357,26 @@ __global__ void __launch_bounds__(BLOCK) k_tile_window(Geometry g, const int32_t
     if (t >= g.p - 1)
         return;
     const int32_t *c = col + (size_t)t * g.tile_elems + lane;
-    int top = 0;
-    while ((1 << top) < g.n && top < 31)
-        top++;
-    unsigned prefix = 0;
-    int k = g.tile_elems / 2;
-    for (int bit = top - 1; bit >= 0; bit--) {
-        int cnt = 0;
-        for (int i = 0; i < g.sigma; i++) {
-            const unsigned v = (unsigned)c[i * OMEGA];
-            cnt += ((v >> (bit + 1)) == (prefix >> (bit + 1))) && !((v >> bit) & 1u);
-        }
-        cnt = wave_sum_i32(cnt);
-        if (k >= cnt) {
-            prefix |= 1u << bit;
-            k -= cnt;
-        }
-    }
-    int lo = (int)prefix - XWIN_ELEMS / 2;
     const int hi_limit = g.n > XWIN_ELEMS ? g.n - XWIN_ELEMS : 0;
-    lo = lo < 0 ? 0 : (lo > hi_limit ? hi_limit : lo);
-    lo &= ~3;
+    auto window_of = [&](int centre) {
+        int lo = centre - XWIN_ELEMS / 2;
+        lo = lo < 0 ? 0 : (lo > hi_limit ? hi_limit : lo);
+        return lo & ~3;
+    };
+    // score every lane's candidate on the 64 samples
+    const int sample = c[0];
+    const int my_lo = window_of(sample);
+    int score = 0;
+    for (int j = 0; j < OMEGA; j++)
+        score += (unsigned)(__shfl(sample, j, OMEGA) - my_lo) < (unsigned)XWIN_ELEMS;
+    // best candidate: highest score, lowest lane on ties (deterministic)
+    int best = score * OMEGA + (OMEGA - 1 - lane);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(best, d, OMEGA);
+        best = o > best ? o : best;
+    }
+    const int lo = __shfl(my_lo, OMEGA - 1 - (best % OMEGA), OMEGA);
     int inside = 0;
     for (int i = 0; i < g.sigma; i++)
         inside += (unsigned)(c[i * OMEGA] - lo) < (unsigned)XWIN_ELEMS;
