@@ -427,3 +427,27 @@ def test_seeded_fuzz_against_oracle(oracle):
         for y in ys:
             assert np.array_equal(y, exp), (case, m, n, sigma, mode, xwin, ldsy, dtype,
                                             np.flatnonzero(y != exp)[:5])
+
+
+def test_multi_tile_rows_stress_cross_xcd_protocol(oracle):
+    """Every row spans many tiles (the > 2-party arrival protocol, all 8 XCDs busy): on those rows the
+    fused result must be bit-identical to the two-pass result (same partials, same summation order by
+    construction) on REAL data, launch after launch -- a stale or torn cross-workgroup read would show
+    up here."""
+    rng = np.random.default_rng(77)
+    lens = rng.integers(1500, 9000, size=260)
+    lens[::7] = rng.integers(1, 40, size=lens[::7].size)  # some short rows in between
+    mat = M.csr_from_row_lengths(lens, 50_000, rng, band=0.0, name="long-rows")
+    for dtype, sigma in ((np.float64, 4), (np.float64, 16), (np.float32, 8)):
+        val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=3, mode="real")
+        _, _, _, y2 = _run(mat, val, x, sigma, H.SPMV_TWO_PASS, dtype=dtype)
+        _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, repeat=25)
+        long_rows = np.diff(mat.row_ptr) > 64 * sigma * 2  # certainly resolved by the arrival protocol
+        for k, y in enumerate(ys):
+            assert np.array_equal(y[long_rows], y2[0][long_rows]), (dtype, sigma, k)
+            assert np.array_equal(y, ys[0]), (dtype, sigma, k)
+        fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+        exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+        scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
+        tol = 1e-12 if dtype == np.float64 else 2e-5
+        assert np.all(np.abs(y2[0] - exp) <= tol * np.maximum(scale, 1.0))
