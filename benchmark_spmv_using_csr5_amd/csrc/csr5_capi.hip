@@ -90,12 +90,12 @@ struct csr5hip_handle_s {
     hipStream_t stream = nullptr;
     const void *x = nullptr;
     DeviceArrays d{};
-    SpmvOptions opt{1, 1, 0, 0}; // fused single-launch SpMV, XCD-contiguous tile ranges
+    SpmvOptions opt{1, 1, 0, 0, 0}; // fused single-launch SpMV, XCD-contiguous tile ranges
     int ldsy_request = 1; // CSR5HIP_OPT_LDS_Y: 0 off, 1 auto (default), 2 force
     int xwin_request = 1; // CSR5HIP_OPT_X_WINDOW: 0 off, 1 auto (default), 2 force
     int xwin_tiles = 0;   // tiles that got a window at conversion
     long long xwin_covered = 0; // non-zeros inside those windows
-    Buffer b_tile_ptr, b_tile_desc, b_offset_ptr, b_offset, b_calibrator, b_acc, b_cnt, b_meta;
+    Buffer b_tile_ptr, b_tile_desc, b_offset_ptr, b_offset, b_calibrator, b_acc, b_cnt, b_meta, b_counters;
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::unordered_map<GraphKey, hipGraphExec_t, GraphKeyHash> graphs;
@@ -160,7 +160,7 @@ int csr5hip_free(csr5hip_handle h)
         return CSR5HIP_INVALID_ARGUMENT;
     h->drop_graphs();
     for (Buffer *b : {&h->b_tile_ptr, &h->b_tile_desc, &h->b_offset_ptr, &h->b_offset,
-                      &h->b_calibrator, &h->b_acc, &h->b_cnt, &h->b_meta})
+                      &h->b_calibrator, &h->b_acc, &h->b_cnt, &h->b_meta, &h->b_counters})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -290,6 +290,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
     h->num_offsets = 0;
     h->xwin_tiles = 0;
     h->xwin_covered = 0;
+    h->opt.long_runs = 0;
     h->t_malloc = h->t_tile_ptr = h->t_tile_desc = h->t_transpose = 0;
     h->drop_graphs();
     hipStream_t s = h->stream;
@@ -304,6 +305,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
     HIP_TRY(h->b_acc.reserve(p1 * h->vsize()));
     HIP_TRY(h->b_cnt.reserve(p1 * 4));
     HIP_TRY(h->b_meta.reserve(p1 * 16));
+    HIP_TRY(h->b_counters.reserve(16));
     h->d.tile_ptr = (uint32_t *)h->b_tile_ptr.ptr;
     h->d.tile_desc = (uint32_t *)h->b_tile_desc.ptr;
     h->d.offset_ptr = (int32_t *)h->b_offset_ptr.ptr;
@@ -311,12 +313,14 @@ int csr5hip_as_csr5(csr5hip_handle h)
     h->d.carry_acc = h->b_acc.ptr;
     h->d.carry_cnt = (uint32_t *)h->b_cnt.ptr;
     h->d.carry_meta = (uint32_t *)h->b_meta.ptr;
+    h->d.counters = (uint32_t *)h->b_counters.ptr;
     h->d.offset = nullptr;
     HIP_TRY(hipMemsetAsync(h->d.tile_desc, 0, desc_words * 4, s));
     HIP_TRY(hipMemsetAsync(h->d.offset_ptr, 0, p1 * 4, s));
     HIP_TRY(hipMemsetAsync(h->d.calibrator, 0, p1 * h->vsize(), s));
     HIP_TRY(hipMemsetAsync(h->d.carry_acc, 0, p1 * h->vsize(), s));
     HIP_TRY(hipMemsetAsync(h->d.carry_cnt, 0, p1 * 4, s));
+    HIP_TRY(hipMemsetAsync(h->d.counters, 0, 16, s));
     HIP_TRY(hipStreamSynchronize(s));
     h->t_malloc += now_ms() - t0;
 
@@ -358,14 +362,12 @@ int csr5hip_as_csr5(csr5hip_handle h)
         HIP_TRY(launch_transpose(g, h->d, h->value_type, true, s));
         HIP_TRY(launch_carry_meta(g, h->d, s));
         HIP_TRY(launch_tile_window(g, h->d, (int)h->vsize(), s));
-        uint32_t xwin_tiles = 0;
-        uint32_t xwin_covered = 0;
-        HIP_TRY(hipMemcpyAsync(&xwin_tiles, h->d.carry_cnt + g.p, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&xwin_covered, (char *)h->d.carry_acc + (size_t)g.p * h->vsize(), 4,
-                               hipMemcpyDeviceToHost, s));
+        uint32_t stats[4] = {0, 0, 0, 0}; // x-window tiles, covered non-zeros, long runs
+        HIP_TRY(hipMemcpyAsync(stats, h->d.counters, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        h->xwin_tiles = (int)xwin_tiles;
-        h->xwin_covered = (long long)xwin_covered;
+        h->xwin_tiles = (int)stats[0];
+        h->xwin_covered = (long long)stats[1];
+        h->opt.long_runs = stats[2] != 0;
         h->t_transpose += now_ms() - t0;
     }
     h->opt.x_window = xwin_decision(h);

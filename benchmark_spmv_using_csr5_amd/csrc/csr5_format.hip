@@ -250,6 +250,8 @@ __global__ void __launch_bounds__(BLOCK) k_transpose(Geometry g, const uint32_t 
 // Fused-SpMV helper (not part of the reference format): who resolves the partial sums that a tile
 // boundary cuts.  One uint4 per tile t (tail = tile p-1):
 //   .x bits 0..23 : fallback protocol only -- number of arrivals expected at slot t (t = run head)
+//      bit 26 LONG_RUN   : (run heads) the run has more than RUN_SERIAL_MAX tiles: every party only parks its
+//                          partial (plain store) and a k_calibrate launch after the tile kernel sums them
 //      bit 27 HAS_CLOSING: (run heads) the closing segment of tile t-1 is one of the arrivals
 //      bit 28 LEAD_SKIP  : the leading partial of tile t is recomputed by tile t-1; do not emit it
 //      bit 29 CLOSE_LOCAL: the closing segment of tile t continues for .z <= 64 elements into tile
@@ -264,7 +266,8 @@ __global__ void __launch_bounds__(BLOCK) k_transpose(Geometry g, const uint32_t 
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK) k_carry_meta(Geometry g, const int32_t *__restrict__ row_ptr,
                                                       const uint32_t *__restrict__ tile_ptr,
-                                                      uint4 *__restrict__ carry_meta)
+                                                      uint4 *__restrict__ carry_meta,
+                                                      uint32_t *__restrict__ long_run_counter)
 {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= g.p)
@@ -300,6 +303,10 @@ __global__ void __launch_bounds__(BLOCK) k_carry_meta(Geometry g, const int32_t 
             reinterpret_cast<unsigned *>(&carry_meta[e])[1] = (unsigned)t; // .y of the run members
         }
         unsigned expected = (unsigned)(e - t + 1);
+        if (e - t + 1 > RUN_SERIAL_MAX) {
+            meta.x |= 1u << 26; // long run: partials are only parked, k_calibrate sums them
+            atomicAdd(long_run_counter, 1u);
+        }
         if ((long long)row_ptr[r] != (long long)t * T) {
             expected += 1; // row r starts inside tile t-1, whose closing segment also arrives
             meta.x |= 1u << 27;
@@ -334,8 +341,8 @@ __global__ void __launch_bounds__(BLOCK) k_carry_meta(Geometry g, const int32_t 
 // tile).  Each candidate centres a window of XWIN_BYTES / sizeof(vT) columns and is scored by how many
 // of the 64 samples fall inside it (64 readlane broadcasts); the best-scoring candidate is then
 // verified against ALL omega*sigma elements.  If at least XWIN_MIN_COVER_PCT % of them fall inside,
-// carry_meta[t].w = window start + 1 (0 = no window); carry_cnt[p] counts such tiles and the spare slot
-// carry_acc[p] the non-zeros they cover.  The SpMV kernel stages that slice of x in LDS and serves the
+// carry_meta[t].w = window start + 1 (0 = no window); counters[0] counts such tiles, counters[1] the
+// non-zeros they cover.  The SpMV kernel stages that slice of x in LDS and serves the
 // in-window gathers from LDS (csr5_spmv.hip, XWIN variant).  Two passes over the tile's columns.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int wave_sum_i32(int v)
@@ -469,7 +476,7 @@ hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream
     if (g.p <= 0)
         return hipSuccess;
     hipLaunchKernelGGL(k_carry_meta, dim3(div_up(g.p, BLOCK)), dim3(BLOCK), 0, s, g, d.row_ptr,
-                       d.tile_ptr, reinterpret_cast<uint4 *>(d.carry_meta));
+                       d.tile_ptr, reinterpret_cast<uint4 *>(d.carry_meta), d.counters + 2);
     return hipGetLastError();
 }
 
@@ -478,8 +485,7 @@ hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int valu
     if (g.p <= 1)
         return hipSuccess;
     hipLaunchKernelGGL(k_tile_window, dim3(div_up(g.p - 1, WAVES_PER_BLOCK)), dim3(BLOCK), 0, s, g,
-                       d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.carry_cnt + g.p,
-                       reinterpret_cast<uint32_t *>((char *)d.carry_acc + (size_t)g.p * value_size),
+                       d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.counters + 0, d.counters + 1,
                        xwin_elems(value_size));
     return hipGetLastError();
 }

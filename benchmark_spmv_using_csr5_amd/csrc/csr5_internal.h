@@ -17,6 +17,7 @@ constexpr int BLOCK = OMEGA * WAVES_PER_BLOCK;
 constexpr int BIT_SS = 6;                     // bits of scansum_offset at omega = 64
 constexpr uint32_t ROW_MASK = 0x7FFFFFFFu;    // tile_ptr bit 31 = "tile has empty rows"
 constexpr int NUM_XCD = 8;
+constexpr int RUN_SERIAL_MAX = 16;            // carry runs up to this many tiles resolve in-kernel; longer ones in k_calibrate
 constexpr int XWIN_BYTES = 4096;              // x-window staged in LDS per wavefront: 1024 fp32 / 512 fp64 columns
 constexpr int xwin_elems(int value_size) { return XWIN_BYTES / value_size; }
 constexpr int XWIN_MIN_COVER_PCT = 30;        // a tile gets a window if it covers at least this share
@@ -55,6 +56,7 @@ struct DeviceArrays {
     void *carry_acc;        // [p] of vT, all zero between launches
     uint32_t *carry_cnt;    // [p], all zero between launches
     uint32_t *carry_meta;   // [p] x uint4 per tile: see k_carry_meta in csr5_format.hip
+    uint32_t *counters;     // [4] conversion statistics: x-window tiles, covered non-zeros, long runs
 };
 
 // ---- conversion (csr5_format.hip) ----
@@ -75,6 +77,7 @@ struct SpmvOptions {
     int xcd_remap;   // CSR5HIP_OPT_XCD_REMAP
     int x_window;    // resolved: 1 = launch the LDS x-window variant of the fused kernel
     int lds_y;       // resolved: 1 = compact y segments through LDS before storing them
+    int long_runs;   // resolved: the matrix has rows spanning > RUN_SERIAL_MAX tiles (fused mode adds k_calibrate)
 };
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s);

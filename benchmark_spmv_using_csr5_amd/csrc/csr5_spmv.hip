@@ -99,8 +99,45 @@ __device__ __forceinline__ VT lane_above(VT v)
 //      store, drains it (s_waitcnt vmcnt(0)), then bumps the arrival counter.  The last arriver reads the
 //      words back with agent-scope loads and adds them IN TILE ORDER -- the same association as the
 //      two-pass k_calibrate, so the result is bit-reproducible -- stores y and re-arms the counter.
+//   long runs (> RUN_SERIAL_MAX tiles): parties only park their partial; k_calibrate finishes them.
 // All slot accesses are device-scope atomics: performed at the memory side, coherent across the 8 XCD
 // L2s, no dependence on dispatch order or placement, nobody ever waits for another workgroup.
+// Sum of the parked partials of the run headed by tile `slot`, in a fixed order shared by the fused
+// kernel (ATOMIC loads, same launch) and k_calibrate (plain loads, next launch):
+//   len <= RUN_SERIAL_MAX : first + cal[slot] + cal[slot+1] + ...                    (one lane, `leader`)
+//   longer                : first + wave_sum(lane-strided partial sums of cal[slot..]) (whole wavefront)
+// `first` = the closing partial of tile slot-1 when the row starts inside it (has_first).
+// The long form must be called by all 64 lanes with wave-uniform arguments; result valid in `leader`.
+template <typename VT, bool ATOMIC>
+__device__ __forceinline__ VT sum_run(const VT *calibrator, int slot, int len, bool has_first, VT first,
+                                      int lane, int leader)
+{
+    using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
+    auto load = [&](int k) -> VT {
+        if constexpr (ATOMIC)
+            return __builtin_bit_cast(VT, __hip_atomic_load(reinterpret_cast<const bits_t *>(&calibrator[slot + k]),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        else
+            return calibrator[slot + k];
+    };
+    VT total = 0;
+    if (len <= RUN_SERIAL_MAX) {
+        if (lane == leader) {
+            total = has_first ? first + load(0) : load(0);
+            for (int k = 1; k < len; k++)
+                total += load(k);
+        }
+    } else {
+        VT part = 0;
+#pragma unroll 4
+        for (int k = lane; k < len; k += OMEGA)
+            part += load(k);
+        part = wave_sum(part);
+        total = has_first ? first + part : part;
+    }
+    return total;
+}
+
 template <typename VT>
 __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, VT *calibrator,
                                              const uint32_t *tile_ptr, int slot, uint32_t meta_x,
@@ -113,7 +150,12 @@ __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, VT *calibra
     using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
     const uint32_t expected = meta_x & 0x00FFFFFFu;
     VT *row_y = y + (tile_ptr[slot] & ROW_MASK);
-    if (expected == 1u) {
+    if ((meta_x >> 26) & 1u) {
+        // long run (> RUN_SERIAL_MAX tiles, e.g. a row with 10^5..10^7 non-zeros): park the partial with a
+        // plain store; k_calibrate<.., true> (second launch, only for matrices that have such rows) sums
+        // them with a whole wavefront.  No counter: 10^4 arrivals on one word would serialise.
+        *(is_closing ? &acc[slot] : &calibrator[my_tile]) = v;
+    } else if (expected == 1u) {
         *row_y = v;
     } else if (expected == 2u) {
         bits_t *s = reinterpret_cast<bits_t *>(&acc[slot]);
@@ -131,18 +173,13 @@ __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, VT *calibra
         const uint32_t arrived =
             __hip_atomic_fetch_add(&cnt[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
         if (arrived == expected) {
-            const bool has_closing = (meta_x >> 27) & 1u;
-            const int len = (int)expected - (has_closing ? 1 : 0);
-            VT total = 0;
-            if (has_closing)
-                total = __builtin_bit_cast(VT, __hip_atomic_load(reinterpret_cast<bits_t *>(&acc[slot]),
+            const bool has_first = (meta_x >> 27) & 1u;
+            const int len = (int)expected - (has_first ? 1 : 0); // <= RUN_SERIAL_MAX here
+            VT first = 0;
+            if (has_first)
+                first = __builtin_bit_cast(VT, __hip_atomic_load(reinterpret_cast<bits_t *>(&acc[slot]),
                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            for (int k = 0; k < len; k++) {
-                const VT c = __builtin_bit_cast(
-                    VT, __hip_atomic_load(reinterpret_cast<bits_t *>(&calibrator[slot + k]), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT));
-                total = (k == 0 && !has_closing) ? c : total + c;
-            }
+            const VT total = sum_run<VT, true>(calibrator, slot, len, has_first, first, 0, 0);
             __hip_atomic_store(&cnt[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *row_y = total;
         }
@@ -174,7 +211,7 @@ constexpr int wave_lds_bytes()
     return (b + 15) & ~15;
 }
 
-template <typename VT, bool FUSED>
+template <typename VT, int SIGMA, bool FUSED>
 __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__restrict__ row_ptr,
                                           const int32_t *__restrict__ col,
                                           const VT *__restrict__ val, const VT *__restrict__ x,
@@ -186,7 +223,9 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
     const int lane = tid & (OMEGA - 1);
     const int first_tail = (g.p - 1) * g.tile_elems;
     const int E = g.nnz - first_tail;
-    constexpr int PER = TAIL_MAX / BLOCK; // 8
+    // elements per thread: the tail holds at most T = 64*sigma non-zeros (sized per instantiation so
+    // that the tail path does not dictate the register allocation of the small-sigma kernels)
+    constexpr int PER = ((SIGMA > 0 ? OMEGA * SIGMA : TAIL_MAX) + BLOCK - 1) / BLOCK;
     int32_t c[PER];
     VT v[PER];
 #pragma unroll
@@ -275,7 +314,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
 #if defined(CSR5_ABLATE) && (CSR5_ABLATE & 4)
         return;
 #endif
-        tail_rows<VT, FUSED>(g, row_ptr, col, val, x, calibrator, y, blk - tile_blocks, acc, cnt,
+        tail_rows<VT, SIGMA, FUSED>(g, row_ptr, col, val, x, calibrator, y, blk - tile_blocks, acc, cnt,
                              meta, tile_ptr, reinterpret_cast<VT *>(smem));
         return;
     }
@@ -557,29 +596,58 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     CSR5_TSTAMP(t, 7);
 }
 
-// ---- two-pass mode, second pass: resolve carries in tile order ------------------------------------
-// One thread per run head; the first carry of a row that begins exactly on a tile boundary stores,
-// every other carry adds (CSR5_avx2 csr5_spmv_avx2.h:42-49,284-291 semantics), in increasing tile
-// order so the result is bit-reproducible.
-template <typename VT>
+// ---- carry resolution by a second launch ---------------------------------------------------------
+// One thread per run head (carry_meta[t].y == t).
+//   LONG_ONLY = false (two-pass mode): every run.  The first carry of a row that begins exactly on a tile
+//     boundary stores, otherwise the closing partial that k_spmv stored into y[r] comes first (CSR5_avx2
+//     csr5_spmv_avx2.h:42-49,284-291 semantics).
+//   LONG_ONLY = true (fused mode, launched only when the matrix has such rows): only the runs longer than
+//     RUN_SERIAL_MAX tiles, whose parties parked their partials (closing partial in acc[head]).
+// Summation order = sum_run(), identical in both modes and to the fused kernel's in-launch finisher; long
+// runs are summed by the whole wavefront.
+template <typename VT, bool LONG_ONLY>
 __global__ void __launch_bounds__(BLOCK)
-k_calibrate(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ tile_ptr,
-            const VT *__restrict__ calibrator, VT *__restrict__ y)
+k_calibrate(Geometry g, const uint32_t *__restrict__ tile_ptr, const uint4 *__restrict__ meta,
+            const VT *__restrict__ calibrator, const VT *__restrict__ acc, VT *__restrict__ y)
 {
+    const int lane = threadIdx.x & (OMEGA - 1);
     const int t = blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= g.p)
-        return;
-    const int r = (int)(tile_ptr[t] & ROW_MASK);
-    if (t > 0 && (int)(tile_ptr[t - 1] & ROW_MASK) == r)
-        return;
-    if (r >= g.m)
-        return;
-    VT v = calibrator[t];
-    if ((long long)row_ptr[r] != (long long)t * g.tile_elems)
-        v = y[r] + v;
-    for (int k = t + 1; k < g.p && (int)(tile_ptr[k] & ROW_MASK) == r; k++)
-        v += calibrator[k];
-    y[r] = v;
+    bool head = false;
+    int len = 0;
+    bool has_first = false;
+    int r = 0;
+    if (t < g.p) {
+        const uint4 mt = meta[t];
+        head = (int)mt.y == t;
+        r = (int)(tile_ptr[t] & ROW_MASK);
+        if ((mt.x >> 28) & 1u) { // short-spill head (fused-mode classification): one carry onto y[r]
+            len = 1;
+            has_first = true;
+        } else {
+            has_first = (mt.x >> 27) & 1u;
+            len = (int)(mt.x & 0x00FFFFFFu) - (has_first ? 1 : 0);
+        }
+        head = head && r < g.m && len > 0;
+        if (LONG_ONLY)
+            head = head && ((mt.x >> 26) & 1u);
+    }
+    if (!LONG_ONLY && head && len <= RUN_SERIAL_MAX)
+        y[r] = sum_run<VT, false>(calibrator, t, len, has_first, has_first ? y[r] : (VT)0, lane, lane);
+    unsigned long long todo = __ballot(head && len > RUN_SERIAL_MAX);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int slot = __shfl(t, leader, OMEGA);
+        const int ln = __shfl(len, leader, OMEGA);
+        const bool hf = __shfl((int)has_first, leader, OMEGA);
+        const int row = __shfl(r, leader, OMEGA);
+        VT first = 0;
+        if (hf && lane == leader)
+            first = LONG_ONLY ? acc[slot] : y[row];
+        const VT total = sum_run<VT, false>(calibrator, slot, ln, hf, first, lane, leader);
+        if (lane == leader)
+            y[row] = total;
+    }
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------
@@ -601,10 +669,12 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
                        opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt,
                        reinterpret_cast<const uint4 *>(d.carry_meta));
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || FUSED)
+    if (e != hipSuccess || (FUSED && !opt.long_runs))
         return e;
-    hipLaunchKernelGGL(k_calibrate<VT>, dim3((g.p + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, g,
-                       d.row_ptr, d.tile_ptr, (const VT *)d.calibrator, (VT *)y);
+    // second launch: two-pass mode always; fused mode only when some row spans > RUN_SERIAL_MAX tiles
+    hipLaunchKernelGGL((k_calibrate<VT, FUSED>), dim3((g.p + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, g,
+                       d.tile_ptr, reinterpret_cast<const uint4 *>(d.carry_meta), (const VT *)d.calibrator,
+                       (const VT *)d.carry_acc, (VT *)y);
     return hipGetLastError();
 }
 
