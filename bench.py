@@ -268,6 +268,10 @@ def main():
                 "traffic_source": traffic_src,
                 "kernel": "csr5::k_spmv",
                 "algorithmic_bytes_per_launch": b_alg,
+                # diagnostic: bytes the CSR5 kernel actually streams = B_alg with row_ptr replaced
+                # by tile_ptr + tile_desc (x and y still counted once)
+                "csr5_stream_bytes_per_launch": b_alg - 4 * (m + 1) + 4 * (info.p + 1)
+                                                + 4 * info.p * 64 * info.num_packet,
                 "launch_us": round(launch_ms * 1e3, 3),
             },
         }
