@@ -18,7 +18,10 @@ constexpr int BIT_SS = 6;                     // bits of scansum_offset at omega
 constexpr uint32_t ROW_MASK = 0x7FFFFFFFu;    // tile_ptr bit 31 = "tile has empty rows"
 constexpr int NUM_XCD = 8;
 constexpr int RUN_SERIAL_MAX = 16;            // carry runs up to this many tiles resolve in-kernel; longer ones in k_calibrate
-constexpr int XWIN_BYTES = 4096;              // x-window staged in LDS per wavefront: 1024 fp32 / 512 fp64 columns
+#ifndef CSR5_XWIN_BYTES
+#define CSR5_XWIN_BYTES 4096
+#endif
+constexpr int XWIN_BYTES = CSR5_XWIN_BYTES;              // x-window staged in LDS per wavefront: 1024 fp32 / 512 fp64 columns
 constexpr int xwin_elems(int value_size) { return XWIN_BYTES / value_size; }
 constexpr int XWIN_MIN_COVER_PCT = 30;        // a tile gets a window if it covers at least this share
 
