@@ -95,7 +95,7 @@ struct csr5hip_handle_s {
     int xwin_request = 1; // CSR5HIP_OPT_X_WINDOW: 0 off, 1 auto (default), 2 force
     int xwin_tiles = 0;   // tiles that got a window at conversion
     long long xwin_covered = 0; // non-zeros inside those windows
-    Buffer b_tile_ptr, b_tile_desc, b_offset_ptr, b_offset, b_calibrator, b_acc, b_cnt, b_meta, b_counters;
+    Buffer b_tile_ptr, b_tile_desc, b_offset_ptr, b_offset, b_calibrator, b_acc, b_cnt, b_meta, b_counters, b_hdr;
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::unordered_map<GraphKey, hipGraphExec_t, GraphKeyHash> graphs;
@@ -160,7 +160,7 @@ int csr5hip_free(csr5hip_handle h)
         return CSR5HIP_INVALID_ARGUMENT;
     h->drop_graphs();
     for (Buffer *b : {&h->b_tile_ptr, &h->b_tile_desc, &h->b_offset_ptr, &h->b_offset,
-                      &h->b_calibrator, &h->b_acc, &h->b_cnt, &h->b_meta, &h->b_counters})
+                      &h->b_calibrator, &h->b_acc, &h->b_cnt, &h->b_meta, &h->b_counters, &h->b_hdr})
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -306,6 +306,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
     HIP_TRY(h->b_cnt.reserve(p1 * 4));
     HIP_TRY(h->b_meta.reserve(p1 * 16));
     HIP_TRY(h->b_counters.reserve(16));
+    HIP_TRY(h->b_hdr.reserve(p1 * 32));
     h->d.tile_ptr = (uint32_t *)h->b_tile_ptr.ptr;
     h->d.tile_desc = (uint32_t *)h->b_tile_desc.ptr;
     h->d.offset_ptr = (int32_t *)h->b_offset_ptr.ptr;
@@ -314,6 +315,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
     h->d.carry_cnt = (uint32_t *)h->b_cnt.ptr;
     h->d.carry_meta = (uint32_t *)h->b_meta.ptr;
     h->d.counters = (uint32_t *)h->b_counters.ptr;
+    h->d.tile_hdr = (uint32_t *)h->b_hdr.ptr;
     h->d.offset = nullptr;
     HIP_TRY(hipMemsetAsync(h->d.tile_desc, 0, desc_words * 4, s));
     HIP_TRY(hipMemsetAsync(h->d.offset_ptr, 0, p1 * 4, s));
@@ -362,6 +364,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
         HIP_TRY(launch_transpose(g, h->d, h->value_type, true, s));
         HIP_TRY(launch_carry_meta(g, h->d, s));
         HIP_TRY(launch_tile_window(g, h->d, (int)h->vsize(), s));
+        HIP_TRY(launch_tile_hdr(g, h->d, s));
         uint32_t stats[4] = {0, 0, 0, 0}; // x-window tiles, covered non-zeros, long runs
         HIP_TRY(hipMemcpyAsync(stats, h->d.counters, 16, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

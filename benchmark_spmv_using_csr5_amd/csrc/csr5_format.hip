@@ -398,6 +398,25 @@ __global__ void __launch_bounds__(BLOCK) k_tile_window(Geometry g, const int32_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Per-tile header of the fused kernel: everything wave-uniform a tile needs, in one 32-byte record
+// (one vector load instead of three): words 0..3 = carry_meta[t], 4 = carry_meta[t+1].x,
+// 5..6 = tile_ptr[t], tile_ptr[t+1] (copies; the format arrays themselves stay untouched).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_tile_hdr(Geometry g, const uint32_t *__restrict__ tile_ptr,
+                                                    const uint4 *__restrict__ carry_meta,
+                                                    uint32_t *__restrict__ hdr)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= g.p)
+        return;
+    const uint4 m = carry_meta[t];
+    uint4 lo = m;
+    uint4 hi = make_uint4(t + 1 < g.p ? carry_meta[t + 1].x : 0u, tile_ptr[t], tile_ptr[t + 1], 0u);
+    reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t] = lo;
+    reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t + 1] = hi;
+}
+
 __global__ void k_warmup(int *out)
 {
     __shared__ int s[OMEGA];
@@ -487,6 +506,15 @@ hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int valu
     hipLaunchKernelGGL(k_tile_window, dim3(div_up(g.p - 1, WAVES_PER_BLOCK)), dim3(BLOCK), 0, s, g,
                        d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.counters + 0, d.counters + 1,
                        xwin_elems(value_size));
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+{
+    if (g.p <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_tile_hdr, dim3(div_up(g.p, BLOCK)), dim3(BLOCK), 0, s, g, d.tile_ptr,
+                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr);
     return hipGetLastError();
 }
 

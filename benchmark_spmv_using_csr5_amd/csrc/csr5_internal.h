@@ -59,6 +59,7 @@ struct DeviceArrays {
     void *carry_acc;        // [p] of vT, all zero between launches
     uint32_t *carry_cnt;    // [p], all zero between launches
     uint32_t *carry_meta;   // [p] x uint4 per tile: see k_carry_meta in csr5_format.hip
+    uint32_t *tile_hdr;     // [8p] fused kernel: carry_meta[t], carry_meta[t+1].x and the tile_ptr pair in ONE 32-B record
     uint32_t *counters;     // [4] conversion statistics: x-window tiles, covered non-zeros, long runs
 };
 
@@ -72,6 +73,7 @@ hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_
                             hipStream_t s);
 hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int value_size, hipStream_t s);
+hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_warmup(hipStream_t s);
 
 // ---- SpMV (csr5_spmv.hip) ----

@@ -299,12 +299,13 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
        const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
        const uint32_t *__restrict__ tile_desc, const int32_t *__restrict__ offset_ptr,
        const int32_t *__restrict__ offset, VT *__restrict__ calibrator, VT *__restrict__ y,
-       int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta)
+       int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta,
+       const uint32_t *__restrict__ hdr)
 {
     // Pull EVERY kernel argument into SGPRs with the first batch of scalar loads: an argument that is
     // first touched further down would otherwise cost its own kernarg round trip on the critical path.
     asm volatile("" ::"s"(row_ptr), "s"(col), "s"(val), "s"(x), "s"(tile_ptr), "s"(tile_desc),
-                 "s"(offset_ptr), "s"(offset), "s"(calibrator), "s"(y), "s"(acc), "s"(cnt), "s"(meta),
+                 "s"(offset_ptr), "s"(offset), "s"(calibrator), "s"(y), "s"(acc), "s"(cnt), "s"(meta), "s"(hdr),
                  "s"(g.nnz), "s"(g.p), "s"(g.m), "s"(g.sigma), "s"(g.tail_start), "s"(g.tile_elems),
                  "s"(g.bit_y), "s"(g.num_packet), "s"(tile_blocks), "s"(xcd_remap));
     // dynamic LDS: the tail's product buffer (T elements) or, XWIN, one x-window per wavefront
@@ -351,15 +352,19 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     // `vz` is an opaque per-lane zero that keeps the compiler from scalarising these loads.
     int vz;
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-    const uint32_t tp0 = tile_ptr[t + vz];
-    const uint32_t tp1 = tile_ptr[t + 1 + vz];
+    uint32_t tp0 = 0, tp1 = 0, hw = 0;
+    if constexpr (FUSED) {
+        // fused mode: the whole 32-byte tile header (k_tile_hdr) in one load, one word per lane (lanes 0..7)
+        hw = hdr[8 * (size_t)t + (lane & 7)];
+    } else {
+        tp0 = tile_ptr[t + vz];
+        tp1 = tile_ptr[t + 1 + vz];
+    }
     uint4 mt = make_uint4(0u, 0u, 0u, 0u);
     uint32_t mt_next_x = 0;
     int32_t spill_c = 0;
     VT spill_v = 0;
     if constexpr (FUSED) {
-        mt = meta[t + vz];
-        mt_next_x = meta[t + 1 + vz].x; // tile t+1 <= p-1 always has a meta entry
         // first 64 elements (CSR order) of tile t+1: a transposed tile keeps element j at
         // (j % sigma)*omega + j / sigma, the CSR tail keeps it at j
         const size_t nb = (size_t)(t + 1) * T;
@@ -391,6 +396,13 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         // everything above is in flight before anything below consumes a loaded value
         __builtin_amdgcn_sched_barrier(0);
         CSR5_TSTAMP(t, 1);
+        if constexpr (FUSED) {
+            mt = make_uint4(__builtin_amdgcn_readlane(hw, 0), __builtin_amdgcn_readlane(hw, 1),
+                            __builtin_amdgcn_readlane(hw, 2), __builtin_amdgcn_readlane(hw, 3));
+            mt_next_x = __builtin_amdgcn_readlane(hw, 4);
+            tp0 = __builtin_amdgcn_readlane(hw, 5);
+            tp1 = __builtin_amdgcn_readlane(hw, 6);
+        }
         VT xv[NREG];
         if constexpr (XWIN) {
             constexpr int XWIN_ELEMS = xwin_elems(sizeof(VT));
@@ -447,6 +459,11 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         CSR5_TSTAMP(t, 3);
 #endif
     } else if constexpr (FUSED) {
+        mt = make_uint4(__builtin_amdgcn_readlane(hw, 0), __builtin_amdgcn_readlane(hw, 1),
+                        __builtin_amdgcn_readlane(hw, 2), __builtin_amdgcn_readlane(hw, 3));
+        mt_next_x = __builtin_amdgcn_readlane(hw, 4);
+        tp0 = __builtin_amdgcn_readlane(hw, 5);
+        tp1 = __builtin_amdgcn_readlane(hw, 6);
         const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
         const VT sx = x[lane < L ? spill_c : 0];
         lead_next = lane < L ? spill_v * sx : (VT)0;
@@ -667,7 +684,7 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
                        g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x, d.tile_ptr,
                        d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, tile_blocks,
                        opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt,
-                       reinterpret_cast<const uint4 *>(d.carry_meta));
+                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || (FUSED && !opt.long_runs))
         return e;
