@@ -17,7 +17,7 @@ constexpr int BLOCK = OMEGA * WAVES_PER_BLOCK;
 constexpr int BIT_SS = 6;                     // bits of scansum_offset at omega = 64
 constexpr uint32_t ROW_MASK = 0x7FFFFFFFu;    // tile_ptr bit 31 = "tile has empty rows"
 constexpr int NUM_XCD = 8;
-constexpr int RUN_SERIAL_MAX = 16;            // carry runs up to this many tiles resolve in-kernel; longer ones in k_calibrate
+constexpr int RUN_SERIAL_MAX = 64;            // carry runs up to this many tiles resolve in-kernel; longer ones in k_calibrate
 #ifndef CSR5_XWIN_BYTES
 #define CSR5_XWIN_BYTES 4096
 #endif

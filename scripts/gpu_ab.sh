@@ -4,9 +4,9 @@ timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
 for rep in 1 2 3; do
   for v in prev cur; do
     if [ $v = prev ]; then export CSR5HIP_LIB=$PWD/scripts/probes/libcsr5hip_prev.so; else unset CSR5HIP_LIB; fi
-    echo -n "$v: "; one --steps 1000
-    echo -n "$v: "; one --steps 1000 --sigma 8
     echo -n "$v: "; one --workload webbase --steps 300
-    if [ $rep = 1 ]; then echo -n "$v: "; one --workload nd24k --steps 100; echo -n "$v: "; one --workload rmat22 --steps 30 --warmup 3; fi
+    echo -n "$v: "; one --workload rmat22 --steps 30 --warmup 3
   done
 done
+unset CSR5HIP_LIB
+timeout 300 python scripts/probes/dense_row.py 2>&1 | grep "row=" 
