@@ -47,6 +47,31 @@ class Csr5Info(C.Structure):
     ]
 
 
+MTX_CANNOT_OPEN = -1
+MTX_BAD_BANNER = -2
+MTX_COMPLEX = -3
+MTX_BAD_SIZE = -4
+FIELD_REAL, FIELD_INTEGER, FIELD_PATTERN = 0, 1, 2
+
+
+class MtxCoo(C.Structure):  # csr5hip_mtx
+    _fields_ = [
+        ("m", C.c_int32), ("n", C.c_int32), ("nz", C.c_int64), ("field", C.c_int), ("symmetric", C.c_int),
+        ("row", C.POINTER(C.c_int32)), ("col", C.POINTER(C.c_int32)), ("val", C.POINTER(C.c_double)),
+        ("threads", C.c_int), ("fast_path", C.c_int), ("t_parse_ms", C.c_double), ("file_bytes", C.c_int64),
+        ("alloc_flags", C.c_int),
+    ]
+
+
+class DeviceCsrStruct(C.Structure):  # csr5hip_csr
+    _fields_ = [
+        ("m", C.c_int32), ("n", C.c_int32), ("nnz", C.c_int32),
+        ("d_row_ptr", C.c_void_p), ("d_col_idx", C.c_void_p), ("d_val", C.c_void_p),
+        ("value_type", C.c_int),
+        ("t_parse_ms", C.c_double), ("t_h2d_ms", C.c_double), ("t_build_ms", C.c_double),
+    ]
+
+
 # every symbol include/csr5hip.h declares: (name, restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = [
@@ -79,6 +104,12 @@ SYMBOLS = [
     ("csr5hip_synchronize", C.c_int, []),
     ("csr5hip_timer_start", C.c_int, [_H]),
     ("csr5hip_timer_stop", C.c_int, [_H, C.POINTER(C.c_double)]),
+    ("csr5hip_mtx_read", C.c_int, [C.c_char_p, C.c_int, C.POINTER(MtxCoo)]),
+    ("csr5hip_mtx_release", C.c_int, [C.POINTER(MtxCoo)]),
+    ("csr5hip_coo_to_csr", C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_int, C.POINTER(DeviceCsrStruct)]),
+    ("csr5hip_csr_release", C.c_int, [C.POINTER(DeviceCsrStruct)]),
+    ("csr5hip_mtx_load", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(DeviceCsrStruct)]),
 ]
 
 _lib = None
@@ -94,6 +125,14 @@ def load():
         raise ImportError(
             f"{path} is missing: the CSR5 HIP extension is not built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    # One HIP runtime per process: torch's libtorch_hip.so asks for "libamdhip64.so" and finds its bundled
+    # copy through RPATH even when /opt/rocm's libamdhip64.so.7 is already mapped, and the second runtime
+    # then sees no GPU.  Loading torch first makes our NEEDED libamdhip64.so.7 resolve to the copy torch
+    # brought in (same SONAME).  Programs that never use torch (the ./spmv CLI, C hosts) are unaffected.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     for name, restype, argtypes in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol

@@ -19,6 +19,14 @@ namespace {
 
 thread_local std::string g_last_error;
 
+} // namespace
+
+namespace csr5 {
+void set_last_error(const std::string &msg) { g_last_error = msg; }
+} // namespace csr5
+
+namespace {
+
 int fail_hip(hipError_t e, const char *what)
 {
     g_last_error = std::string(what) + ": " + hipGetErrorString(e);

@@ -141,6 +141,63 @@ int csr5hip_synchronize(void);
 int csr5hip_timer_start(csr5hip_handle h);
 int csr5hip_timer_stop(csr5hip_handle h, double *ms);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Matrix Market ingest and COO -> CSR: the step BEFORE the path.
+ * Replaces the serial fscanf loop and the host counting scatter of the reference CLI
+ * (CSR5_avx2/main.cpp:126-281, CSR5_cuda/main.cu reads through the same code) with a multi-threaded
+ * mmap parser and a device-side stable sort; the resulting CSR is identical, entry for entry, to the
+ * one the reference builds (file order inside a row; the mirror of a symmetric off-diagonal follows
+ * its original).
+ * ------------------------------------------------------------------------------------------------- */
+#define CSR5HIP_MTX_CANNOT_OPEN   (-1)   /* CLI exit codes, main.cpp:135-157 */
+#define CSR5HIP_MTX_BAD_BANNER    (-2)
+#define CSR5HIP_MTX_COMPLEX       (-3)
+#define CSR5HIP_MTX_BAD_SIZE      (-4)   /* also: fewer entries in the file than the size line announces */
+
+#define CSR5HIP_FIELD_REAL     0
+#define CSR5HIP_FIELD_INTEGER  1
+#define CSR5HIP_FIELD_PATTERN  2
+
+/* COO triplets of a .mtx file: 0-based, file order, host memory owned by the library. */
+typedef struct csr5hip_mtx {
+    int32_t m, n;
+    int64_t nz;            /* entries in the file (nnzA_mtx_report, main.cpp:132) */
+    int field;             /* CSR5HIP_FIELD_* ; pattern entries get the value 1.0 (main.cpp:198) */
+    int symmetric;         /* 1 for a symmetric or hermitian banner (main.cpp:159-163); skew-symmetric is NOT expanded */
+    int32_t *row, *col;    /* [nz] */
+    double *val;           /* [nz] */
+    int threads;           /* parser threads used */
+    int fast_path;         /* 1 = parallel line parser, 0 = sequential fscanf-compatible scanner */
+    double t_parse_ms;
+    int64_t file_bytes;
+    int alloc_flags;       /* private: which arrays are pinned host memory */
+} csr5hip_mtx;
+
+/* Device CSR built from COO; every d_* array is allocated here, release with csr5hip_csr_release. */
+typedef struct csr5hip_csr {
+    int32_t m, n, nnz;
+    int32_t *d_row_ptr;    /* [m+1] */
+    int32_t *d_col_idx;    /* [nnz] */
+    void *d_val;           /* [nnz] of value_type, or NULL when no values were requested */
+    int value_type;
+    double t_parse_ms, t_h2d_ms, t_build_ms;   /* filled by csr5hip_mtx_load / csr5hip_coo_to_csr */
+} csr5hip_csr;
+
+/* Parse `path` (threads <= 0: one per hardware thread, capped at 64).  Returns 0 or CSR5HIP_MTX_*;
+ * CSR5HIP_INVALID_ARGUMENT for an index outside [1,m] x [1,n] (the reference would corrupt memory). */
+int csr5hip_mtx_read(const char *path, int threads, csr5hip_mtx *out);
+int csr5hip_mtx_release(csr5hip_mtx *mtx);
+
+/* main.cpp:213-275 on the device.  d_row / d_col / d_val: nz COO triplets in file order (d_val may be
+ * NULL: structure only, out->d_val = NULL).  symmetric != 0 mirrors every off-diagonal entry right after
+ * the original.  Values are converted to value_type (the reference stores VALUE_TYPE, main.cpp:207). */
+int csr5hip_coo_to_csr(int32_t m, int32_t n, int64_t nz, const int32_t *d_row, const int32_t *d_col,
+                       const double *d_val, int symmetric, int value_type, csr5hip_csr *out);
+int csr5hip_csr_release(csr5hip_csr *csr);
+
+/* csr5hip_mtx_read + H2D + csr5hip_coo_to_csr in one call (what `./spmv foo.mtx` does first). */
+int csr5hip_mtx_load(const char *path, int threads, int value_type, csr5hip_csr *out);
+
 #ifdef __cplusplus
 }
 #endif

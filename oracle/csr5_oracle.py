@@ -51,11 +51,35 @@ class Csr5Format:
     val: np.ndarray = field(repr=False)          # tile-transposed value
 
 
+class MtxExit(Exception):
+    """The exit code the reference CLI would return for an unreadable .mtx (main.cpp:135-157)."""
+
+    def __init__(self, code: int):
+        super().__init__(f"mtx ingest exit code {code}")
+        self.code = code
+
+
+@dataclass
+class MtxIngest:
+    m: int
+    n: int
+    nnz: int            # after symmetric expansion
+    nz_file: int        # entries in the file
+    symmetric: bool
+    field: int          # 0 real, 1 integer, 2 pattern
+    coo_row: np.ndarray = field(repr=False)
+    coo_col: np.ndarray = field(repr=False)
+    coo_val: np.ndarray = field(repr=False)
+    row_ptr: np.ndarray = field(repr=False)
+    col: np.ndarray = field(repr=False)
+    val: np.ndarray = field(repr=False)
+
+
 def build_oracle(force: bool = False) -> str:
     """Compile oracle/libcsr5oracle.so (and, where /root/reference exists, oracle/_ref)."""
     so = os.path.join(_HERE, "libcsr5oracle.so")
-    src = os.path.join(_HERE, "csr5_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("csr5_oracle.c", "mtx_oracle.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "libcsr5oracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference/CSR5_avx2"):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -85,7 +109,56 @@ class Oracle:
         L.csr5o_csr_spmv_f64.argtypes = [C.c_int, _I32P, _I32P, _F64P, _F64P, _F64P]
         L.csr5o_csr_spmv_f32.argtypes = [C.c_int, _I32P, _I32P, _F32P, _F32P, _F32P]
         L.csr5o_num_threads.restype = C.c_int
+        L.csr5o_mtx_read.argtypes = [C.c_char_p, _I32P]
+        L.csr5o_mtx_read.restype = C.c_int
+        L.csr5o_mtx_coo.argtypes = [_I32P, _I32P, _F64P]
+        L.csr5o_mtx_coo.restype = None
+        L.csr5o_mtx_csr.argtypes = [_I32P, _I32P, _F64P]
+        L.csr5o_mtx_csr.restype = None
+        L.csr5o_coo_nnz.argtypes = [C.c_int, _I32P, _I32P, C.c_int]
+        L.csr5o_coo_nnz.restype = C.c_int
+        L.csr5o_coo_to_csr.argtypes = [C.c_int, C.c_int, _I32P, _I32P, C.c_void_p, C.c_int, _I32P, _I32P,
+                                       C.c_void_p]
+        L.csr5o_coo_to_csr.restype = None
         self.L = L
+
+    # ---- Matrix Market ingest (oracle/mtx_oracle.c; reference main.cpp:126-281) ----
+    def mtx_read(self, path: str) -> "MtxIngest":
+        """Sequential fscanf ingest exactly as the reference CLI does.  Raises MtxExit(code)."""
+        dims = np.zeros(6, dtype=np.int32)
+        rc = self.L.csr5o_mtx_read(os.fsencode(path), dims)
+        if rc:
+            raise MtxExit(rc)
+        m, n, nnz, nz, symm, fld = (int(v) for v in dims)
+        row = np.zeros(max(nz, 1), dtype=np.int32)
+        col = np.zeros(max(nz, 1), dtype=np.int32)
+        val = np.zeros(max(nz, 1), dtype=np.float64)
+        self.L.csr5o_mtx_coo(row, col, val)
+        row_ptr = np.zeros(m + 1, dtype=np.int32)
+        ci = np.zeros(max(nnz, 1), dtype=np.int32)
+        cv = np.zeros(max(nnz, 1), dtype=np.float64)
+        self.L.csr5o_mtx_csr(row_ptr, ci, cv)
+        return MtxIngest(m, n, nnz, nz, bool(symm), fld, row[:nz], col[:nz], val[:nz], row_ptr, ci[:nnz],
+                         cv[:nnz])
+
+    def coo_to_csr(self, m: int, row, col, val, symmetric: bool):
+        """The reference's counting scatter (main.cpp:213-275) on COO triplets in file order."""
+        row = np.ascontiguousarray(row, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        nz = int(row.size)
+        r_ = row if nz else np.zeros(1, np.int32)
+        c_ = col if nz else np.zeros(1, np.int32)
+        nnz = int(self.L.csr5o_coo_nnz(nz, r_, c_, int(symmetric)))
+        row_ptr = np.zeros(m + 1, dtype=np.int32)
+        ci = np.zeros(max(nnz, 1), dtype=np.int32)
+        if val is None:
+            self.L.csr5o_coo_to_csr(m, nz, r_, c_, None, int(symmetric), row_ptr, ci, None)
+            return row_ptr, ci[:nnz], None
+        v = np.ascontiguousarray(val, dtype=np.float64)
+        v_ = v if nz else np.zeros(1)
+        cv = np.zeros(max(nnz, 1), dtype=np.float64)
+        self.L.csr5o_coo_to_csr(m, nz, r_, c_, v_.ctypes.data, int(symmetric), row_ptr, ci, cv.ctypes.data)
+        return row_ptr, ci[:nnz], cv[:nnz]
 
     def num_threads(self) -> int:
         return int(self.L.csr5o_num_threads())
@@ -214,6 +287,28 @@ class Reference:
         return Csr5Format(omega, sigma, m, nnz, bit_y, bit_ss, num_packet, p, tail_start,
                           int(num_offsets), tile_ptr, tile_desc[: p * omega * num_packet],
                           offset_ptr, offset[:num_offsets], col, val)
+
+    @staticmethod
+    def ingest_available() -> bool:
+        return os.path.exists(os.path.join(_HERE, "_ref", "libref_ingest.so"))
+
+    def ingest(self, path: str):
+        """CSR exactly as the reference CLI holds it at main.cpp:281 -> (m, n, row_ptr, col, val)."""
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_ingest.so"))
+        L.ref_ingest_run.argtypes = [C.c_char_p, _I32P]
+        L.ref_ingest_run.restype = C.c_int
+        L.ref_ingest_fetch.argtypes = [_I32P, _I32P, _F64P]
+        L.ref_ingest_fetch.restype = None
+        dims = np.zeros(3, dtype=np.int32)
+        rc = L.ref_ingest_run(os.fsencode(path), dims)
+        if rc:
+            raise MtxExit(rc)
+        m, n, nnz = (int(v) for v in dims)
+        row_ptr = np.zeros(m + 1, dtype=np.int32)
+        col = np.zeros(max(nnz, 1), dtype=np.int32)
+        val = np.zeros(max(nnz, 1), dtype=np.float64)
+        L.ref_ingest_fetch(row_ptr, col, val)
+        return m, n, row_ptr, col[:nnz], val[:nnz]
 
     def _avx2_lib(self):
         if self._avx2 is None:
