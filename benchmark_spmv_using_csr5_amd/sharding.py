@@ -125,3 +125,130 @@ def hip_local_spmv(device, sigma: int = -1, mode: int = 1):
         return state["y"]
 
     return run
+
+
+# ---------------------------------------------------------------------------------------------------
+# Iterative-solver coupling: y feeds the next x, so every iteration needs the
+# y shards on every rank -- the first place a per-iteration collective appears.
+# ---------------------------------------------------------------------------------------------------
+class PaddedLayout:
+    """Vector layout for coupled iterations: `world` slots of `width` elements; slot g holds the entries
+    cuts[g] .. cuts[g+1]-1 of the global vector and zero padding behind them.
+
+    With x kept in this layout a rank's SpMV writes its y shard STRAIGHT into its slot of the next x and
+    one in-place all-gather (equal counts, no staging copy, no unpadding) completes the vector on every
+    rank.  Column indices of the row blocks are remapped once (`remap_columns`) so that they address the
+    padded vector; nothing else about the CSR changes."""
+
+    ALIGN = 64  # elements; keeps every slot 256-/512-byte aligned
+
+    def __init__(self, cuts):
+        self.cuts = np.asarray(cuts, dtype=np.int64)
+        self.world = self.cuts.size - 1
+        widest = int(np.max(np.diff(self.cuts))) if self.world else 0
+        self.width = max(self.ALIGN, (widest + self.ALIGN - 1) // self.ALIGN * self.ALIGN)
+        self.shift = np.arange(self.world, dtype=np.int64) * self.width - self.cuts[:-1]
+
+    @property
+    def padded_len(self) -> int:
+        return self.world * self.width
+
+    def owner(self, idx):
+        return np.clip(np.searchsorted(self.cuts, idx, side="right") - 1, 0, self.world - 1)
+
+    def remap_columns(self, col):
+        col = np.asarray(col, dtype=np.int64)
+        return (col + self.shift[self.owner(col)]).astype(np.int32)
+
+    def to_padded(self, vec):
+        """global vector (numpy) -> padded copy"""
+        out = np.zeros(self.padded_len, dtype=np.asarray(vec).dtype)
+        for g in range(self.world):
+            lo, hi = int(self.cuts[g]), int(self.cuts[g + 1])
+            out[g * self.width: g * self.width + hi - lo] = vec[lo:hi]
+        return out
+
+    def from_padded(self, padded):
+        return np.concatenate([np.asarray(padded[g * self.width: g * self.width + int(self.cuts[g + 1] - self.cuts[g])])
+                               for g in range(self.world)])
+
+    def slot(self, t, rank: int):
+        """view of slot `rank` of a padded torch tensor"""
+        return t[rank * self.width: (rank + 1) * self.width]
+
+
+def allgather_slots(x_padded, layout: PaddedLayout, rank: int):
+    """The per-iteration collective: in-place all-gather of the `world` slots (RCCL over xGMI on the GPUs)."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_gather_into_tensor(x_padded, layout.slot(x_padded, rank))
+    return x_padded
+
+
+class CoupledSpmv:
+    """x_{k+1} = A x_k (optionally normalised) on a square matrix sharded by row blocks.
+
+    `local_spmv(block, x_padded, y_slot)` multiplies this rank's block (columns already remapped to the
+    padded layout, block.n == layout.padded_len) by the padded x and writes block.m results into y_slot."""
+
+    def __init__(self, row_ptr, col, val, n: int, rank: int, world: int):
+        m = int(np.asarray(row_ptr).size - 1)
+        if m != n:
+            raise ValueError("coupled iterations need a square matrix (y becomes the next x)")
+        self.cuts = partition_rows_by_nnz(row_ptr, world)
+        self.layout = PaddedLayout(self.cuts)
+        blk = extract_row_block(row_ptr, col, val, n, self.cuts, rank)
+        self.block = RowBlock(rank, blk.row_lo, blk.row_hi, self.layout.padded_len, blk.row_ptr,
+                              self.layout.remap_columns(blk.col), blk.val)
+        self.rank, self.world = rank, world
+
+    def step(self, local_spmv, x_in, x_out):
+        """one iteration: x_out <- A x_in, complete on every rank when the call returns (stream-ordered)"""
+        y_slot = self.layout.slot(x_out, self.rank)[: self.block.m]
+        local_spmv(self.block, x_in, y_slot)
+        return allgather_slots(x_out, self.layout, self.rank)
+
+    def power_iteration(self, local_spmv, x0_padded, scratch, iters: int, normalise: bool = True):
+        """`iters` coupled steps ping-ponging between the two padded buffers; returns (x, rayleigh) with
+        rayleigh = <x_k, A x_k> / <x_k, x_k> of the last step (every rank holds the same numbers)."""
+        import torch
+
+        a, b = x0_padded, scratch
+        rayleigh = None
+        for _ in range(iters):
+            self.step(local_spmv, a, b)
+            rayleigh = torch.dot(a, b) / torch.dot(a, a)
+            if normalise:
+                b.mul_(1.0 / torch.linalg.vector_norm(b))
+            a, b = b, a
+        return a, rayleigh
+
+
+def hip_coupled_spmv(device, sigma: int = -1, mode: int = 1):
+    """Factory for CoupledSpmv.step on a GPU: one CSR5 handle for the block, y written in place."""
+    import torch
+
+    from . import handle as H
+
+    state = {}
+
+    def run(block: RowBlock, x_padded, y_slot):
+        if "A" not in state:
+            rp = torch.from_numpy(block.row_ptr).to(device)
+            ci = torch.from_numpy(block.col.astype(np.int32)).to(device)
+            va = torch.from_numpy(block.val).to(device)
+            A = H.anonymouslibHandle(block.m, block.n, dtype=str(block.val.dtype))
+            assert A.inputCSR(block.nnz, rp, ci, va) == 0
+            assert A.setSigma(sigma) == 0
+            assert A.setSpmvMode(mode) == 0
+            assert A.setStream(torch.cuda.current_stream(device).cuda_stream) == 0
+            assert A.asCSR5() == 0
+            state.update(A=A, keep=(rp, ci, va))
+        A = state["A"]
+        assert A.setX(x_padded) == 0
+        assert A.spmv(1.0, y_slot) == 0
+        return y_slot
+
+    run.state = state
+    return run

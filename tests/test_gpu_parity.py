@@ -451,3 +451,66 @@ def test_multi_tile_rows_stress_cross_xcd_protocol(oracle):
         scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
         tol = 1e-12 if dtype == np.float64 else 2e-5
         assert np.all(np.abs(y2[0] - exp) <= tol * np.maximum(scale, 1.0))
+
+
+# ---------------------------------------------------------------------------------------------------
+# coupled iterations
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 3])
+def test_coupled_step_writes_next_x_in_place(oracle, world):
+    """One rank's view of a `world`-way coupled step on the GPU: the CSR5 SpMV of the remapped block must put
+    exactly A[block] x into the rank's slot of the next x (the collective itself is covered by the gloo tests)."""
+    import torch
+    from benchmark_spmv_using_csr5_amd import sharding as S
+    dev = torch.device("cuda:0")
+    mat = M.rmat(scale=12, edge_factor=8, seed=5)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=6, mode="int")
+    y_ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    got = np.zeros(mat.m)
+    for rank in range(world):
+        cp = S.CoupledSpmv(mat.row_ptr, mat.col, val, mat.n, rank, world)
+        run = S.hip_coupled_spmv(dev)
+        a = torch.from_numpy(cp.layout.to_padded(x)).to(dev)
+        b = torch.full_like(a, -7.0)
+        cp.step(run, a, b)           # no process group: the all-gather is skipped, only this rank's slot is written
+        torch.cuda.synchronize()
+        bh = b.cpu().numpy()
+        lo, hi = cp.block.row_lo, cp.block.row_hi
+        slot = bh[rank * cp.layout.width: rank * cp.layout.width + (hi - lo)]
+        nonempty = np.diff(cp.block.row_ptr) > 0
+        assert np.array_equal(slot[nonempty], y_ref[lo:hi][nonempty])
+        # nothing outside the slot was touched
+        mask = np.ones(bh.size, dtype=bool)
+        mask[rank * cp.layout.width: rank * cp.layout.width + (hi - lo)] = False
+        assert np.all(bh[mask] == -7.0)
+        got[lo:hi] = np.where(nonempty, slot, 0.0)
+        run.state["A"].destroy()
+        run.state["A"].close()
+    assert np.array_equal(got, np.where(np.diff(mat.row_ptr) > 0, y_ref, 0.0))
+
+
+@pytest.mark.gpu
+def test_coupled_power_iteration_single_gpu(oracle):
+    import torch
+    from benchmark_spmv_using_csr5_amd import sharding as S
+    dev = torch.device("cuda:0")
+    mat = M.rmat(scale=12, edge_factor=8, seed=5)
+    val, x0 = M.fill_values(mat.nnz, mat.n, np.float64, seed=6, mode="pos")
+    x0 = x0 / np.linalg.norm(x0)
+    cp = S.CoupledSpmv(mat.row_ptr, mat.col, val, mat.n, 0, 1)
+    run = S.hip_coupled_spmv(dev)
+    a = torch.from_numpy(cp.layout.to_padded(x0)).to(dev)
+    b = torch.zeros_like(a)
+    xk, lam = cp.power_iteration(run, a, b, iters=15)
+    torch.cuda.synchronize()
+    x, lam_ref = x0.copy(), None
+    for _ in range(15):
+        y = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+        lam_ref = float(np.dot(x, y) / np.dot(x, x))
+        x = y / np.linalg.norm(y)
+    got = cp.layout.from_padded(xk.cpu().numpy())
+    assert np.max(np.abs(got - x)) < 1e-10          # fp64, different summation order per row
+    assert abs(float(lam) - lam_ref) < 1e-9 * abs(lam_ref)
+    run.state["A"].destroy()
+    run.state["A"].close()

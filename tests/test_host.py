@@ -191,3 +191,86 @@ def test_sharded_spmv_world2_gloo():
     assert [r[1] for r in res] == [True, True]
     total = M.webbase_like(scale=0.01, seed=3).nnz
     assert res[0][2] + res[1][2] == total and abs(res[0][2] - res[1][2]) < 0.2 * total
+
+
+# ---------------------------------------------------------------------------------------------------
+# coupled iterations: y shards written into the next x + in-place all-gather
+# ---------------------------------------------------------------------------------------------------
+def test_padded_layout_roundtrip_and_column_remap():
+    rng = np.random.default_rng(0)
+    for cuts in ([0, 10, 10, 37, 100], [0, 100], [0, 0, 64, 130], [0, 1, 2, 3]):
+        lay = S.PaddedLayout(cuts)
+        n = cuts[-1]
+        assert lay.width % S.PaddedLayout.ALIGN == 0 and lay.width >= np.diff(cuts).max()
+        v = rng.standard_normal(n)
+        padded = lay.to_padded(v)
+        assert padded.size == lay.padded_len and np.array_equal(lay.from_padded(padded), v)
+        col = rng.integers(0, n, 500)
+        assert np.array_equal(padded[lay.remap_columns(col)], v[col])  # the remapped gather reads the same x
+        own = lay.owner(col)
+        assert np.all((np.asarray(cuts)[own] <= col) & (col < np.asarray(cuts)[own + 1]))
+
+
+def _coupled_problem():
+    mat = M.rmat(scale=11, edge_factor=8, seed=5)            # square, skewed rows, empty rows
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=6, mode="pos")
+    return mat, val, x / np.linalg.norm(x)
+
+
+def _power_reference(orc, mat, val, x0, iters):
+    x, lam = x0.copy(), None
+    for _ in range(iters):
+        y = orc.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+        lam = float(np.dot(x, y) / np.dot(x, x))
+        x = y / np.linalg.norm(y)
+    return x, lam
+
+
+def _coupled_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle.csr5_oracle import Oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mat, val, x0 = _coupled_problem()
+        orc = Oracle()
+        cp = S.CoupledSpmv(mat.row_ptr, mat.col, val, mat.n, rank, world)
+        lay = cp.layout
+
+        def local(block, xp, y_slot):  # CPU stand-in for the per-rank HIP kernel
+            y = orc.csr_spmv(block.m, block.row_ptr, block.col, block.val, xp.numpy())
+            y_slot.copy_(torch.from_numpy(y))
+
+        a = torch.from_numpy(lay.to_padded(x0))
+        b = torch.zeros_like(a)
+        # one plain step first: every rank must end up with the complete A x
+        cp.step(local, a, b)
+        y1 = lay.from_padded(b.numpy())
+        ok_step = bool(np.array_equal(y1, orc.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x0)))
+        b.zero_()
+        xk, lam = cp.power_iteration(local, a, b, iters=12)
+        x_ref, lam_ref = _power_reference(orc, mat, val, x0, 12)
+        err = float(np.max(np.abs(lay.from_padded(xk.numpy()) - x_ref)))
+        q.put((rank, ok_step, err, abs(float(lam) - lam_ref) / abs(lam_ref), int(cp.block.nnz)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_coupled_power_iteration_gloo(world):
+    """per-iteration collective path on CPU: y shard -> slot of the next x -> in-place all-gather."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_coupled_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), "A x differs after one coupled step"
+    assert max(r[2] for r in res) < 1e-12 and max(r[3] for r in res) < 1e-12
+    assert sum(r[4] for r in res) == _coupled_problem()[0].nnz
