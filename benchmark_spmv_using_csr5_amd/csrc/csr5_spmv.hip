@@ -64,7 +64,22 @@ __device__ __forceinline__ double dpp_move(double v)
 }
 // lanes masked off by row/bank masks or shifted in from outside a row read 0 (old = 0, bound_ctrl off)
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108;
 constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHL1 = 0x130;
+
+// value of lane `src` (wave-uniform index) in every lane: v_readlane, no LDS crossbar trip
+template <typename VT>
+__device__ __forceinline__ VT bcast_lane(VT v, int src)
+{
+    if constexpr (sizeof(VT) == 8) {
+        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
+        return __builtin_bit_cast(VT, ((unsigned long long)hi << 32) | lo);
+    } else {
+        return __builtin_bit_cast(VT, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+    }
+}
 
 // sum over the 64 lanes, result in every lane (6 DPP steps + one readlane broadcast)
 template <typename VT>
@@ -76,7 +91,7 @@ __device__ __forceinline__ VT wave_sum(VT v)
     v += dpp_move<DPP_ROW_SHR8>(v);                 // lane 15 of every row holds the row sum
     v += dpp_move<DPP_ROW_BCAST15, 0xA>(v);         // rows 1,3 += row 0,2 totals
     v += dpp_move<DPP_ROW_BCAST31, 0xC>(v);         // rows 2,3 += lane 31 total -> lane 63 = wave sum
-    return __shfl(v, OMEGA - 1, OMEGA);             // v_readlane broadcast
+    return bcast_lane(v, OMEGA - 1);
 }
 // value of lane l+1 (lane 63 receives 0)
 template <typename VT>
@@ -553,14 +568,43 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     // R[j] = lead[j] + (present[j] ? 0 : R[j+1])  -- backward segmented scan, 6 shuffle steps.
     CSR5_TSTAMP(t, 5);
     VT R = f0 ? (VT)0 : first_sum;
-    if (pmask != ~0ull) {
+    // All on DPP / readlane (a ds_bpermute shuffle costs an LDS round trip per step): 4 in-row steps
+    // (row_shl reads 0 across a 16-lane row edge), then the three row edges top-down: the lanes whose
+    // run leaves row r add the finished R of the first lane of row r+1.  Steps no lane needs are skipped
+    // by scalar tests on the flag-owner mask (a step of k lanes matters only if k absent lanes are adjacent).
+    const unsigned long long z1 = ~pmask;
+    if (z1) {
         const unsigned long long ahead = pmask >> lane;
         const int dist = ahead ? __builtin_ctzll(ahead) : OMEGA - 1 - lane;
+        {
+            const VT up = dpp_move<DPP_ROW_SHL1>(R);
+            R += dist >= 1 ? up : (VT)0;
+        }
+        const unsigned long long z2 = z1 & (z1 >> 1);
+        if (z2) {
+            {
+                const VT up = dpp_move<DPP_ROW_SHL2>(R);
+                R += dist >= 2 ? up : (VT)0;
+            }
+            const unsigned long long z4 = z2 & (z2 >> 2);
+            if (z4) {
+                {
+                    const VT up = dpp_move<DPP_ROW_SHL4>(R);
+                    R += dist >= 4 ? up : (VT)0;
+                }
+                if (z4 & (z4 >> 4)) {
+                    const VT up = dpp_move<DPP_ROW_SHL8>(R);
+                    R += dist >= 8 ? up : (VT)0;
+                }
+            }
+        }
+        const int reach = lane + dist;
 #pragma unroll
-        for (int k = 1; k < OMEGA; k <<= 1) {
-            const VT up = __shfl_down(R, k, OMEGA);
-            if (dist >= k)
-                R += up;
+        for (int edge = 48; edge >= 16; edge -= 16) {
+            if (!((pmask >> (edge - 1)) & 1ull)) { // lane edge-1 owns no flag: its run crosses the edge
+                const VT carry_in = bcast_lane(R, edge);
+                R += ((lane >> 4) == (edge >> 4) - 1 && reach >= edge) ? carry_in : (VT)0;
+            }
         }
     }
     const VT S = lane_above(R); // lane 63 gets 0
@@ -590,7 +634,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         // row); slot indices grow with the lane, so the highest storing lane knows nseg
         const unsigned long long smask = __ballot(stored_hi != 0);
         if (smask) {
-            const int nseg = __shfl(stored_hi, 63 - __builtin_clzll(smask), OMEGA);
+            const int nseg = __builtin_amdgcn_readlane(stored_hi, 63 - __builtin_clzll(smask));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             for (int j = lane; j < nseg; j += OMEGA)
