@@ -48,18 +48,25 @@ extern "C" int csr5hip_debug_set_timing_buffer(void *dptr)
 
 // ---- cross-lane helpers on DPP (data-parallel primitives: lane moves folded into VALU operands, no LDS
 //      crossbar round trip as with ds_bpermute).  A 64-bit value moves as two 32-bit halves. -------------
+// Full row/bank masks: bound_ctrl makes source lanes outside the row / wave read 0 and leaves no "old"
+// operand to initialise (2 VALU less per 64-bit move).  Partial masks: masked lanes keep old = 0.
+template <int CTRL, int ROW_MASK_ = 0xF, int BANK_MASK_ = 0xF>
+__device__ __forceinline__ int dpp_word(int w)
+{
+    constexpr bool FULL = ROW_MASK_ == 0xF && BANK_MASK_ == 0xF;
+    return __builtin_amdgcn_update_dpp(0, w, CTRL, ROW_MASK_, BANK_MASK_, FULL);
+}
 template <int CTRL, int ROW_MASK_ = 0xF, int BANK_MASK_ = 0xF>
 __device__ __forceinline__ float dpp_move(float v)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL,
-                                                                 ROW_MASK_, BANK_MASK_, false));
+    return __builtin_bit_cast(float, dpp_word<CTRL, ROW_MASK_, BANK_MASK_>(__builtin_bit_cast(int, v)));
 }
 template <int CTRL, int ROW_MASK_ = 0xF, int BANK_MASK_ = 0xF>
 __device__ __forceinline__ double dpp_move(double v)
 {
     const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK_, BANK_MASK_, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK_, BANK_MASK_, false);
+    const int lo = dpp_word<CTRL, ROW_MASK_, BANK_MASK_>((int)(unsigned)b);
+    const int hi = dpp_word<CTRL, ROW_MASK_, BANK_MASK_>((int)(unsigned)(b >> 32));
     return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
 }
 // lanes masked off by row/bank masks or shifted in from outside a row read 0 (old = 0, bound_ctrl off)
@@ -81,7 +88,9 @@ __device__ __forceinline__ VT bcast_lane(VT v, int src)
     }
 }
 
-// sum over the 64 lanes, result in every lane (6 DPP steps + one readlane broadcast)
+// sum over the 64 lanes, result in every lane (6 DPP steps + one readlane broadcast).  Only lane 63 has
+// to end up right, so the two row broadcasts run with full row masks as well: rows that receive a value
+// they should not are never read again.
 template <typename VT>
 __device__ __forceinline__ VT wave_sum(VT v)
 {
@@ -89,9 +98,27 @@ __device__ __forceinline__ VT wave_sum(VT v)
     v += dpp_move<DPP_ROW_SHR2>(v);                 // quads
     v += dpp_move<DPP_ROW_SHR4>(v);                 // 8
     v += dpp_move<DPP_ROW_SHR8>(v);                 // lane 15 of every row holds the row sum
-    v += dpp_move<DPP_ROW_BCAST15, 0xA>(v);         // rows 1,3 += row 0,2 totals
-    v += dpp_move<DPP_ROW_BCAST31, 0xC>(v);         // rows 2,3 += lane 31 total -> lane 63 = wave sum
+    v += dpp_move<DPP_ROW_BCAST15>(v);              // lane 16r+15 += total of row r-1
+    v += dpp_move<DPP_ROW_BCAST31>(v);              // rows 2,3 += lane 31 -> lane 63 = wave sum
     return bcast_lane(v, OMEGA - 1);
+}
+// sum over lanes 0..count-1 of a value that is ZERO in every other lane (count wave-uniform, 1..64)
+template <typename VT>
+__device__ __forceinline__ VT head_sum(VT v, int count)
+{
+    if (count <= 4) {
+        v += dpp_move<DPP_ROW_SHR1>(v);
+        v += dpp_move<DPP_ROW_SHR2>(v);
+        return bcast_lane(v, 3);
+    }
+    if (count <= 16) {
+        v += dpp_move<DPP_ROW_SHR1>(v);
+        v += dpp_move<DPP_ROW_SHR2>(v);
+        v += dpp_move<DPP_ROW_SHR4>(v);
+        v += dpp_move<DPP_ROW_SHR8>(v);
+        return bcast_lane(v, 15);
+    }
+    return wave_sum(v);
 }
 // value of lane l+1 (lane 63 receives 0)
 template <typename VT>
@@ -395,7 +422,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
 
     // products of this lane's sigma elements (coalesced: lane stride 1 at every step)
     constexpr int NREG = SIGMA > 0 ? SIGMA : 1;
-    VT prod[NREG];
+    VT mv[NREG], mx[NREG]; // matrix value and gathered x of element i: multiplied inside the fused multiply-adds below
     VT lead_next = 0;
     if constexpr (SIGMA > 0) {
         int32_t c[NREG];
@@ -440,12 +467,12 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++) {
                     const unsigned dlt = (unsigned)(c[i] - wlo);
-                    xv[i] = dlt < (unsigned)XWIN_ELEMS ? win[dlt] : x[c[i]];
+                    xv[i] = dlt < (unsigned)XWIN_ELEMS ? win[dlt] : x[(uint32_t)c[i]];
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++)
-                    xv[i] = x[c[i]];
+                    xv[i] = x[(uint32_t)c[i]];
             }
         } else {
 #pragma unroll
@@ -453,7 +480,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
 #if defined(CSR5_ABLATE) && (CSR5_ABLATE & 1)
                 xv[i] = (VT)c[i]; // experiment build only: no x gather
 #else
-                xv[i] = x[c[i]];
+                xv[i] = x[(uint32_t)c[i]];
 #endif
         }
         if constexpr (FUSED) {
@@ -461,16 +488,18 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
             // gather x for exactly those lanes; the other lanes re-read x[0] (one cache line), so the
             // gather is unconditional and rides in the same round trip as the tile's own gathers
             const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
-            const VT sx = x[lane < L ? spill_c : 0];
+            const VT sx = x[lane < L ? (uint32_t)spill_c : 0u];
             lead_next = lane < L ? spill_v * sx : (VT)0;
         }
         __builtin_amdgcn_sched_barrier(0);
         CSR5_TSTAMP(t, 2);
 #pragma unroll
-        for (int i = 0; i < SIGMA; i++)
-            prod[i] = v[i] * xv[i];
+        for (int i = 0; i < SIGMA; i++) {
+            mv[i] = v[i];
+            mx[i] = xv[i];
+        }
 #ifdef CSR5_TIMING_PROBE
-        asm volatile("" ::"v"(prod[SIGMA - 1]), "v"(lead_next));
+        asm volatile("" ::"v"(mx[SIGMA - 1]), "v"(lead_next));
         CSR5_TSTAMP(t, 3);
 #endif
     } else if constexpr (FUSED) {
@@ -485,9 +514,16 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     }
     auto product = [&](int i) -> VT {
         if constexpr (SIGMA > 0)
-            return prod[i];
+            return mv[i] * mx[i];
         else
             return vt[i * OMEGA] * x[ct[i * OMEGA]];
+    };
+    // acc + element i as ONE fused multiply-add
+    auto accumulate = [&](int i, VT acc) -> VT {
+        if constexpr (SIGMA > 0)
+            return __builtin_fma(mv[i], mx[i], acc);
+        else
+            return __builtin_fma(vt[i * OMEGA], x[ct[i * OMEGA]], acc);
     };
 
     // Decode the descriptor and reduce the spill HERE, in the entry block, before any data-dependent
@@ -501,8 +537,12 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     const bool present = f0 | ((flags & 0x7FFFFFFFu) != 0);
     const unsigned long long pmask = __ballot(present);
     VT spill = 0;
-    if constexpr (FUSED)
-        spill = wave_sum(lead_next);
+    if constexpr (FUSED) {
+        // lead_next is zero beyond the spill length, so a short spill needs only the first DPP steps
+        const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
+        if (L > 0)
+            spill = head_sum(lead_next, L);
+    }
     const uint32_t rs_raw = __builtin_amdgcn_readfirstlane(tp0);
     const uint32_t row_stop = __builtin_amdgcn_readfirstlane(tp1) & ROW_MASK;
 
@@ -511,7 +551,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
         VT s = 0;
 #pragma unroll
         for (int i = 0; i < sigma; i++)
-            s += product(i);
+            s = accumulate(i, s);
         s = wave_sum(s);
         if (lane == 0) {
             if constexpr (FUSED) // member of a multi-tile run: expected count lives at the run head
@@ -558,7 +598,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
             direct = true;
             sum = 0;
         }
-        sum += product(i);
+        sum = accumulate(i, sum);
     }
     if (!direct)
         first_sum = sum;
