@@ -406,33 +406,47 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     uint32_t mt_next_x = 0;
     int32_t spill_c = 0;
     VT spill_v = 0;
+    // Issue order matters: vector loads return in order and this first round trip is bandwidth-bound
+    // (every resident wave streams its tile at once), so the words the SECOND round trip depends on --
+    // the column indices -- are requested first; the x gathers then go out while the values (2/3 of the
+    // bytes) are still streaming in, instead of after them.
+    size_t spill_pos = 0;
     if constexpr (FUSED) {
         // first 64 elements (CSR order) of tile t+1: a transposed tile keeps element j at
         // (j % sigma)*omega + j / sigma, the CSR tail keeps it at j
         const size_t nb = (size_t)(t + 1) * T;
         size_t pos = (t + 1 == g.p - 1) ? nb + lane : nb + (size_t)(lane % sigma) * OMEGA + lane / sigma;
-        pos = pos < (size_t)g.nnz ? pos : (size_t)g.nnz - 1;
+        spill_pos = pos < (size_t)g.nnz ? pos : (size_t)g.nnz - 1;
 #if !(defined(CSR5_ABLATE) && (CSR5_ABLATE & 32))
-        spill_c = col[pos];
-        spill_v = val[pos];
+        spill_c = col[spill_pos];
 #endif
+    }
+    constexpr int NREG = SIGMA > 0 ? SIGMA : 1;
+    int32_t c[NREG];
+    VT v[NREG];
+    if constexpr (SIGMA > 0) {
+#pragma unroll
+        for (int i = 0; i < SIGMA; i++)
+            c[i] = ct[i * OMEGA];
+        __builtin_amdgcn_sched_barrier(0);
     }
     const uint32_t w0 = d[lane];
     const uint32_t w1 = num_packet > 1 ? d[OMEGA + lane] : 0u;
+    if constexpr (FUSED) {
+#if !(defined(CSR5_ABLATE) && (CSR5_ABLATE & 32))
+        spill_v = val[spill_pos];
+#endif
+    }
 
-    // products of this lane's sigma elements (coalesced: lane stride 1 at every step)
-    constexpr int NREG = SIGMA > 0 ? SIGMA : 1;
+    // this lane's sigma elements (coalesced: lane stride 1 at every step)
     VT mv[NREG], mx[NREG]; // matrix value and gathered x of element i: multiplied inside the fused multiply-adds below
     VT lead_next = 0;
     if constexpr (SIGMA > 0) {
-        int32_t c[NREG];
-        VT v[NREG];
 #pragma unroll
         for (int i = 0; i < SIGMA; i++) {
             // plain loads on purpose: a non-temporal hint on the streams helps only when the matrix is far
             // larger than the 256-MiB Infinity Cache (R-MAT 22: +5 %) and costs 18-25 % when it is not
             // (R-MAT 20, nd24k-like), because repeated SpMVs then re-stream from HBM
-            c[i] = ct[i * OMEGA];
             v[i] = vt[i * OMEGA];
         }
         // everything above is in flight before anything below consumes a loaded value
