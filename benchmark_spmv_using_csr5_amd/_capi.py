@@ -110,6 +110,8 @@ SYMBOLS = [
                                      C.c_int, C.c_int, C.POINTER(DeviceCsrStruct)]),
     ("csr5hip_csr_release", C.c_int, [C.POINTER(DeviceCsrStruct)]),
     ("csr5hip_mtx_load", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(DeviceCsrStruct)]),
+    ("csr5hip_save", C.c_int, [_H, C.c_char_p]),
+    ("csr5hip_load", C.c_int, [C.c_char_p, C.POINTER(_H), C.POINTER(DeviceCsrStruct)]),
 ]
 
 _lib = None

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 #include "csr5_internal.h"
 
@@ -274,19 +275,12 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
     return CSR5HIP_SUCCESS;
 }
 
-int csr5hip_as_csr5(csr5hip_handle h)
+// ---- pieces of the conversion shared by csr5hip_as_csr5 and csr5hip_load -------------------------
+// geometry from sigma (anonymouslib_cuda.h:121-137)
+static int derive_geometry(csr5hip_handle h, int sigma)
 {
-    if (!h)
-        return CSR5HIP_INVALID_ARGUMENT;
-    if (h->format == CSR5HIP_FORMAT_CSR5)
-        return CSR5HIP_SUCCESS;
-    if (h->format != CSR5HIP_FORMAT_CSR)
-        return CSR5HIP_UNKOWN_FORMAT;
-    if (h->sigma_request < CSR5HIP_MIN_SIGMA)
-        h->sigma_request = csr5hip_auto_sigma(h->g.m, h->g.nnz, h->value_type);
-
     Geometry &g = h->g;
-    g.sigma = h->sigma_request;
+    g.sigma = sigma;
     g.bit_y = bit_y_of(g.sigma);
     g.bit_all = g.bit_y + BIT_SS;
     if (g.bit_all > 31) // the first flag must sit in the first packet (anonymouslib_cuda.h:130)
@@ -301,9 +295,14 @@ int csr5hip_as_csr5(csr5hip_handle h)
     h->opt.long_runs = 0;
     h->t_malloc = h->t_tile_ptr = h->t_tile_desc = h->t_transpose = 0;
     h->drop_graphs();
-    hipStream_t s = h->stream;
+    return CSR5HIP_SUCCESS;
+}
 
-    double t0 = now_ms();
+// the auxiliary arrays of the handle (anonymouslib_cuda.h:142-151) plus the carry state, zeroed
+static int reserve_aux(csr5hip_handle h)
+{
+    const Geometry &g = h->g;
+    hipStream_t s = h->stream;
     const size_t p1 = (size_t)g.p + 1;
     const size_t desc_words = (size_t)(g.p > 0 ? g.p : 1) * OMEGA * g.num_packet;
     HIP_TRY(h->b_tile_ptr.reserve(p1 * 4));
@@ -332,6 +331,47 @@ int csr5hip_as_csr5(csr5hip_handle h)
     HIP_TRY(hipMemsetAsync(h->d.carry_cnt, 0, p1 * 4, s));
     HIP_TRY(hipMemsetAsync(h->d.counters, 0, 16, s));
     HIP_TRY(hipStreamSynchronize(s));
+    return CSR5HIP_SUCCESS;
+}
+
+// what the fused kernel needs on top of the reference's format arrays: carry meta, x windows, tile headers
+static int derive_kernel_tables(csr5hip_handle h)
+{
+    const Geometry &g = h->g;
+    hipStream_t s = h->stream;
+    HIP_TRY(launch_carry_meta(g, h->d, s));
+    HIP_TRY(launch_tile_window(g, h->d, (int)h->vsize(), s));
+    HIP_TRY(launch_tile_hdr(g, h->d, s));
+    uint32_t stats[4] = {0, 0, 0, 0}; // x-window tiles, covered non-zeros, long runs
+    HIP_TRY(hipMemcpyAsync(stats, h->d.counters, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    h->xwin_tiles = (int)stats[0];
+    h->xwin_covered = (long long)stats[1];
+    h->opt.long_runs = stats[2] != 0;
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_as_csr5(csr5hip_handle h)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (h->format == CSR5HIP_FORMAT_CSR5)
+        return CSR5HIP_SUCCESS;
+    if (h->format != CSR5HIP_FORMAT_CSR)
+        return CSR5HIP_UNKOWN_FORMAT;
+    if (h->sigma_request < CSR5HIP_MIN_SIGMA)
+        h->sigma_request = csr5hip_auto_sigma(h->g.m, h->g.nnz, h->value_type);
+
+    int rc = derive_geometry(h, h->sigma_request);
+    if (rc != CSR5HIP_SUCCESS)
+        return rc;
+    Geometry &g = h->g;
+    hipStream_t s = h->stream;
+
+    double t0 = now_ms();
+    rc = reserve_aux(h);
+    if (rc != CSR5HIP_SUCCESS)
+        return rc;
     h->t_malloc += now_ms() - t0;
 
     if (g.p > 0) {
@@ -370,20 +410,161 @@ int csr5hip_as_csr5(csr5hip_handle h)
         // step 3: in-place tile transpose of column_index and value
         t0 = now_ms();
         HIP_TRY(launch_transpose(g, h->d, h->value_type, true, s));
-        HIP_TRY(launch_carry_meta(g, h->d, s));
-        HIP_TRY(launch_tile_window(g, h->d, (int)h->vsize(), s));
-        HIP_TRY(launch_tile_hdr(g, h->d, s));
-        uint32_t stats[4] = {0, 0, 0, 0}; // x-window tiles, covered non-zeros, long runs
-        HIP_TRY(hipMemcpyAsync(stats, h->d.counters, 16, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        h->xwin_tiles = (int)stats[0];
-        h->xwin_covered = (long long)stats[1];
-        h->opt.long_runs = stats[2] != 0;
+        rc = derive_kernel_tables(h);
+        if (rc != CSR5HIP_SUCCESS)
+            return rc;
         h->t_transpose += now_ms() - t0;
     }
     h->opt.x_window = xwin_decision(h);
     h->opt.lds_y = ldsy_decision(h);
     h->format = CSR5HIP_FORMAT_CSR5;
+    return CSR5HIP_SUCCESS;
+}
+
+// ---- serialise / deserialise (checkpoint of the converted matrix) ----------
+// File = header + row_ptr + column_index and value IN TILE ORDER + the four CSR5 arrays of the reference
+// (anonymouslib_cuda.h:27-52).  Loading skips the conversion: only the kernel-side tables are re-derived.
+namespace {
+struct Csr5FileHeader {
+    char magic[8];      // "CSR5HIP1"
+    int32_t value_type, omega, sigma, m, n, nnz, p, num_packet, num_offsets, tail_start;
+    int32_t reserved[4];
+};
+bool write_dev(FILE *f, const void *dptr, size_t bytes, std::vector<char> &stage)
+{
+    if (!bytes)
+        return true;
+    stage.resize(bytes);
+    if (hipMemcpy(stage.data(), dptr, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        return false;
+    return fwrite(stage.data(), 1, bytes, f) == bytes;
+}
+bool read_dev(FILE *f, void *dptr, size_t bytes, std::vector<char> &stage)
+{
+    if (!bytes)
+        return true;
+    stage.resize(bytes);
+    if (fread(stage.data(), 1, bytes, f) != bytes)
+        return false;
+    return hipMemcpy(dptr, stage.data(), bytes, hipMemcpyHostToDevice) == hipSuccess;
+}
+} // namespace
+
+int csr5hip_save(csr5hip_handle h, const char *path)
+{
+    if (!h || !path)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (h->format != CSR5HIP_FORMAT_CSR5) {
+        g_last_error = "csr5hip_save: the handle is not in CSR5 format";
+        return CSR5HIP_UNKOWN_FORMAT;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        g_last_error = std::string("csr5hip_save: cannot open ") + path;
+        return CSR5HIP_INVALID_ARGUMENT;
+    }
+    const Geometry &g = h->g;
+    Csr5FileHeader hd;
+    memset(&hd, 0, sizeof hd);
+    memcpy(hd.magic, "CSR5HIP1", 8);
+    hd.value_type = h->value_type, hd.omega = OMEGA, hd.sigma = g.sigma, hd.m = g.m, hd.n = g.n, hd.nnz = g.nnz;
+    hd.p = g.p, hd.num_packet = g.num_packet, hd.num_offsets = h->num_offsets, hd.tail_start = g.tail_start;
+    std::vector<char> stage;
+    bool ok = fwrite(&hd, sizeof hd, 1, f) == 1;
+    ok = ok && write_dev(f, h->d.row_ptr, ((size_t)g.m + 1) * 4, stage);
+    ok = ok && write_dev(f, h->d.col, (size_t)g.nnz * 4, stage);
+    ok = ok && write_dev(f, h->d.val, (size_t)g.nnz * h->vsize(), stage);
+    ok = ok && write_dev(f, h->d.tile_ptr, ((size_t)g.p + 1) * 4, stage);
+    ok = ok && write_dev(f, h->d.tile_desc, (size_t)g.p * OMEGA * g.num_packet * 4, stage);
+    ok = ok && write_dev(f, h->d.offset_ptr, ((size_t)g.p + 1) * 4, stage);
+    ok = ok && write_dev(f, h->d.offset, (size_t)h->num_offsets * 4, stage);
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        g_last_error = std::string("csr5hip_save: write failed: ") + path;
+        return CSR5HIP_HIP_ERROR;
+    }
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_load(const char *path, csr5hip_handle *out, csr5hip_csr *arrays)
+{
+    if (!path || !out || !arrays)
+        return CSR5HIP_INVALID_ARGUMENT;
+    *out = nullptr;
+    memset(arrays, 0, sizeof *arrays);
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        g_last_error = std::string("csr5hip_load: cannot open ") + path;
+        return CSR5HIP_INVALID_ARGUMENT;
+    }
+    Csr5FileHeader hd;
+    bool ok = fread(&hd, sizeof hd, 1, f) == 1 && memcmp(hd.magic, "CSR5HIP1", 8) == 0;
+    ok = ok && hd.omega == OMEGA && (hd.value_type == CSR5HIP_F64 || hd.value_type == CSR5HIP_F32);
+    ok = ok && hd.m >= 0 && hd.n >= 0 && hd.nnz >= 0 && hd.sigma >= CSR5HIP_MIN_SIGMA && hd.sigma <= CSR5HIP_MAX_SIGMA;
+    ok = ok && hd.num_offsets >= 0 && hd.tail_start >= 0 && hd.tail_start <= hd.m;
+    ok = ok && hd.p == (int)(((long long)hd.nnz + (long long)OMEGA * hd.sigma - 1) / ((long long)OMEGA * hd.sigma));
+    ok = ok && hd.num_packet == num_packet_of(hd.sigma);
+    if (!ok) {
+        fclose(f);
+        g_last_error = std::string("csr5hip_load: not a CSR5 checkpoint of this library: ") + path;
+        return CSR5HIP_INVALID_ARGUMENT;
+    }
+    const size_t vs = hd.value_type == CSR5HIP_F64 ? 8 : 4;
+    csr5hip_handle h = nullptr;
+    int rc = csr5hip_create(&h, hd.m, hd.n, hd.value_type);
+    auto fail_with = [&](int code, const char *msg) {
+        if (msg)
+            g_last_error = std::string("csr5hip_load: ") + msg;
+        fclose(f);
+        if (h)
+            csr5hip_free(h);
+        csr5hip_csr_release(arrays);
+        return code;
+    };
+    if (rc != CSR5HIP_SUCCESS)
+        return fail_with(rc, nullptr);
+    arrays->m = hd.m, arrays->n = hd.n, arrays->nnz = hd.nnz, arrays->value_type = hd.value_type;
+    if (hipMalloc(&arrays->d_row_ptr, ((size_t)hd.m + 1) * 4) != hipSuccess ||
+        hipMalloc(&arrays->d_col_idx, (size_t)(hd.nnz ? hd.nnz : 1) * 4) != hipSuccess ||
+        hipMalloc(&arrays->d_val, (size_t)(hd.nnz ? hd.nnz : 1) * vs) != hipSuccess)
+        return fail_with(CSR5HIP_HIP_ERROR, "device allocation failed");
+    std::vector<char> stage;
+    ok = read_dev(f, arrays->d_row_ptr, ((size_t)hd.m + 1) * 4, stage);
+    ok = ok && read_dev(f, arrays->d_col_idx, (size_t)hd.nnz * 4, stage);
+    ok = ok && read_dev(f, arrays->d_val, (size_t)hd.nnz * vs, stage);
+    if (!ok)
+        return fail_with(CSR5HIP_INVALID_ARGUMENT, "truncated file");
+    csr5hip_input_csr(h, hd.nnz, arrays->d_row_ptr, arrays->d_col_idx, arrays->d_val);
+    h->sigma_request = hd.sigma;
+    rc = derive_geometry(h, hd.sigma);
+    if (rc == CSR5HIP_SUCCESS)
+        rc = reserve_aux(h);
+    if (rc != CSR5HIP_SUCCESS)
+        return fail_with(rc, nullptr);
+    h->g.tail_start = hd.tail_start;
+    h->num_offsets = hd.num_offsets;
+    if (hd.num_offsets > 0) {
+        if (h->b_offset.reserve((size_t)hd.num_offsets * 4) != hipSuccess)
+            return fail_with(CSR5HIP_HIP_ERROR, "device allocation failed");
+        h->d.offset = (int32_t *)h->b_offset.ptr;
+    }
+    ok = read_dev(f, h->d.tile_ptr, ((size_t)hd.p + 1) * 4, stage);
+    ok = ok && read_dev(f, h->d.tile_desc, (size_t)hd.p * OMEGA * hd.num_packet * 4, stage);
+    ok = ok && read_dev(f, h->d.offset_ptr, ((size_t)hd.p + 1) * 4, stage);
+    ok = ok && read_dev(f, h->d.offset, (size_t)hd.num_offsets * 4, stage);
+    if (!ok)
+        return fail_with(CSR5HIP_INVALID_ARGUMENT, "truncated file");
+    if (hd.p > 0) {
+        rc = derive_kernel_tables(h);
+        if (rc != CSR5HIP_SUCCESS)
+            return fail_with(rc, nullptr);
+    }
+    fclose(f);
+    h->opt.x_window = xwin_decision(h);
+    h->opt.lds_y = ldsy_decision(h);
+    h->format = CSR5HIP_FORMAT_CSR5;
+    *out = h;
     return CSR5HIP_SUCCESS;
 }
 

@@ -157,11 +157,38 @@ class anonymouslibHandle:
             offset=self._d2h(i.d_offset, i.num_offsets, np.int32),
         )
 
+    # -- checkpoint -----------------------------------------------
+    def save(self, path: str) -> int:
+        """Write the CSR5 state (row_ptr, tile-ordered col/val, the four format arrays) to `path`."""
+        import os
+        return self._lib.csr5hip_save(self._h, os.fsencode(path))
+
+    @classmethod
+    def load(cls, path: str):
+        """Restore a checkpoint written by :meth:`save` -> handle already in CSR5 format (no conversion).
+        The CSR arrays live in ``handle.arrays`` (an ``ingest.DeviceCsr`` owned by the handle object)."""
+        import os
+        from .ingest import DeviceCsr
+        lib = _capi.load()
+        h = C.c_void_p()
+        raw = _capi.DeviceCsrStruct()
+        err = lib.csr5hip_load(os.fsencode(path), C.byref(h), C.byref(raw))
+        if err:
+            raise RuntimeError(f"csr5hip_load -> {err}: {_capi.last_error()}")
+        self = cls.__new__(cls)
+        self._lib, self._h, self._vt, self._keep = lib, h, int(raw.value_type), {}
+        self.arrays = DeviceCsr(raw)
+        return self
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.csr5hip_free(self._h)
             self._h = C.c_void_p()
         self._keep = {}
+        arrays = getattr(self, "arrays", None)
+        if arrays is not None:  # CSR arrays of a loaded checkpoint: released after the handle that borrowed them
+            arrays.release()
+            self.arrays = None
 
     def __del__(self):
         try:

@@ -198,6 +198,18 @@ int csr5hip_csr_release(csr5hip_csr *csr);
 /* csr5hip_mtx_read + H2D + csr5hip_coo_to_csr in one call (what `./spmv foo.mtx` does first). */
 int csr5hip_mtx_load(const char *path, int threads, int value_type, csr5hip_csr *out);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Checkpoint of a converted matrix.  csr5hip_save writes the handle's CSR5
+ * state -- row_ptr, column_index / value in tile order and the four format arrays of the reference
+ * (_csr5_partition_pointer, _csr5_partition_descriptor, ..._offset_pointer, ..._offset;
+ * anonymouslib_cuda.h:27-52) -- to one binary file; csr5hip_load restores it into a NEW handle that is in
+ * CSR5 format at once (no conversion pass).  The CSR arrays of the loaded matrix are allocated here and
+ * returned in `arrays` (the handle borrows them as after csr5hip_input_csr; release them with
+ * csr5hip_csr_release AFTER csr5hip_free).  asCSR / destroy on the loaded handle give back plain CSR order.
+ * ------------------------------------------------------------------------------------------------- */
+int csr5hip_save(csr5hip_handle h, const char *path);
+int csr5hip_load(const char *path, csr5hip_handle *h, csr5hip_csr *arrays);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,6 +13,7 @@ torch = pytest.importorskip("torch")
 
 from benchmark_spmv_using_csr5_amd import matrices as M  # noqa: E402
 from benchmark_spmv_using_csr5_amd import handle as H  # noqa: E402
+from benchmark_spmv_using_csr5_amd import _capi  # noqa: E402
 from tests import zoo  # noqa: E402
 
 DEV = "cuda:0"
@@ -514,3 +515,56 @@ def test_coupled_power_iteration_single_gpu(oracle):
     assert abs(float(lam) - lam_ref) < 1e-9 * abs(lam_ref)
     run.state["A"].destroy()
     run.state["A"].close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# checkpoint of the converted matrix
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_save_load_roundtrip(tmp_path, dtype):
+    import torch
+    from benchmark_spmv_using_csr5_amd.handle import anonymouslibHandle
+    dev = torch.device("cuda:0")
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    mat = M.webbase_like(scale=0.02, seed=8)       # empty rows -> offset arrays are exercised
+    val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=2, mode="int")
+    rp, ci, va, xd = (torch.from_numpy(a).to(dev) for a in (mat.row_ptr, mat.col, val, x))
+    y0 = torch.zeros(mat.m, dtype=tdt, device=dev)
+    A = anonymouslibHandle(mat.m, mat.n, dtype=np.dtype(dtype).name)
+    assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0
+    path = str(tmp_path / "a.csr5")
+    assert A.save(path) != 0                        # still CSR: nothing to checkpoint
+    assert A.setSigma(6) == 0 and A.asCSR5() == 0
+    assert A.spmv(1.0, y0) == 0
+    torch.cuda.synchronize()
+    before = A.csr5_arrays()
+    assert A.save(path) == 0
+
+    B = anonymouslibHandle.load(path)
+    ib = B.info()
+    assert (ib.format, ib.m, ib.n, ib.nnz, ib.sigma, ib.p) == (_capi.FORMAT_CSR5, mat.m, mat.n, mat.nnz, 6, A.info().p)
+    after = B.csr5_arrays()
+    for k in ("tile_ptr", "tile_desc", "offset_ptr", "offset"):
+        assert np.array_equal(before[k], after[k]), k
+    y1 = torch.full_like(y0, -1.0)
+    y1[torch.from_numpy(np.diff(mat.row_ptr) == 0).to(dev)] = 0
+    assert B.setX(xd) == 0 and B.spmv(1.0, y1) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    # back to CSR on the loaded arrays: the caller's original matrix
+    assert B.asCSR() == 0
+    host = B.arrays.to_host()
+    assert np.array_equal(host.row_ptr, mat.row_ptr) and np.array_equal(host.col, mat.col)
+    assert np.array_equal(host.val, val)
+    B.close()
+    A.destroy()
+    A.close()
+    # damaged files are rejected before anything is built
+    bad = tmp_path / "bad.csr5"
+    bad.write_bytes(open(path, "rb").read()[:200])
+    with pytest.raises(RuntimeError):
+        anonymouslibHandle.load(str(bad))
+    bad.write_bytes(b"NOTCSR5!" + bytes(100))
+    with pytest.raises(RuntimeError):
+        anonymouslibHandle.load(str(bad))
