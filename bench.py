@@ -66,13 +66,15 @@ def parse_args():
                          "cut into nnz-balanced row blocks (BASELINE config: rmat24 over 8 GPUs)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the synthetic stand-in (experiments)")
+    ap.add_argument("--band", type=float, default=None,
+                    help="webbase only: share of near-diagonal links of the stand-in (default 0.3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
 def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device, scale: float = 1.0,
-               strong: bool = False):
+               strong: bool = False, band=None):
     """Row block `rank` of a global matrix made of `world` equally sized row blocks.  Returns
     (CsrMatrix-like with device tensors or numpy arrays, global n)."""
     from benchmark_spmv_using_csr5_amd import matrices as M
@@ -83,6 +85,8 @@ def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device, s
                 f"R-MAT scale {scale} EF16 (synthetic)")
     gen = {"scircuit": M.scircuit_like, "webbase": M.webbase_like, "nd24k": M.nd24k_like}[workload]
     kw = {} if scale == 1.0 else {"scale": scale}
+    if workload == "webbase" and band is not None:
+        kw["band"] = band
     if workload == "scircuit" and os.environ.get("CSR5_BENCH_ROWCAP"):  # experiment knob, not a config
         kw["row_cap"] = int(os.environ["CSR5_BENCH_ROWCAP"])
     if strong and world > 1:  # one global matrix, nnz-balanced row blocks (sharding.py)
@@ -137,7 +141,7 @@ def main():
     vsize = 8 if dtype_name == "f64" else 4
 
     mat, label = make_shard(args.workload, rank, world, args.seed, np_dtype, dev, args.scale,
-                            strong=args.scaling == "strong")
+                            strong=args.scaling == "strong", band=args.band)
     if args.scale != 1.0:
         label += f" x{args.scale:g}"
     m, n, nnz = mat.m, mat.n, mat.nnz

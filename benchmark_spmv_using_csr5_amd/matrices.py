@@ -107,16 +107,19 @@ def scircuit_like(seed: int = 1, scale: float = 1.0, dtype=np.float64, row_cap: 
     return csr_from_row_lengths(raw, m, rng, band=0.5, name="scircuit-like(synthetic)", dtype=dtype)
 
 
-def webbase_like(seed: int = 2, scale: float = 1.0, dtype=np.float64) -> CsrMatrix:
+def webbase_like(seed: int = 2, scale: float = 1.0, dtype=np.float64, band: float = 0.3) -> CsrMatrix:
     """SuiteSparse webbase-1M stand-in: 1 000 005 square, 3 105 536 nnz, power-law rows capped at
-    4 700, >= 10 % empty rows (stresses the empty-row offsets and the segmented sum)."""
+    4 700, >= 10 % empty rows (stresses the empty-row offsets and the segmented sum).  `band` = share of
+    the links that stay within +-64 of the diagonal (default 0.3: a harsh guess, 70 % of the x gathers are
+    uniformly random; crawl-ordered web graphs keep most links inside a host, i.e. near the diagonal)."""
     rng = np.random.default_rng(seed)
     m = max(int(1_000_005 * scale), 16)
     nnz = max(int(3_105_536 * scale), m // 2)
     raw = np.floor(rng.pareto(1.6, size=m) * 1.6 + 1.0).astype(np.int64)
     raw[rng.random(m) < 0.12] = 0
     raw = _scale_to_total(raw, nnz, rng, cap=4700)
-    return csr_from_row_lengths(raw, m, rng, band=0.3, name="webbase-1M-like(synthetic)", dtype=dtype)
+    name = "webbase-1M-like(synthetic)" if band == 0.3 else f"webbase-1M-like(synthetic, band={band:g})"
+    return csr_from_row_lengths(raw, m, rng, band=band, name=name, dtype=dtype)
 
 
 def nd24k_like(seed: int = 3, scale: float = 1.0, dtype=np.float32) -> CsrMatrix:
