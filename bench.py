@@ -68,10 +68,8 @@ def parse_args():
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the synthetic stand-in (experiments)")
     ap.add_argument("--band", type=float, default=None,
                     help="webbase only: share of near-diagonal links of the stand-in (default 0.3)")
-    ap.add_argument("--spinup-seconds", type=float, default=2.0,
-                    help="untimed replay of the same SpMV before the W warm-up steps: a box that has been idle "
-                         "runs the first seconds of GPU work at lower clocks (measured: 6.3 vs 5.7 us per scircuit "
-                         "SpMV), and W = 50 steps is only 0.3 ms; 0 disables")
+    ap.add_argument("--spinup-seconds", type=float, default=0.0,
+                    help="experiment knob: untimed replay of the same SpMV before the W warm-up steps (default off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
