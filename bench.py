@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--x-window", default="auto", choices=["auto", "off", "force"])
     ap.add_argument("--xcd-remap", type=int, default=1, choices=[0, 1])
     ap.add_argument("--lds-y", default="auto", choices=["auto", "off", "force"])
+    ap.add_argument("--stream-nt", default="auto", choices=["auto", "off", "force"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = one fixed-size row block per GPU (default); strong = ONE global matrix "
                          "cut into nnz-balanced row blocks (BASELINE config: rmat24 over 8 GPUs)")
@@ -173,6 +174,7 @@ def main():
     assert A.setXWindow({"off": 0, "auto": 1, "force": 2}[args.x_window]) == 0
     assert A.setOption(2, args.xcd_remap) == 0  # CSR5HIP_OPT_XCD_REMAP
     assert A.setLdsY({"off": 0, "auto": 1, "force": 2}[args.lds_y]) == 0
+    assert A.setStreamNT({"off": 0, "auto": 1, "force": 2}[args.stream_nt]) == 0
     A.warmup()
     torch.cuda.synchronize()
     if tuned:  # setup, outside every timed region (like asCSR5)

@@ -31,6 +31,7 @@ OPT_SPMV_MODE = 1
 OPT_XCD_REMAP = 2
 OPT_X_WINDOW = 3
 OPT_LDS_Y = 4
+OPT_STREAM_NT = 5
 
 
 class Csr5Info(C.Structure):

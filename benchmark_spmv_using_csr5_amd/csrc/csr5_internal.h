@@ -82,6 +82,7 @@ struct SpmvOptions {
     int xcd_remap;   // CSR5HIP_OPT_XCD_REMAP
     int x_window;    // resolved: 1 = launch the LDS x-window variant of the fused kernel
     int lds_y;       // resolved: 1 = compact y segments through LDS before storing them
+    int stream_nt;   // resolved: 1 = column/value streams use non-temporal loads
     int long_runs;   // resolved: the matrix has rows spanning > RUN_SERIAL_MAX tiles (fused mode adds k_calibrate)
 };
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,

@@ -335,7 +335,7 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
 // ---- tiles 0..p-2 ------------------------------------------------------------------------------
 // SIGMA > 0: compile-time sigma (loads hoisted into registers, flag walk fully unrolled).
 // SIGMA == 0: run-time sigma (any 1..32), same code shape, used for sigma < 4 and as a cross-check.
-template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
        const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
@@ -425,9 +425,15 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     int32_t c[NREG];
     VT v[NREG];
     if constexpr (SIGMA > 0) {
+        if constexpr (NT) {
 #pragma unroll
-        for (int i = 0; i < SIGMA; i++)
-            c[i] = ct[i * OMEGA];
+            for (int i = 0; i < SIGMA; i++)
+                c[i] = __builtin_nontemporal_load(ct + i * OMEGA);
+        } else {
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++)
+                c[i] = ct[i * OMEGA];
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
     const uint32_t w0 = d[lane];
@@ -442,12 +448,18 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     VT mv[NREG], mx[NREG]; // matrix value and gathered x of element i: multiplied inside the fused multiply-adds below
     VT lead_next = 0;
     if constexpr (SIGMA > 0) {
+        // a non-temporal hint on the streams helps only when the matrix is far larger than the 256-MiB
+        // Infinity Cache (R-MAT 22: +5 %) and costs 18-25 % when it is not (R-MAT 20, nd24k-like), because
+        // repeated SpMVs then re-stream from HBM: chosen per matrix by the host (CSR5HIP_OPT_STREAM_NT),
+        // compiled as its own kernel variant (a run-time branch gets merged and loses the hint)
+        if constexpr (NT) {
 #pragma unroll
-        for (int i = 0; i < SIGMA; i++) {
-            // plain loads on purpose: a non-temporal hint on the streams helps only when the matrix is far
-            // larger than the 256-MiB Infinity Cache (R-MAT 22: +5 %) and costs 18-25 % when it is not
-            // (R-MAT 20, nd24k-like), because repeated SpMVs then re-stream from HBM
-            v[i] = vt[i * OMEGA];
+            for (int i = 0; i < SIGMA; i++)
+                v[i] = __builtin_nontemporal_load(vt + i * OMEGA);
+        } else {
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++)
+                v[i] = vt[i * OMEGA];
         }
         // everything above is in flight before anything below consumes a loaded value
         __builtin_amdgcn_sched_barrier(0);
@@ -766,7 +778,7 @@ k_calibrate(Geometry g, const uint32_t *__restrict__ tile_ptr, const uint4 *__re
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------
-template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false>
 static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
                              const SpmvOptions &opt, hipStream_t s)
 {
@@ -778,7 +790,7 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
     size_t lds = (size_t)g.tile_elems * sizeof(VT); // tail product buffer (tail workgroups)
     if (lds < (size_t)WAVES_PER_BLOCK * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>())
         lds = (size_t)WAVES_PER_BLOCK * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>();
-    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN, LDSY_REQ>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), lds, s,
+    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), lds, s,
                        g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x, d.tile_ptr,
                        d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, tile_blocks,
                        opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt,
@@ -800,10 +812,14 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
     switch (g.sigma) {
 #define CSR5_CASE(S)                                                                               \
     case S:                                                                                        \
-        if constexpr (FUSED)                                                                       \
+        if constexpr (FUSED) {                                                                     \
             if (opt.x_window)                                                                      \
                 return opt.lds_y ? launch_one<VT, S, FUSED, true, true>(g, d, x, y, opt, s)        \
                                  : launch_one<VT, S, FUSED, true, false>(g, d, x, y, opt, s);      \
+            if (opt.stream_nt)                                                                     \
+                return opt.lds_y ? launch_one<VT, S, FUSED, false, true, true>(g, d, x, y, opt, s) \
+                                 : launch_one<VT, S, FUSED, false, false, true>(g, d, x, y, opt, s); \
+        }                                                                                          \
         return opt.lds_y ? launch_one<VT, S, FUSED, false, true>(g, d, x, y, opt, s)               \
                          : launch_one<VT, S, FUSED, false, false>(g, d, x, y, opt, s);
 #if defined(CSR5_ABLATE) || defined(CSR5_FEW_SIGMAS) // experiment builds: few instantiations only

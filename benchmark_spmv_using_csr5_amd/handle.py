@@ -117,6 +117,10 @@ class anonymouslibHandle:
         """0 = off, 1 = auto (default), 2 = force the LDS compaction of a tile's y segments."""
         return self.setOption(_capi.OPT_LDS_Y, value)
 
+    def setStreamNT(self, value: int) -> int:
+        """0 off, 1 auto (non-temporal column/value loads when the streams exceed the Infinity Cache), 2 force"""
+        return self.setOption(_capi.OPT_STREAM_NT, int(value))
+
     def info(self) -> _capi.Csr5Info:
         info = _capi.Csr5Info()
         err = self._lib.csr5hip_get_info(self._h, C.byref(info))

@@ -59,6 +59,10 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       stores: 0 = off, 1 = auto (default: on at <= 32 non-zeros per row),
                                       2 = force (applies while 64*sigma*sizeof(vT) <= 8 KiB) */
 
+#define CSR5HIP_OPT_STREAM_NT   5  /* non-temporal loads for the column/value streams: 0 = off, 1 = auto (default: on
+                                      when those streams exceed the 256-MiB Infinity Cache, so that a matrix that
+                                      cannot stay cached between SpMVs does not evict x either), 2 = force */
+
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
 /* Host-visible snapshot of the handle's private state (anonymouslib_cuda.h:27-52). */

@@ -28,7 +28,7 @@ def _device_csr(mat, val, dtype):
     return rp, ci, va
 
 
-def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None):
+def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None, nt=None):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
@@ -42,6 +42,8 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         assert A.setXWindow(xwin) == 0
     if ldsy is not None:
         assert A.setLdsY(ldsy) == 0
+    if nt is not None:
+        assert A.setStreamNT(nt) == 0
     assert A.spmv(1.0, yd) == H.ANONYMOUSLIB_UNSUPPORTED_CSR_SPMV  # still CSR (anonymouslib_cuda.h:268-271)
     assert A.asCSR5() == 0
     arrays = A.csr5_arrays()
@@ -167,6 +169,18 @@ def test_lds_x_window_variant(oracle, xwin, ldsy):
             scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
             tol = 1e-12 if dtype == np.float64 else 1e-5
             assert np.all(np.abs(ys[0] - exp) <= tol * np.maximum(scale, 1.0)), (mat.name, sigma, xwin)
+
+
+def test_non_temporal_stream_variant_is_bit_identical():
+    """CSR5HIP_OPT_STREAM_NT only changes the cache policy of the column/value loads: forced on and forced off
+    must give the same bits on real data (same arithmetic), fp64 and fp32, with and without LDS y segments."""
+    for mat in zoo.small_zoo():
+        for sigma, dtype in ((4, np.float64), (16, np.float64), (24, np.float64), (12, np.float32)):
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=52, mode="real")
+            for ldsy in (0, 2):
+                _, _, _, plain = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=0, ldsy=ldsy, nt=0)
+                _, _, _, hinted = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=0, ldsy=ldsy, nt=2)
+                assert np.array_equal(plain[0], hinted[0]), (mat.name, sigma, ldsy)
 
 
 @pytest.mark.parametrize("ldsy", [0, 2])
