@@ -17,6 +17,7 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 traffic = {}
 rows = []
+ingest = []
 for d in sorted(glob.glob(os.path.join(src, "profiles_*"))):
     tag = os.path.basename(d)[len("profiles_"):]
     stats = os.path.join(d, "trace", "t_kernel_stats.csv")
@@ -24,6 +25,10 @@ for d in sorted(glob.glob(os.path.join(src, "profiles_*"))):
         continue
     shutil.copy(stats, os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv"))
     line = json.loads(open(os.path.join(d, "bench_line.json")).read())
+    if tag.startswith("ingest_"):
+        top = sorted(csv.DictReader(open(stats)), key=lambda r: -float(r["TotalDurationNs"]))[:6]
+        ingest.append((tag, line, top))
+        continue
     pmc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(d, "pmc_*", "p_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
@@ -56,4 +61,16 @@ with open(os.path.join(dst, f"{rnd}_summary.md"), "w") as f:
         f.write("| %s | %d | %s | %.2f | %.2f | %.2f | %.1f | %s | %s |\n" % (
             r[0], r[1], r[2], r[3] / 1e3, r[4] / 1e3, r[5], r[6] / 1e6,
             "n/a" if r[7] is None else "%.1f" % (r[7] / 1e6), "n/a" if r[8] is None else "%.0f %%" % (100 * r[8])))
+    if ingest:
+        f.write("\n## Matrix Market ingest (`scripts/bench_ingest.py` under `rocprofv3 --kernel-trace --stats`)\n\n"
+                "| run | entries | nnz | parse ms | H2D ms | device COO->CSR ms | M entries/s | reference algorithm on 1 host core, s |\n|---|---|---|---|---|---|---|---|\n")
+        for tag, line, top in ingest:
+            ph, cfg = line["phases_ms"], line["config"]
+            f.write("| %s | %d | %d | %.1f | %.1f | %.2f | %.0f | %s |\n" % (
+                tag, cfg["entries"], cfg["nnz"], ph["parse_ms"], ph["h2d_ms"], ph["build_ms"], line["value"],
+                line.get("cpu_baseline", {}).get("seconds", "n/a")))
+        for tag, line, top in ingest:
+            f.write(f"\nLongest device kernels of `{tag}` (all calls of the run, ns):\n\n| kernel | calls | total | average |\n|---|---|---|---|\n")
+            for r in top:
+                f.write("| `%s` | %s | %s | %.0f |\n" % (r["Name"][:90], r["Calls"], r["TotalDurationNs"], float(r["AverageNs"])))
 print(open(os.path.join(dst, f"{rnd}_summary.md")).read())
