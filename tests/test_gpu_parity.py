@@ -582,3 +582,43 @@ def test_save_load_roundtrip(tmp_path, dtype):
     bad.write_bytes(b"NOTCSR5!" + bytes(100))
     with pytest.raises(RuntimeError):
         anonymouslibHandle.load(str(bad))
+
+
+@pytest.mark.gpu
+def test_handle_lifecycle_does_not_leak_device_memory(tmp_path):
+    """create -> convert -> eager + graph SpMV -> sigma change -> save/load -> destroy -> free, many times:
+    the device's free memory must come back (buffers, graphs, events, checkpoint arrays)."""
+    import torch
+    from benchmark_spmv_using_csr5_amd.handle import anonymouslibHandle
+    dev = torch.device("cuda:0")
+    mat = M.scircuit_like(scale=0.2)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=3, mode="int")
+    rp, ci, va, xd = (torch.from_numpy(a).to(dev) for a in (mat.row_ptr, mat.col, val, x))
+    yd = torch.zeros(mat.m, dtype=torch.float64, device=dev)
+    path = str(tmp_path / "c.csr5")
+
+    def cycle():
+        A = anonymouslibHandle(mat.m, mat.n)
+        assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0
+        for sigma in (5, 16):
+            assert A.setSigma(sigma) == 0 and A.asCSR5() == 0
+            assert A.spmv(1.0, yd) == 0 and A.spmv_repeat(1.0, yd, 20) == 0
+            assert A.asCSR() == 0
+        assert A.asCSR5() == 0 and A.save(path) == 0
+        B = anonymouslibHandle.load(path)
+        assert B.setX(xd) == 0 and B.spmv(1.0, yd) == 0
+        torch.cuda.synchronize()
+        B.close()
+        assert A.destroy() == 0
+        A.close()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 32 << 20, f"{(free0 - free1) >> 20} MiB of device memory did not come back"
+    assert np.array_equal(ci.cpu().numpy(), mat.col)
