@@ -355,9 +355,7 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 
 __global__ void __launch_bounds__(BLOCK) k_tile_window(Geometry g, const int32_t *__restrict__ col,
                                                        uint4 *__restrict__ carry_meta,
-                                                       uint32_t *__restrict__ enabled_counter,
-                                                       uint32_t *__restrict__ covered_counter,
-                                                       int XWIN_ELEMS)
+                                                       uint32_t *__restrict__ covered, int XWIN_ELEMS)
 {
     const int lane = threadIdx.x & (OMEGA - 1);
     const int t = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -370,12 +368,13 @@ __global__ void __launch_bounds__(BLOCK) k_tile_window(Geometry g, const int32_t
         lo = lo < 0 ? 0 : (lo > hi_limit ? hi_limit : lo);
         return lo & ~3;
     };
-    // score every lane's candidate on the 64 samples
+    // score every lane's candidate on the 64 samples (v_readlane broadcasts, no LDS shuffles)
     const int sample = c[0];
     const int my_lo = window_of(sample);
     int score = 0;
+#pragma unroll
     for (int j = 0; j < OMEGA; j++)
-        score += (unsigned)(__shfl(sample, j, OMEGA) - my_lo) < (unsigned)XWIN_ELEMS;
+        score += (unsigned)(__builtin_amdgcn_readlane(sample, j) - my_lo) < (unsigned)XWIN_ELEMS;
     // best candidate: highest score, lowest lane on ties (deterministic)
     int best = score * OMEGA + (OMEGA - 1 - lane);
 #pragma unroll
@@ -383,7 +382,7 @@ __global__ void __launch_bounds__(BLOCK) k_tile_window(Geometry g, const int32_t
         const int o = __shfl_xor(best, d, OMEGA);
         best = o > best ? o : best;
     }
-    const int lo = __shfl(my_lo, OMEGA - 1 - (best % OMEGA), OMEGA);
+    const int lo = __builtin_amdgcn_readlane(my_lo, OMEGA - 1 - (__builtin_amdgcn_readfirstlane(best) % OMEGA));
     int inside = 0;
     for (int i = 0; i < g.sigma; i++)
         inside += (unsigned)(c[i * OMEGA] - lo) < (unsigned)XWIN_ELEMS;
@@ -391,10 +390,27 @@ __global__ void __launch_bounds__(BLOCK) k_tile_window(Geometry g, const int32_t
     if (lane == 0) {
         const bool on = inside * 100 >= g.tile_elems * XWIN_MIN_COVER_PCT;
         reinterpret_cast<unsigned *>(&carry_meta[t])[3] = on ? (unsigned)lo + 1u : 0u;
-        if (on) {
-            atomicAdd(enabled_counter, 1u);
-            atomicAdd(covered_counter, (unsigned)inside);
-        }
+        // per-tile result, summed by k_window_stats: two global atomics per tile on the same two words
+        // serialised the whole kernel (646 us for 28 k tiles)
+        covered[t] = on ? (unsigned)inside : 0u;
+    }
+}
+
+// counters[0] += tiles with a window, counters[1] += non-zeros inside those windows
+__global__ void __launch_bounds__(256) k_window_stats(int tiles, const uint32_t *__restrict__ covered,
+                                                      uint32_t *__restrict__ counters)
+{
+    unsigned on = 0, in = 0;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < tiles; t += gridDim.x * 256) {
+        const unsigned v = covered[t];
+        on += v != 0;
+        in += v;
+    }
+    on = (unsigned)wave_sum_i32((int)on);
+    in = (unsigned)wave_sum_i32((int)in);
+    if ((threadIdx.x & (OMEGA - 1)) == 0 && (on | in)) {
+        atomicAdd(counters + 0, on);
+        atomicAdd(counters + 1, in);
     }
 }
 
@@ -503,9 +519,15 @@ hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int valu
 {
     if (g.p <= 1)
         return hipSuccess;
+    // the per-tile coverage words live in tile_hdr until k_tile_hdr (launched afterwards) overwrites them
     hipLaunchKernelGGL(k_tile_window, dim3(div_up(g.p - 1, WAVES_PER_BLOCK)), dim3(BLOCK), 0, s, g,
-                       d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.counters + 0, d.counters + 1,
-                       xwin_elems(value_size));
+                       d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.tile_hdr, xwin_elems(value_size));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    int blocks = div_up(g.p - 1, 256 * 8);
+    blocks = blocks > 64 ? 64 : blocks;
+    hipLaunchKernelGGL(k_window_stats, dim3(blocks), dim3(256), 0, s, g.p - 1, d.tile_hdr, d.counters);
     return hipGetLastError();
 }
 
