@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(BLOCK) k_tile_ptr(Geometry g, const int32_t *_
 //  * an EMPTY row with e > 0 lies in the row range [tile_ptr[t], tile_ptr[t+1]) of exactly one
 //    tile, t = (e-1)/T  (tile_ptr[t] is the last row with pointer <= t*T, so r > tile_ptr[t] iff
 //    e > t*T, and r < tile_ptr[t+1] iff e <= (t+1)*T); leading empty rows (e == 0) precede every
-//    tile.  That replaces the reference's per-tile row loop by one atomicOr.
+//    tile.  That replaces the reference's per-tile row loop by one store per run of empty rows.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(BLOCK) k_row_scan(Geometry g, const int32_t *__restrict__ row_ptr,
                                                     uint32_t *__restrict__ tile_ptr,
@@ -74,8 +74,13 @@ __global__ void __launch_bounds__(BLOCK) k_row_scan(Geometry g, const int32_t *_
         const size_t loc = (size_t)tile * OMEGA * g.num_packet + (size_t)(gbit >> 5) * OMEGA + lane;
         atomicOr(&tile_desc[loc], 1u << (31 - (gbit & 31)));
     }
-    if (e == e1 && e > 0)
-        atomicOr(&tile_ptr[(e - 1) / T], 0x80000000u);
+    // Empty rows come in runs with the same pointer (R-MAT: half of all rows), i.e. the same target tile:
+    // only the first lane of a run marks it.  Every writer stores the same word (the row index that
+    // k_tile_ptr left there, plus bit 31), so a plain load/store replaces the contended atomicOr.
+    const int target = (e == e1 && e > 0) ? (e - 1) / T : -1;
+    const int before = __shfl_up(target, 1, OMEGA);
+    if (target >= 0 && ((threadIdx.x & (OMEGA - 1)) == 0 || before != target))
+        tile_ptr[target] = tile_ptr[target] | 0x80000000u;
 }
 
 // ---------------------------------------------------------------------------------------------
