@@ -108,6 +108,7 @@ struct csr5hip_handle_s {
     Buffer b_tile_ptr, b_tile_desc, b_offset_ptr, b_offset, b_calibrator, b_acc, b_cnt, b_meta, b_counters, b_hdr;
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t phase[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // asCSR5 phase boundaries
     std::unordered_map<GraphKey, hipGraphExec_t, GraphKeyHash> graphs;
 
     size_t vsize() const { return value_type == CSR5HIP_F64 ? 8 : 4; }
@@ -186,6 +187,8 @@ int csr5hip_free(csr5hip_handle h)
         b->release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (hipEvent_t e : h->phase)
+        if (e) (void)hipEventDestroy(e);
     delete h;
     return CSR5HIP_SUCCESS;
 }
@@ -350,8 +353,7 @@ static int reserve_aux(csr5hip_handle h)
     HIP_TRY(hipMemsetAsync(h->d.carry_acc, 0, p1 * h->vsize(), s));
     HIP_TRY(hipMemsetAsync(h->d.carry_cnt, 0, p1 * 4, s));
     HIP_TRY(hipMemsetAsync(h->d.counters, 0, 16, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    return CSR5HIP_SUCCESS;
+    return CSR5HIP_SUCCESS; // stream-ordered: the conversion kernels follow on the same stream
 }
 
 // what the fused kernel needs on top of the reference's format arrays: carry meta, x windows, tile headers
@@ -388,6 +390,13 @@ int csr5hip_as_csr5(csr5hip_handle h)
     Geometry &g = h->g;
     hipStream_t s = h->stream;
 
+    // Two host round trips in all (the reference synchronises after every phase, anonymouslib_cuda.h:161-208):
+    // one for the two words the host needs -- tail start and number of offsets, as in the reference
+    // (anonymouslib_cuda.h:165-167, format_cuda.h:331-343) -- and one at the end.  The four phase times the
+    // reference prints are taken from events on the stream instead of host timers around synchronisations.
+    for (hipEvent_t &e : h->phase)
+        if (!e)
+            HIP_TRY(hipEventCreate(&e));
     double t0 = now_ms();
     rc = reserve_aux(h);
     if (rc != CSR5HIP_SUCCESS)
@@ -396,15 +405,12 @@ int csr5hip_as_csr5(csr5hip_handle h)
 
     if (g.p > 0) {
         // step 1: tile_ptr (+ empty-row marks) -- flag scatter shares the row pass
-        t0 = now_ms();
+        HIP_TRY(hipEventRecord(h->phase[0], s));
         HIP_TRY(launch_tile_ptr(g, h->d, s));
         HIP_TRY(launch_row_scan(g, h->d, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        h->t_tile_ptr += now_ms() - t0;
+        HIP_TRY(hipEventRecord(h->phase[1], s));
 
-        // step 2: tile_desc, offset_ptr scan; two 4-byte reads as in the reference
-        // (anonymouslib_cuda.h:165-167, format_cuda.h:331-343), issued together
-        t0 = now_ms();
+        // step 2: tile_desc, offset_ptr scan, then the two 4-byte reads
         HIP_TRY(launch_tile_desc(g, h->d, s));
         HIP_TRY(launch_offset_scan(g, h->d, s));
         uint32_t tail_word = 0;
@@ -414,26 +420,31 @@ int csr5hip_as_csr5(csr5hip_handle h)
         HIP_TRY(hipStreamSynchronize(s));
         g.tail_start = (int)(tail_word & ROW_MASK);
         h->num_offsets = num_offsets;
-        h->t_tile_desc += now_ms() - t0;
 
         if (num_offsets > 0) {
             t0 = now_ms();
             HIP_TRY(h->b_offset.reserve((size_t)num_offsets * 4));
             h->d.offset = (int32_t *)h->b_offset.ptr;
             h->t_malloc += now_ms() - t0;
-            t0 = now_ms();
             HIP_TRY(launch_desc_offset(g, h->d, s));
-            HIP_TRY(hipStreamSynchronize(s));
-            h->t_tile_desc += now_ms() - t0;
         }
+        HIP_TRY(hipEventRecord(h->phase[2], s));
 
-        // step 3: in-place tile transpose of column_index and value
-        t0 = now_ms();
+        // step 3: in-place tile transpose of column_index and value, then the kernel-side tables
         HIP_TRY(launch_transpose(g, h->d, h->value_type, true, s));
-        rc = derive_kernel_tables(h);
+        HIP_TRY(hipEventRecord(h->phase[3], s));
+        rc = derive_kernel_tables(h); // ends with the second (last) synchronisation
         if (rc != CSR5HIP_SUCCESS)
             return rc;
-        h->t_transpose += now_ms() - t0;
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, h->phase[0], h->phase[1]));
+        h->t_tile_ptr += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, h->phase[1], h->phase[2]));
+        h->t_tile_desc += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, h->phase[2], h->phase[3]));
+        h->t_transpose += ms;
+    } else {
+        HIP_TRY(hipStreamSynchronize(s));
     }
     h->opt.x_window = xwin_decision(h);
     h->opt.lds_y = ldsy_decision(h);
