@@ -1,0 +1,9 @@
+#!/bin/bash
+# one-off long fuzz campaign against the oracle (several seeds x N cases, small and 30x larger shapes);
+# the CI run uses 60 small cases
+for seed in 11 12 13 14; do
+  CSR5_FUZZ_SEED=$seed CSR5_FUZZ_CASES=${1:-600} timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k seeded_fuzz 2>&1 | tail -2
+done
+for seed in 21 22 23; do
+  CSR5_FUZZ_SCALE=30 CSR5_FUZZ_SEED=$seed CSR5_FUZZ_CASES=${2:-150} timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k seeded_fuzz 2>&1 | tail -2
+done

@@ -405,10 +405,13 @@ def test_autotune_sigma(oracle):
 def test_seeded_fuzz_against_oracle(oracle):
     """Seeded fuzz: random shapes, row-length laws (incl. bursts of empty rows and hub rows), sigma, SpMV
     mode, LDS options and dtype; integer data, so format and y must be bit-identical to the oracle."""
-    rng = np.random.default_rng(20260928)
-    for case in range(60):
-        m = int(rng.integers(1, 4000))
-        n = int(rng.integers(1, 6000))
+    # CSR5_FUZZ_CASES / CSR5_FUZZ_SEED: longer one-off campaigns (scripts/gpu_fuzz_long.sh); defaults = the CI run
+    import os
+    rng = np.random.default_rng(int(os.environ.get("CSR5_FUZZ_SEED", "20260928")))
+    scale = int(os.environ.get("CSR5_FUZZ_SCALE", "1"))
+    for case in range(int(os.environ.get("CSR5_FUZZ_CASES", "60"))):
+        m = int(rng.integers(1, 4000 * scale))
+        n = int(rng.integers(1, 6000 * scale))
         law = case % 5
         if law == 0:
             lens = rng.integers(0, 12, size=m)
@@ -416,12 +419,12 @@ def test_seeded_fuzz_against_oracle(oracle):
             lens = np.floor(rng.pareto(1.3, size=m) * 2).astype(np.int64)
         elif law == 2:
             lens = rng.integers(0, 3, size=m) * (rng.random(m) < 0.3)
-            lens[rng.integers(0, m)] = int(rng.integers(500, 20000))
+            lens[rng.integers(0, m)] = int(rng.integers(500, 20000 * scale))
         elif law == 3:
             lens = np.where(rng.random(m) < 0.5, 0, rng.integers(1, 200, size=m))
         else:
             lens = np.full(m, int(rng.integers(1, 130)))
-        lens = np.minimum(lens, 30000)
+        lens = np.minimum(lens, 30000 * scale)
         if lens.sum() == 0:
             lens[0] = 1
         band = float(rng.choice([0.0, 0.5, 1.0]))
@@ -435,12 +438,13 @@ def test_seeded_fuzz_against_oracle(oracle):
         mode = int(rng.integers(0, 2))
         xwin = int(rng.choice([0, 2])) if mode == H.SPMV_FUSED else None
         ldsy = int(rng.choice([0, 2]))
+        nt = int(rng.choice([0, 2])) if mode == H.SPMV_FUSED and not xwin else None
         fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
-        arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, dtype=dtype, xwin=xwin, ldsy=ldsy, repeat=2)
+        arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, dtype=dtype, xwin=xwin, ldsy=ldsy, nt=nt, repeat=2)
         _check_format(arrays, col_t, val_t, fmt)
         exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
         for y in ys:
-            assert np.array_equal(y, exp), (case, m, n, sigma, mode, xwin, ldsy, dtype,
+            assert np.array_equal(y, exp), (case, m, n, sigma, mode, xwin, ldsy, nt, dtype,
                                             np.flatnonzero(y != exp)[:5])
 
 
