@@ -303,15 +303,19 @@ def test_gpu_cli_on_every_fixture():
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                        "benchmark_spmv_using_csr5_amd", "csrc", "spmv")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
+    exe32 = exe + "_f32"   # the reference builds one binary per precision (make VALUE_TYPE=float)
+    assert os.path.exists(exe32), "run __graft_entry__.build() first"
     for name in GOOD:
         m, n, row_ptr, col, val = expected_csr(name)
         if col.size == 0:
             continue  # the reference CLI divides by zero tiles on an empty matrix; nothing to compare
-        out = subprocess.run([exe, path_of(name)], capture_output=True, text=True, timeout=300,
-                             env=dict(os.environ, CSR5_SEED="3"))
-        assert out.returncode == 0, (name, out.stderr)
-        assert f" ( {m}, {n} ) nnz = {col.size}\n" in out.stdout, (name, out.stdout)
-        assert "Check... PASS!" in out.stdout, (name, out.stdout)
+        for binary, banner in ((exe, "64-bit Double Precision"), (exe32, "32-bit Single Precision")):
+            out = subprocess.run([binary, path_of(name)], capture_output=True, text=True, timeout=300,
+                                 env=dict(os.environ, CSR5_SEED="3"))
+            assert out.returncode == 0, (name, out.stderr)
+            assert f"PRECISION = {banner}" in out.stdout
+            assert f" ( {m}, {n} ) nnz = {col.size}\n" in out.stdout, (name, out.stdout)
+            assert "Check... PASS!" in out.stdout, (name, out.stdout)
     for name in BAD:
         rc = subprocess.run([exe, path_of(name)], capture_output=True, timeout=60).returncode
         assert rc == 256 + int(EXPECTED[name + ".code"]), name
