@@ -310,6 +310,15 @@ class Reference:
         L.ref_ingest_fetch(row_ptr, col, val)
         return m, n, row_ptr, col[:nnz], val[:nnz]
 
+    def cli(self, path: str) -> tuple:
+        """Run the reference's whole CLI (CSR5_avx2/main.cpp) on `path` -> (exit code, stdout text)."""
+        L = C.CDLL(os.path.join(_HERE, "_ref", "libref_ingest.so"))
+        L.ref_cli_run.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.ref_cli_run.restype = C.c_int
+        buf = C.create_string_buffer(1 << 16)
+        rc = L.ref_cli_run(os.fsencode(path), buf, len(buf))
+        return rc, buf.value.decode(errors="replace")
+
     def _avx2_lib(self):
         if self._avx2 is None:
             L = C.CDLL(os.path.join(_HERE, "_ref", "libref_avx2.so"))

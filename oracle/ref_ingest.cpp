@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <sstream>
 #include <vector>
 
 #include "anonymouslib_avx2.h"
@@ -30,9 +31,14 @@ struct Captured {
 };
 Captured g_cap;
 struct CaptureDone {};
+bool g_stop_after_ingest = true;
 
 void ref_capture(int m, int n, int nnz, const int *rp, const int *ci, const double *v)
 {
+    if (!g_stop_after_ingest) { // full CLI run (ref_cli_run): behave like the statement we replaced, fixed seed
+        srand(20240928u);
+        return;
+    }
     g_cap.m = m;
     g_cap.n = n;
     g_cap.nnz = nnz;
@@ -73,6 +79,31 @@ extern "C" int ref_ingest_run(const char *path, int *dims)
     dims[1] = g_cap.n;
     dims[2] = g_cap.nnz;
     return 0;
+}
+
+// Runs the WHOLE reference CLI (ingest, CSR5_avx2 conversion, SpMV loop, self-check) on `path` with a fixed
+// rand() seed and returns its stdout in `out` (truncated to cap-1 characters).  BASELINE.json configs[0].
+extern "C" int ref_cli_run(const char *path, char *out, int cap)
+{
+    char prog[] = "spmv";
+    std::vector<char> p(path, path + strlen(path) + 1);
+    char *argv[] = {prog, p.data(), 0};
+    std::ostringstream text;
+    std::streambuf *old = std::cout.rdbuf(text.rdbuf());
+    g_stop_after_ingest = false;
+    int rc = 0;
+    try {
+        rc = ref_cli_main(2, argv);
+    } catch (...) {
+        rc = -100;
+    }
+    g_stop_after_ingest = true;
+    std::cout.rdbuf(old);
+    const std::string t = text.str();
+    const size_t k = t.size() < (size_t)cap - 1 ? t.size() : (size_t)cap - 1;
+    memcpy(out, t.data(), k);
+    out[k] = 0;
+    return rc;
 }
 
 extern "C" void ref_ingest_fetch(int *row_ptr, int *col_idx, double *val)

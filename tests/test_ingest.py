@@ -83,6 +83,19 @@ def test_oracle_ingest_matches_live_reference(oracle, name):
     assert_same_values(got.val, val)
 
 
+@pytest.mark.skipif(not Reference.ingest_available(), reason="oracle/_ref not built (no /root/reference)")
+@pytest.mark.parametrize("name", [f for f in GOOD if f not in ("empty_matrix",)])
+def test_reference_cli_runs_on_the_fixtures(name):
+    """BASELINE.json configs[0] (plumbing + correctness baseline on the host CPU, no GPU): the reference's own CLI
+    -- ingest, CSR5_avx2 conversion, SpMV loop, self-check -- compiled from its sources where they lie, accepts
+    every fixture, reports the dimensions the goldens hold and passes its own check."""
+    m, n, row_ptr, col, val = expected_csr(name)
+    rc, text = Reference().cli(path_of(name))
+    assert rc == 0, text
+    assert f" ( {m}, {n} ) nnz = {col.size}\n" in text
+    assert "omega = 4, sigma = 16." in text and "Check... PASS!" in text
+
+
 # ---------------------------------------------------------------------------------------------
 # the library's host parser (no GPU needed)
 # ---------------------------------------------------------------------------------------------
