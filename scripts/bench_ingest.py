@@ -83,15 +83,22 @@ def main():
         "file_generation_s": round(gen_s, 1),
     }
     if not args.no_cpu_baseline:
-        from oracle.csr5_oracle import Oracle
-        o = Oracle()
-        t0 = time.time()
-        seq = o.mtx_read(path)
-        cpu_s = time.time() - t0
-        same = (np.array_equal(seq.row_ptr, host.row_ptr) and np.array_equal(seq.col, host.col)
-                and np.array_equal(seq.val.view(np.uint64), host.val.view(np.uint64)))
+        from oracle.csr5_oracle import Oracle, Reference
+        if Reference.ingest_available():   # the reference CLI's own ingest (oracle/_ref, built from its sources)
+            t0 = time.time()
+            _, _, r_rp, r_col, r_val = Reference().ingest(path)
+            cpu_s = time.time() - t0
+            kind = "reference"
+        else:                               # our C restatement of it
+            t0 = time.time()
+            seq = Oracle().mtx_read(path)
+            cpu_s = time.time() - t0
+            r_rp, r_col, r_val = seq.row_ptr, seq.col, seq.val
+            kind = "port"
+        same = (np.array_equal(r_rp, host.row_ptr) and np.array_equal(r_col, host.col)
+                and np.array_equal(r_val.view(np.uint64), host.val.view(np.uint64)))
         out["cpu_baseline"] = {"value": round(args.entries / cpu_s * 1e-6, 3), "unit": "M entries/s", "cores": 1,
-                               "kind": "port", "seconds": round(cpu_s, 2),
+                               "kind": kind, "seconds": round(cpu_s, 2),
                                "sample": "same file, fscanf per entry + serial counting scatter (main.cpp:181-275)",
                                "csr_identical": bool(same)}
         out["speedup_vs_cpu"] = round(cpu_s * 1e3 / total_ms, 1)
