@@ -405,7 +405,7 @@ def test_autotune_sigma(oracle):
 def test_seeded_fuzz_against_oracle(oracle):
     """Seeded fuzz: random shapes, row-length laws (incl. bursts of empty rows and hub rows), sigma, SpMV
     mode, LDS options and dtype; integer data, so format and y must be bit-identical to the oracle."""
-    # CSR5_FUZZ_CASES / CSR5_FUZZ_SEED: longer one-off campaigns (scripts/gpu_fuzz_long.sh); defaults = the CI run
+    # CSR5_FUZZ_CASES / CSR5_FUZZ_SEED: longer one-off campaigns (scripts/experiments/fuzz_long.sh); defaults = the CI run
     import os
     rng = np.random.default_rng(int(os.environ.get("CSR5_FUZZ_SEED", "20260928")))
     scale = int(os.environ.get("CSR5_FUZZ_SCALE", "1"))
