@@ -15,7 +15,7 @@ for grp in ${PMC_GROUPS:+"$PMC_GROUPS"} "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES 
            "FETCH_SIZE" "WRITE_SIZE" \
            "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" ; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_${tag}_$i -o p -- python $REPO/bench.py --no-cpu-baseline --steps 20 --warmup 5 "$@" > $OUT/pmc_${tag}_$i.log 2>&1
+  timeout 240 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_${tag}_$i -o p -- python $REPO/bench.py --no-cpu-baseline --steps 20 --warmup 5 "$@" > $OUT/pmc_${tag}_$i.log 2>&1
   f=$(find $OUT/pmc_${tag}_$i -name "*counter_collection.csv" | head -1)
   echo "== pass $i: $grp -> $f"
   [ -n "$f" ] && python3 - "$f" <<'PY'
