@@ -25,6 +25,8 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cctype>
 #include <chrono>
 #include <climits>
@@ -339,18 +341,12 @@ int scan_sequential(const char *base, size_t size, const Head &h, int32_t *row, 
     return rc;
 }
 
+// Plain pageable memory: measured on the MI355X box for 160 MB of triplets, pinning costs 7 ms and saves 3.3 ms
+// of the H2D copy (3.4 ms pinned, 6.6 ms pageable), so it does not pay for arrays that are copied once.
 void *host_alloc(size_t bytes, int *pinned)
 {
-    void *p = nullptr;
-    if (bytes == 0)
-        bytes = 8;
-    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) {
-        *pinned = 1;
-        return p;
-    }
-    (void)hipGetLastError();
     *pinned = 0;
-    return malloc(bytes);
+    return malloc(bytes ? bytes : 8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -463,7 +459,7 @@ extern "C" int csr5hip_mtx_read(const char *path, int threads, csr5hip_mtx *out)
     const char *base = (const char *)"";
     void *map = nullptr;
     if (size) {
-        map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0); // no MAP_POPULATE: the 64 counting threads fault the pages in 5x faster than one serial populate
         if (map == MAP_FAILED) {
             close(fd);
             return fail(CSR5HIP_MTX_CANNOT_OPEN, std::string("mmap failed: ") + path);
@@ -526,30 +522,51 @@ extern "C" int csr5hip_mtx_read(const char *path, int threads, csr5hip_mtx *out)
         chunks[(size_t)t] = Chunk{at, end, 0, 0};
         at = end;
     }
+    // ONE set of threads for both passes: a thread parses the chunk whose lines it has just counted, so the
+    // second pass finds its 4-MB share of the file in that core's caches.
+    std::atomic<long long> bad_index(-1);
+    std::vector<char> ok((size_t)T, 1);
+    bool fast = false;
+    long long total = 0;
+    double t_count = 0;
+    struct Gate {
+        std::mutex m;
+        std::condition_variable cv;
+        int expected, waiting = 0, generation = 0;
+        void wait()
+        {
+            std::unique_lock<std::mutex> l(m);
+            const int g = generation;
+            if (++waiting == expected) {
+                waiting = 0;
+                generation++;
+                cv.notify_all();
+            } else {
+                cv.wait(l, [&] { return generation != g; });
+            }
+        }
+    } gate;
+    gate.expected = T;
+    auto work = [&](int t) {
+        chunks[(size_t)t].lines = count_lines(base, chunks[(size_t)t].begin, chunks[(size_t)t].end);
+        gate.wait();
+        if (t == 0) {
+            for (auto &c : chunks) { c.first = total; total += c.lines; }
+            fast = total >= h.nz;
+            t_count = now_ms();
+        }
+        gate.wait();
+        if (fast)
+            ok[(size_t)t] = parse_chunk(base, chunks[(size_t)t], h, h.nz, row, col, val, bad_index);
+    };
     {
         std::vector<std::thread> pool;
         for (int t = 1; t < T; ++t)
-            pool.emplace_back([&, t]() { chunks[(size_t)t].lines = count_lines(base, chunks[(size_t)t].begin, chunks[(size_t)t].end); });
-        chunks[0].lines = count_lines(base, chunks[0].begin, chunks[0].end);
+            pool.emplace_back(work, t);
+        work(0);
         for (auto &th : pool) th.join();
     }
-    long long total = 0;
-    for (auto &c : chunks) { c.first = total; total += c.lines; }
-    const double t_count = now_ms();
-
-    std::atomic<long long> bad_index(-1);
-    bool fast = total >= h.nz;
-    if (fast) {
-        std::vector<char> ok((size_t)T, 1);
-        std::vector<std::thread> pool;
-        for (int t = 1; t < T; ++t)
-            pool.emplace_back([&, t]() {
-                ok[(size_t)t] = parse_chunk(base, chunks[(size_t)t], h, h.nz, row, col, val, bad_index);
-            });
-        ok[0] = parse_chunk(base, chunks[0], h, h.nz, row, col, val, bad_index);
-        for (auto &th : pool) th.join();
-        for (char k : ok) fast = fast && k;
-    }
+    for (char k : ok) fast = fast && k;
     long long bad = bad_index.load();
     if (!fast) {
         bad = -1;
