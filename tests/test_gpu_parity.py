@@ -626,3 +626,13 @@ def test_handle_lifecycle_does_not_leak_device_memory(tmp_path):
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 32 << 20, f"{(free0 - free1) >> 20} MiB of device memory did not come back"
     assert np.array_equal(ci.cpu().numpy(), mat.col)
+
+
+@pytest.mark.gpu
+def test_plain_c_host_program(tmp_path):
+    """tests/c/abi_smoke.c: a C99 program on the C ABI alone (what a foreign-language binding would do)."""
+    import subprocess
+    from tests.test_host import _build_c_host
+    out = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    assert "mismatches=0" in out.stdout

@@ -274,3 +274,18 @@ def test_coupled_power_iteration_gloo(world):
     assert all(r[1] for r in res), "A x differs after one coupled step"
     assert max(r[2] for r in res) < 1e-12 and max(r[3] for r in res) < 1e-12
     assert sum(r[4] for r in res) == _coupled_problem()[0].nnz
+
+
+def _build_c_host(out_dir) -> str:
+    """gcc -std=c99 on tests/c/abi_smoke.c against include/csr5hip.h + libcsr5hip.so: the ABI really is plain C."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(str(out_dir), "abi_smoke")
+    lib_dir = os.path.join(root, "benchmark_spmv_using_csr5_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", lib_dir, "-lcsr5hip",
+                           "-Wl,-rpath," + lib_dir, "-lm"])
+    return exe
+
+
+def test_plain_c_host_compiles_and_links(tmp_path):
+    assert os.path.exists(_build_c_host(tmp_path))
