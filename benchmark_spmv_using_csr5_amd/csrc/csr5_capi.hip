@@ -800,7 +800,9 @@ int csr5hip_device_name(int device, char *buf, size_t buflen, double *clock_mhz)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (buf && buflen) {
-        strncpy(buf, prop.name, buflen - 1);
+        // the marketing name comes from libdrm's amdgpu.ids and is empty where that file is missing:
+        // fall back to the architecture string (gfx950:...)
+        strncpy(buf, prop.name[0] ? prop.name : prop.gcnArchName, buflen - 1);
         buf[buflen - 1] = 0;
     }
     if (clock_mhz)
