@@ -234,14 +234,15 @@ int csr5hip_set_x(csr5hip_handle h, const void *d_x)
 
 // gfx950 table in the shape of the reference's (r, s, t, u) rule (anonymouslib_cuda.h:297-313):
 // k = nnz/m; sigma = r if k <= r; k if k <= s; s if k <= t; else u.
-// (r, s, t, u) = (6, 16, 256, 32), from a sweep of all sigma over mean row lengths 2..512, random and near-diagonal
-// columns, fp64 and fp32 (scripts/experiments/sigma_table.py, profiles/r01_sigma_table.txt): the rule is within 0-6 %
-// of the measured best everywhere; r = 6 instead of the reference's 4 costs random-column matrices 0.5 % and gains
-// 6-9 % where the columns are local; u = 32 gains 5-15 % beyond 256 non-zeros per row.
+// (r, s, t, u) = (6, 16, 256, 16), from a sweep of all sigma over mean row lengths 2..512, random and near-diagonal
+// columns, fp64 and fp32 (scripts/experiments/sigma_table.py, profiles/r01_sigma_table.txt): the sigma surface is
+// flat on gfx950 and the rule stays within 0-7 % of the measured best everywhere; r = 6 instead of the reference's 4
+// costs random-column matrices < 1 % and gains 4-8 % where the columns are local.  Beyond 256 non-zeros per row
+// sigma = 32 would gain 3-7 % on random columns but loses 10 % on the nd24k-like stand-in (x-window + jitter): u = 16.
 int csr5hip_auto_sigma(int m, int nnz, int value_type)
 {
     (void)value_type;
-    const int r = 6, s = 16, t = 256, u = 32;
+    const int r = 6, s = 16, t = 256, u = 16;
     const int k = m > 0 ? nnz / m : 0;
     if (k <= r) return r;
     if (k <= s) return k;

@@ -37,10 +37,10 @@ __device__ __forceinline__ int upper_bound(const int32_t *__restrict__ a, int ke
 // ---------------------------------------------------------------------------------------------
 // K1: tile_ptr[t] = (last row r in [0, m] with row_ptr[r] <= min(t*T, nnz)),  t in [0, p]
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_tile_ptr(Geometry g, const int32_t *__restrict__ row_ptr,
+__global__ void __launch_bounds__(FMT_BLOCK) k_tile_ptr(Geometry g, const int32_t *__restrict__ row_ptr,
                                                     uint32_t *__restrict__ tile_ptr)
 {
-    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    const int t = blockIdx.x * FMT_BLOCK + threadIdx.x;
     if (t > g.p)
         return;
     long long b = (long long)t * g.tile_elems;
@@ -57,11 +57,11 @@ __global__ void __launch_bounds__(BLOCK) k_tile_ptr(Geometry g, const int32_t *_
 //    e > t*T, and r < tile_ptr[t+1] iff e <= (t+1)*T); leading empty rows (e == 0) precede every
 //    tile.  That replaces the reference's per-tile row loop by one store per run of empty rows.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_row_scan(Geometry g, const int32_t *__restrict__ row_ptr,
+__global__ void __launch_bounds__(FMT_BLOCK) k_row_scan(Geometry g, const int32_t *__restrict__ row_ptr,
                                                     uint32_t *__restrict__ tile_ptr,
                                                     uint32_t *__restrict__ tile_desc)
 {
-    const int r = blockIdx.x * BLOCK + threadIdx.x;
+    const int r = blockIdx.x * FMT_BLOCK + threadIdx.x;
     if (r >= g.m)
         return;
     const int e = row_ptr[r];
@@ -89,12 +89,12 @@ __global__ void __launch_bounds__(BLOCK) k_row_scan(Geometry g, const int32_t *_
 //   y_off = exclusive wave prefix of segn, minus one for lanes > 0 (index into y_local)
 //   ss    = number of directly following lanes without any flag (scansum_offset)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_tile_desc(Geometry g, const uint32_t *__restrict__ tile_ptr,
+__global__ void __launch_bounds__(FMT_BLOCK) k_tile_desc(Geometry g, const uint32_t *__restrict__ tile_ptr,
                                                      uint32_t *__restrict__ tile_desc,
                                                      int32_t *__restrict__ offset_ptr)
 {
     const int lane = threadIdx.x & (OMEGA - 1);
-    const int t = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int t = blockIdx.x * FMT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (t >= g.p - 1)
         return;
     const uint32_t raw = tile_ptr[t];
@@ -181,14 +181,14 @@ __global__ void __launch_bounds__(1024) k_offset_scan(int32_t *__restrict__ a, i
 // K7: tiles whose tile_ptr carries bit 31: the k-th store slot of the tile gets the row index
 // (relative to row_start+1) of the segment that starts there.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_desc_offset(Geometry g, const int32_t *__restrict__ row_ptr,
+__global__ void __launch_bounds__(FMT_BLOCK) k_desc_offset(Geometry g, const int32_t *__restrict__ row_ptr,
                                                        const uint32_t *__restrict__ tile_ptr,
                                                        const uint32_t *__restrict__ tile_desc,
                                                        const int32_t *__restrict__ offset_ptr,
                                                        int32_t *__restrict__ offset)
 {
     const int lane = threadIdx.x & (OMEGA - 1);
-    const int t = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int t = blockIdx.x * FMT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (t >= g.p - 1)
         return;
     const uint32_t raw = tile_ptr[t];
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(BLOCK) k_desc_offset(Geometry g, const int32_t
 // LDS rows are padded by one element so both passes are bank-conflict free.
 // ---------------------------------------------------------------------------------------------
 template <typename VT>
-__global__ void __launch_bounds__(BLOCK) k_transpose(Geometry g, const uint32_t *__restrict__ tile_ptr,
+__global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint32_t *__restrict__ tile_ptr,
                                                      int32_t *__restrict__ col, VT *__restrict__ val,
                                                      int r2c)
 {
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(BLOCK) k_transpose(Geometry g, const uint32_t 
     VT *sv = reinterpret_cast<VT *>(smem);
     int32_t *sc = reinterpret_cast<int32_t *>(smem + (size_t)sigma * (OMEGA + 1) * sizeof(VT));
     const size_t base = (size_t)t * T;
-    for (int idx = threadIdx.x; idx < T; idx += BLOCK) {
+    for (int idx = threadIdx.x; idx < T; idx += FMT_BLOCK) {
         int i, l;
         if (r2c) { i = idx % sigma; l = idx / sigma; }
         else     { l = idx & (OMEGA - 1); i = idx >> 6; }
@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(BLOCK) k_transpose(Geometry g, const uint32_t 
         sv[i * (OMEGA + 1) + l] = val[base + idx];
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < T; idx += BLOCK) {
+    for (int idx = threadIdx.x; idx < T; idx += FMT_BLOCK) {
         int i, l;
         if (r2c) { l = idx & (OMEGA - 1); i = idx >> 6; }
         else     { i = idx % sigma; l = idx / sigma; }
@@ -269,12 +269,12 @@ __global__ void __launch_bounds__(BLOCK) k_transpose(Geometry g, const uint32_t 
 // for short rows), tile h-1 owns y[r] outright and nothing is communicated.  Otherwise every partial
 // of r arrives at slot h and the last arriver stores y[r] (csr5_spmv.hip carry_arrive).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_carry_meta(Geometry g, const int32_t *__restrict__ row_ptr,
+__global__ void __launch_bounds__(FMT_BLOCK) k_carry_meta(Geometry g, const int32_t *__restrict__ row_ptr,
                                                       const uint32_t *__restrict__ tile_ptr,
                                                       uint4 *__restrict__ carry_meta,
                                                       uint32_t *__restrict__ long_run_counter)
 {
-    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    const int t = blockIdx.x * FMT_BLOCK + threadIdx.x;
     if (t >= g.p)
         return;
     const long long T = g.tile_elems;
@@ -358,12 +358,12 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return v;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_tile_window(Geometry g, const int32_t *__restrict__ col,
+__global__ void __launch_bounds__(FMT_BLOCK) k_tile_window(Geometry g, const int32_t *__restrict__ col,
                                                        uint4 *__restrict__ carry_meta,
                                                        uint32_t *__restrict__ covered, int XWIN_ELEMS)
 {
     const int lane = threadIdx.x & (OMEGA - 1);
-    const int t = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    const int t = blockIdx.x * FMT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (t >= g.p - 1)
         return;
     const int32_t *c = col + (size_t)t * g.tile_elems + lane;
@@ -424,11 +424,11 @@ __global__ void __launch_bounds__(256) k_window_stats(int tiles, const uint32_t 
 // (one vector load instead of three): words 0..3 = carry_meta[t], 4 = carry_meta[t+1].x,
 // 5..6 = tile_ptr[t], tile_ptr[t+1] (copies; the format arrays themselves stay untouched).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BLOCK) k_tile_hdr(Geometry g, const uint32_t *__restrict__ tile_ptr,
+__global__ void __launch_bounds__(FMT_BLOCK) k_tile_hdr(Geometry g, const uint32_t *__restrict__ tile_ptr,
                                                     const uint4 *__restrict__ carry_meta,
                                                     uint32_t *__restrict__ hdr)
 {
-    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    const int t = blockIdx.x * FMT_BLOCK + threadIdx.x;
     if (t >= g.p)
         return;
     const uint4 m = carry_meta[t];
@@ -457,7 +457,7 @@ static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
 
 hipError_t launch_tile_ptr(const Geometry &g, const DeviceArrays &d, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tile_ptr, dim3(div_up(g.p + 1, BLOCK)), dim3(BLOCK), 0, s, g, d.row_ptr,
+    hipLaunchKernelGGL(k_tile_ptr, dim3(div_up(g.p + 1, FMT_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
                        d.tile_ptr);
     return hipGetLastError();
 }
@@ -466,7 +466,7 @@ hipError_t launch_row_scan(const Geometry &g, const DeviceArrays &d, hipStream_t
 {
     if (g.m <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_row_scan, dim3(div_up(g.m, BLOCK)), dim3(BLOCK), 0, s, g, d.row_ptr,
+    hipLaunchKernelGGL(k_row_scan, dim3(div_up(g.m, FMT_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
                        d.tile_ptr, d.tile_desc);
     return hipGetLastError();
 }
@@ -475,7 +475,7 @@ hipError_t launch_tile_desc(const Geometry &g, const DeviceArrays &d, hipStream_
 {
     if (g.p <= 1)
         return hipSuccess;
-    hipLaunchKernelGGL(k_tile_desc, dim3(div_up(g.p - 1, WAVES_PER_BLOCK)), dim3(BLOCK), 0, s, g,
+    hipLaunchKernelGGL(k_tile_desc, dim3(div_up(g.p - 1, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g,
                        d.tile_ptr, d.tile_desc, d.offset_ptr);
     return hipGetLastError();
 }
@@ -490,7 +490,7 @@ hipError_t launch_desc_offset(const Geometry &g, const DeviceArrays &d, hipStrea
 {
     if (g.p <= 1)
         return hipSuccess;
-    hipLaunchKernelGGL(k_desc_offset, dim3(div_up(g.p - 1, WAVES_PER_BLOCK)), dim3(BLOCK), 0, s, g,
+    hipLaunchKernelGGL(k_desc_offset, dim3(div_up(g.p - 1, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g,
                        d.row_ptr, d.tile_ptr, d.tile_desc, d.offset_ptr, d.offset);
     return hipGetLastError();
 }
@@ -503,10 +503,10 @@ hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_
     const size_t vsz = value_type == CSR5HIP_F64 ? 8 : 4;
     const size_t lds = (size_t)g.sigma * (OMEGA + 1) * (vsz + 4);
     if (value_type == CSR5HIP_F64)
-        hipLaunchKernelGGL(k_transpose<double>, dim3(g.p - 1), dim3(BLOCK), lds, s, g, d.tile_ptr,
+        hipLaunchKernelGGL(k_transpose<double>, dim3(g.p - 1), dim3(FMT_BLOCK), lds, s, g, d.tile_ptr,
                            d.col, (double *)d.val, r2c ? 1 : 0);
     else
-        hipLaunchKernelGGL(k_transpose<float>, dim3(g.p - 1), dim3(BLOCK), lds, s, g, d.tile_ptr,
+        hipLaunchKernelGGL(k_transpose<float>, dim3(g.p - 1), dim3(FMT_BLOCK), lds, s, g, d.tile_ptr,
                            d.col, (float *)d.val, r2c ? 1 : 0);
     return hipGetLastError();
 }
@@ -515,7 +515,7 @@ hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream
 {
     if (g.p <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_carry_meta, dim3(div_up(g.p, BLOCK)), dim3(BLOCK), 0, s, g, d.row_ptr,
+    hipLaunchKernelGGL(k_carry_meta, dim3(div_up(g.p, FMT_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
                        d.tile_ptr, reinterpret_cast<uint4 *>(d.carry_meta), d.counters + 2);
     return hipGetLastError();
 }
@@ -525,7 +525,7 @@ hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int valu
     if (g.p <= 1)
         return hipSuccess;
     // the per-tile coverage words live in tile_hdr until k_tile_hdr (launched afterwards) overwrites them
-    hipLaunchKernelGGL(k_tile_window, dim3(div_up(g.p - 1, WAVES_PER_BLOCK)), dim3(BLOCK), 0, s, g,
+    hipLaunchKernelGGL(k_tile_window, dim3(div_up(g.p - 1, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g,
                        d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.tile_hdr, xwin_elems(value_size));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
@@ -540,7 +540,7 @@ hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, hipStream_t
 {
     if (g.p <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_tile_hdr, dim3(div_up(g.p, BLOCK)), dim3(BLOCK), 0, s, g, d.tile_ptr,
+    hipLaunchKernelGGL(k_tile_hdr, dim3(div_up(g.p, FMT_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.tile_ptr,
                        reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr);
     return hipGetLastError();
 }

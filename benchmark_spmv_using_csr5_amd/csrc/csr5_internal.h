@@ -10,10 +10,16 @@ namespace csr5 {
 
 constexpr int OMEGA = CSR5HIP_OMEGA;          // one wavefront per tile
 #ifndef CSR5_WAVES_PER_BLOCK
-#define CSR5_WAVES_PER_BLOCK 2
+#define CSR5_WAVES_PER_BLOCK 1
 #endif
-constexpr int WAVES_PER_BLOCK = CSR5_WAVES_PER_BLOCK; // 128-thread workgroups: measured best on MI355X (2 vs 4 waves: +5 % nd24k-like, +0..7 % scircuit-like)
+// SpMV kernels: one tile per 64-thread workgroup.  Measured on MI355X with several processes per point
+// (scripts/experiments/wpb_modes.sh): 1 wave vs 2 vs 4 per workgroup = 338 / 333 / 324 GFLOPS scircuit-like,
+// 1 408 / 1 388 / 1 320 nd24k-like, 186 / 183 / 185 webbase-like.
+constexpr int WAVES_PER_BLOCK = CSR5_WAVES_PER_BLOCK;
 constexpr int BLOCK = OMEGA * WAVES_PER_BLOCK;
+// conversion kernels keep 128-thread workgroups (thread-per-item kernels and the per-tile transpose)
+constexpr int FMT_WAVES_PER_BLOCK = 2;
+constexpr int FMT_BLOCK = OMEGA * FMT_WAVES_PER_BLOCK;
 constexpr int BIT_SS = 6;                     // bits of scansum_offset at omega = 64
 constexpr uint32_t ROW_MASK = 0x7FFFFFFFu;    // tile_ptr bit 31 = "tile has empty rows"
 constexpr int NUM_XCD = 8;
