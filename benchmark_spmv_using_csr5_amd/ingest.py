@@ -120,8 +120,8 @@ class DeviceCsr:
 
 
 def coo_to_csr(m: int, n: int, row, col, val, symmetric: bool, dtype=np.float64) -> DeviceCsr:
-    """row / col / val: torch CUDA tensors (int32, int32, float64 or None) or raw device pointers with `nz`
-    given by a tuple ``(ptr, count)`` for row."""
+    """row / col: torch CUDA int32 tensors with the COO triplets in file order; val: float64 tensor or None
+    (structure only).  Returns the CSR in HBM (library-allocated arrays)."""
     lib = _capi.load()
     nz = int(row.numel())
     vt = _capi.F64 if np.dtype(dtype) == np.float64 else _capi.F32
