@@ -309,7 +309,18 @@ def cpu_baseline(mat, val, x, y_gpu, budget_s: float) -> dict:
     x64 = x.astype(np.float64)
     if Reference.available():
         ref = Reference()
-        cores = ref.avx2_threads()
+        # The reference runs with the ambient OpenMP thread count; on a 2-socket host the full count is far from
+        # its best for a 1 M-nnz matrix, so give it the best of a few counts (short probe each), then time that one.
+        full = ref.avx2_threads()
+        tried = {}
+        for t in sorted({full, max(full // 2, 1), max(full // 4, 1), max(full // 8, 1), 16, 8} - {0}):
+            if t > full:
+                continue
+            ref.avx2_set_threads(t)
+            _, ms_t, _ = ref.avx2_spmv(m, n, mat.row_ptr, mat.col, val64, x64, warm=5, runs=20)
+            tried[t] = round(ms_t, 4)
+        cores = min(tried, key=tried.get)
+        ref.avx2_set_threads(cores)
         y, ms1, _ = ref.avx2_spmv(m, n, mat.row_ptr, mat.col, val64, x64, warm=2, runs=5)
         runs = int(max(20, min(2000, budget_s * 1e3 / max(ms1, 1e-3))))
         y, ms, conv_ms = ref.avx2_spmv(m, n, mat.row_ptr, mat.col, val64, x64, warm=50, runs=runs)
@@ -327,6 +338,7 @@ def cpu_baseline(mat, val, x, y_gpu, budget_s: float) -> dict:
             y = orc.spmv(fmt, mat.row_ptr, x64)
         ms = (time.perf_counter() - t0) * 1e3 / runs
         conv_ms = None
+        tried = {cores: round(ms, 4)}
         kind = "port"
     nonempty = np.diff(mat.row_ptr) > 0
     denom = np.maximum(np.abs(y[nonempty]), 1e-300)
@@ -337,6 +349,10 @@ def cpu_baseline(mat, val, x, y_gpu, budget_s: float) -> dict:
         "cores": cores,
         "kind": kind,
         "sample": f"same matrix ({nnz} nnz), CSR5_avx2 omega=4 sigma=16 fp64 OpenMP, 50 warm-up + {runs} timed SpMV",
+        # 20-run probes per thread count (ms per SpMV).  They can be several times faster than the long timed run:
+        # the box's container throttles sustained multi-thread CPU use, short bursts escape it.
+        "threads_tried_ms": tried,
+        "burst_gflops": round(2.0 * nnz / (min(tried.values()) * 1e-3) / 1e9, 3),
         "ms_per_spmv": round(ms, 5),
         "csr_to_csr5_ms": None if conv_ms is None else round(conv_ms, 3),
         "max_rel_err_gpu_vs_cpu": max_rel,

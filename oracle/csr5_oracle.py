@@ -331,6 +331,10 @@ class Reference:
     def avx2_threads(self) -> int:
         return int(self._avx2_lib().ref_avx2_threads())
 
+    def avx2_set_threads(self, n: int) -> None:
+        """ambient OpenMP thread count of the reference build (omp_set_num_threads)"""
+        self._avx2_lib().ref_avx2_set_threads(int(n))
+
     def avx2_spmv(self, m, n, row_ptr, col, val, x, y0=None, warm=0, runs=0):
         """y from CSR5_avx2 (omega=4, sigma=16, fp64).  Returns (y, ms_per_run, convert_ms)."""
         L = self._avx2_lib()

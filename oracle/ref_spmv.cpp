@@ -38,6 +38,8 @@ struct quiet_stdout {
 } // namespace
 
 extern "C" int ref_avx2_threads() { return omp_get_max_threads(); }
+// the reference takes the ambient OpenMP thread count (csr5_spmv_avx2.h:70); this sets that ambient count
+extern "C" void ref_avx2_set_threads(int n) { omp_set_num_threads(n); }
 extern "C" int ref_avx2_omega() { return ANONYMOUSLIB_CSR5_OMEGA; }
 extern "C" int ref_avx2_sigma() { return ANONYMOUSLIB_CSR5_SIGMA; }
 
