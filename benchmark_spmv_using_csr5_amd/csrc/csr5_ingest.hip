@@ -343,11 +343,7 @@ int scan_sequential(const char *base, size_t size, const Head &h, int32_t *row, 
 
 // Plain pageable memory: measured on the MI355X box for 160 MB of triplets, pinning costs 7 ms and saves 3.3 ms
 // of the H2D copy (3.4 ms pinned, 6.6 ms pageable), so it does not pay for arrays that are copied once.
-void *host_alloc(size_t bytes, int *pinned)
-{
-    *pinned = 0;
-    return malloc(bytes ? bytes : 8);
-}
+void *host_alloc(size_t bytes) { return malloc(bytes ? bytes : 8); }
 
 // ------------------------------------------------------------------------------------------------
 // device side
@@ -484,15 +480,13 @@ extern "C" int csr5hip_mtx_read(const char *path, int threads, csr5hip_mtx *out)
     }
     const bool trace = getenv("CSR5_INGEST_TRACE") != nullptr;
     const double t_head = now_ms();
-    int pinned = 0;
-    int32_t *row = (int32_t *)host_alloc(sizeof(int32_t) * (size_t)h.nz, &pinned);
-    int p2 = 0, p3 = 0;
-    int32_t *col = (int32_t *)host_alloc(sizeof(int32_t) * (size_t)h.nz, &p2);
-    double *val = (double *)host_alloc(sizeof(double) * (size_t)h.nz, &p3);
+    int32_t *row = (int32_t *)host_alloc(sizeof(int32_t) * (size_t)h.nz);
+    int32_t *col = (int32_t *)host_alloc(sizeof(int32_t) * (size_t)h.nz);
+    double *val = (double *)host_alloc(sizeof(double) * (size_t)h.nz);
     auto drop = [&]() {
-        if (row) { if (pinned) (void)hipHostFree(row); else free(row); }
-        if (col) { if (p2) (void)hipHostFree(col); else free(col); }
-        if (val) { if (p3) (void)hipHostFree(val); else free(val); }
+        free(row);
+        free(col);
+        free(val);
     };
     if (!row || !col || !val) {
         drop();
@@ -587,11 +581,11 @@ extern "C" int csr5hip_mtx_read(const char *path, int threads, csr5hip_mtx *out)
     out->row = row, out->col = col, out->val = val;
     out->threads = T, out->fast_path = fast ? 1 : 0;
     out->file_bytes = (int64_t)size;
-    out->alloc_flags = (pinned ? 1 : 0) | (p2 ? 2 : 0) | (p3 ? 4 : 0);
+    out->alloc_flags = 0;
     out->t_parse_ms = now_ms() - t0;
     if (trace)
-        fprintf(stderr, "[csr5hip ingest] %d threads: open+head %.2f ms, alloc(%s) %.2f ms, count lines %.2f ms, parse %.2f ms\n",
-                T, t_head - t0, pinned ? "pinned" : "pageable", t_alloc - t_head, t_count - t_alloc, now_ms() - t_count);
+        fprintf(stderr, "[csr5hip ingest] %d threads: open+head %.2f ms, alloc %.2f ms, count lines %.2f ms, parse %.2f ms\n",
+                T, t_head - t0, t_alloc - t_head, t_count - t_alloc, now_ms() - t_count);
     return CSR5HIP_SUCCESS;
 }
 
@@ -599,10 +593,9 @@ extern "C" int csr5hip_mtx_release(csr5hip_mtx *mtx)
 {
     if (!mtx)
         return CSR5HIP_INVALID_ARGUMENT;
-    const int flags = mtx->alloc_flags;
-    if (mtx->row) { if (flags & 1) (void)hipHostFree(mtx->row); else free(mtx->row); }
-    if (mtx->col) { if (flags & 2) (void)hipHostFree(mtx->col); else free(mtx->col); }
-    if (mtx->val) { if (flags & 4) (void)hipHostFree(mtx->val); else free(mtx->val); }
+    free(mtx->row);
+    free(mtx->col);
+    free(mtx->val);
     memset(mtx, 0, sizeof *mtx);
     return CSR5HIP_SUCCESS;
 }

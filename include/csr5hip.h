@@ -174,7 +174,7 @@ typedef struct csr5hip_mtx {
     int fast_path;         /* 1 = parallel line parser, 0 = sequential fscanf-compatible scanner */
     double t_parse_ms;
     int64_t file_bytes;
-    int alloc_flags;       /* private: which arrays are pinned host memory */
+    int alloc_flags;       /* reserved (0) */
 } csr5hip_mtx;
 
 /* Device CSR built from COO; every d_* array is allocated here, release with csr5hip_csr_release. */
