@@ -71,7 +71,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the synthetic stand-in (experiments)")
     ap.add_argument("--band", type=float, default=None,
-                    help="webbase only: share of near-diagonal links of the stand-in (default 0.3)")
+                    help="scircuit / webbase: share of near-diagonal entries of the stand-in (defaults 0.5 / 0.3)")
     ap.add_argument("--spinup-seconds", type=float, default=0.0,
                     help="experiment knob: untimed replay of the same SpMV before the W warm-up steps (default off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -91,7 +91,7 @@ def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device, s
                 f"R-MAT scale {scale} EF16 (synthetic)")
     gen = {"scircuit": M.scircuit_like, "webbase": M.webbase_like, "nd24k": M.nd24k_like}[workload]
     kw = {} if scale == 1.0 else {"scale": scale}
-    if workload == "webbase" and band is not None:
+    if workload in ("webbase", "scircuit") and band is not None:
         kw["band"] = band
     if workload == "scircuit" and os.environ.get("CSR5_BENCH_ROWCAP"):  # experiment knob, not a config
         kw["row_cap"] = int(os.environ["CSR5_BENCH_ROWCAP"])

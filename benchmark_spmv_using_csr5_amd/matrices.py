@@ -96,7 +96,8 @@ def _scale_to_total(lengths: np.ndarray, total: int, rng, cap: int) -> np.ndarra
     return lengths
 
 
-def scircuit_like(seed: int = 1, scale: float = 1.0, dtype=np.float64, row_cap: int = 353) -> CsrMatrix:
+def scircuit_like(seed: int = 1, scale: float = 1.0, dtype=np.float64, row_cap: int = 353,
+                  band: float = 0.5) -> CsrMatrix:
     """SuiteSparse scircuit stand-in: 170 998 x 170 998, 958 936 nnz, heavy-tailed rows (mean 5.6,
     max ~350), no structural empty rows, half the entries near the diagonal."""
     rng = np.random.default_rng(seed)
@@ -104,7 +105,8 @@ def scircuit_like(seed: int = 1, scale: float = 1.0, dtype=np.float64, row_cap: 
     nnz = max(int(958_936 * scale), m)
     raw = 1 + np.floor(rng.pareto(2.2, size=m) * 3.0).astype(np.int64)
     raw = _scale_to_total(raw, nnz, rng, cap=row_cap)
-    return csr_from_row_lengths(raw, m, rng, band=0.5, name="scircuit-like(synthetic)", dtype=dtype)
+    name = "scircuit-like(synthetic)" if band == 0.5 else f"scircuit-like(synthetic, band={band:g})"
+    return csr_from_row_lengths(raw, m, rng, band=band, name=name, dtype=dtype)
 
 
 def webbase_like(seed: int = 2, scale: float = 1.0, dtype=np.float64, band: float = 0.3) -> CsrMatrix:
