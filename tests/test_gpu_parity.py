@@ -636,3 +636,42 @@ def test_plain_c_host_program(tmp_path):
     out = subprocess.run([_build_c_host(tmp_path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, (out.stdout, out.stderr)
     assert "mismatches=0" in out.stdout
+
+
+@pytest.mark.gpu
+def test_spmv_is_capturable_in_a_callers_graph(oracle):
+    """csr5hip_spmv only enqueues kernels on the handle's stream (no allocation, no synchronisation), so a caller
+    can record it into its own hipGraph next to other work -- here a torch CUDA graph: scale x, SpMV, add."""
+    mat = M.scircuit_like(scale=0.1)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=5, mode="int")
+    rp, ci, va = _device_csr(mat, val, np.float64)
+    xd = torch.from_numpy(x).to(DEV)
+    yd = torch.zeros(mat.m, dtype=torch.float64, device=DEV)
+    zd = torch.zeros_like(yd)
+    side = torch.cuda.Stream(device=DEV)
+    for mode in (H.SPMV_FUSED, H.SPMV_TWO_PASS):
+        A = H.anonymouslibHandle(mat.m, mat.n, stream=side.cuda_stream)
+        assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0
+        assert A.setSpmvMode(mode) == 0 and A.setSigma(8) == 0 and A.asCSR5() == 0
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            assert A.spmv(1.0, yd) == 0          # warm-up outside the capture
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            xd.mul_(2.0)
+            assert A.spmv(1.0, yd) == 0
+            zd.copy_(yd).add_(1.0)
+        for rep in range(3):
+            xd.copy_(torch.from_numpy(x).to(DEV))
+            yd.fill_(-5.0)
+            torch.cuda.synchronize()
+            graph.replay()
+            torch.cuda.synchronize()
+            ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, 2.0 * x)
+            nonempty = np.diff(mat.row_ptr) > 0
+            assert np.array_equal(yd.cpu().numpy()[nonempty], ref[nonempty]), (mode, rep)
+            assert np.array_equal(zd.cpu().numpy()[nonempty], ref[nonempty] + 1.0)
+        del graph
+        A.destroy()
+        A.close()
