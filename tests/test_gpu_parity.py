@@ -305,6 +305,19 @@ def test_full_size_webbase_properties(oracle):
         assert np.array_equal(ys[0], ref)
 
 
+def test_full_size_nd24k_fp32_properties(oracle):
+    """BASELINE config 4 (fp32, 28.7 M non-zeros, 399 per row): integer data keeps every fp32 partial sum below
+    2^24, so the result must equal the fp32 scalar CSR loop exactly, with and without the LDS x-window."""
+    mat = M.nd24k_like()
+    val, x = M.fill_values(mat.nnz, mat.n, np.float32, seed=13, mode="int")
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    assert ref.dtype == np.float32 and float(ref.max()) < 2 ** 24
+    for mode in (H.SPMV_TWO_PASS, H.SPMV_FUSED):
+        for xwin in ((0, 1) if mode == H.SPMV_FUSED else (None,)):
+            _, _, _, ys = _run(mat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, mode, dtype=np.float32, y0=0.0, xwin=xwin)
+            assert np.array_equal(ys[0], ref), (mode, xwin)
+
+
 def test_cli_drop_in(tmp_path):
     """`./spmv file.mtx` (csrc/main.cpp on top of include/anonymouslib_hip.h): the reference CLI's stdout
     lines in the reference's order (CSR5_cuda/main.cu:30,119-384) and its self-check."""
