@@ -836,17 +836,36 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
     }
 }
 
+// The product build compiles this file twice (-DCSR5_SPMV_ONLY_F64 / -DCSR5_SPMV_ONLY_F32: the two halves of the
+// ~460 kernel instantiations build in parallel); experiment builds compile it once with neither macro.
+#if !defined(CSR5_SPMV_ONLY_F32)
+hipError_t launch_spmv_f64(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
+                           const SpmvOptions &opt, hipStream_t s)
+{
+    return opt.mode == 1 ? launch_sigma<double, true>(g, d, x, y, opt, s)
+                         : launch_sigma<double, false>(g, d, x, y, opt, s);
+}
+#endif
+#if !defined(CSR5_SPMV_ONLY_F64)
+hipError_t launch_spmv_f32(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
+                           const SpmvOptions &opt, hipStream_t s)
+{
+    return opt.mode == 1 ? launch_sigma<float, true>(g, d, x, y, opt, s)
+                         : launch_sigma<float, false>(g, d, x, y, opt, s);
+}
+#endif
+
+#if !defined(CSR5_SPMV_ONLY_F32)
+hipError_t launch_spmv_f32(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
+                           const SpmvOptions &opt, hipStream_t s);
+
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s)
 {
     if (g.p <= 0)
         return hipSuccess;
-    const bool fused = opt.mode == 1;
-    if (value_type == CSR5HIP_F64)
-        return fused ? launch_sigma<double, true>(g, d, x, y, opt, s)
-                     : launch_sigma<double, false>(g, d, x, y, opt, s);
-    return fused ? launch_sigma<float, true>(g, d, x, y, opt, s)
-                 : launch_sigma<float, false>(g, d, x, y, opt, s);
+    return value_type == CSR5HIP_F64 ? launch_spmv_f64(g, d, x, y, opt, s) : launch_spmv_f32(g, d, x, y, opt, s);
 }
+#endif
 
 } // namespace csr5
