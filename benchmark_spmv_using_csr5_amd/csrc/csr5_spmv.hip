@@ -6,7 +6,7 @@
 //   K11 spmv_csr5_tail_partition_kernel :384-419   one 32-thread block per tail ROW
 // i.e. three dependent launches per SpMV and a y that the caller must have zeroed.
 //
-// Here (one wavefront = one tile, omega = 64, 128-thread workgroups = 2 tiles):
+// Here (one wavefront = one tile, omega = 64, one tile per 64-thread workgroup):
 //   fused mode    : k_spmv<.., FUSED=true>  ONE launch per SpMV [default].  Tiles, the CSR tail (extra
 //                   workgroups of the same grid) and the carries.  A row that starts in tile t and spills
 //                   <= 64 elements into tile t+1 (the common case) is finished by tile t itself, which
@@ -15,12 +15,13 @@
 //                   exchange handshake, > 2 -> per-party words + arrival counter, summed in tile order by the
 //                   last arriver.  No spinning, bit-reproducible, y need not be zeroed.
 //   two-pass mode : k_spmv<.., FUSED=false> + k_calibrate: carries added in tile order by a second launch
-//                   (the reference's summation order).
+//                   (the reference's compute -> calibrate structure).
 // Variants chosen at conversion: XWIN (a 4-KB slice of x per tile staged in LDS, in-window lanes gather
-// with ds_read) and LDSY (a tile's y segments compacted in LDS, flushed with coalesced stores).
+// with ds_read), LDSY (a tile's y segments compacted in LDS, flushed with coalesced stores) and NT (non-temporal
+// column/value streams for matrices beyond the Infinity Cache).
 // Lane-local work walks the bit flags held in ONE 32-bit register (sigma <= 32); the cross-lane step is a
 // flag-propagating backward segmented scan over the 64 lanes (no prefix-sum difference, so no
-// cancellation) with DPP reductions; every independent load of a tile is in flight before any loaded
+// cancellation) on DPP row shifts and v_readlane row carries; every independent load of a tile is in flight before any loaded
 // value is consumed (two memory round trips per tile); column_index/value loads are fully coalesced
 // 256-B / 512-B wave accesses thanks to the tile transpose.
 #include "csr5_internal.h"
