@@ -282,6 +282,7 @@ def main():
                 "spmv_mode": args.mode, "launch": args.launch,
                 "lds_x_window": bool(info.x_window_active), "x_window_tiles": info.x_window_tiles,
                 "x_window_cover_pct": info.x_window_cover_pct,
+                "x_window_lines_per_gather": info.x_window_lines,
                 "values": "rand()%10 integers (reference CLI data, exact in fp)",
                 "clock_spinup_s": args.spinup_seconds,
                 "ingest_ms": ingest_ms,

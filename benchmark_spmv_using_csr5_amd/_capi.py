@@ -43,6 +43,7 @@ class Csr5Info(C.Structure):
         ("d_tile_ptr", C.c_void_p), ("d_tile_desc", C.c_void_p),
         ("d_offset_ptr", C.c_void_p), ("d_offset", C.c_void_p),
         ("x_window_tiles", C.c_int), ("x_window_active", C.c_int), ("x_window_cover_pct", C.c_int),
+        ("x_window_lines", C.c_int),
         ("t_malloc_ms", C.c_double), ("t_tile_ptr_ms", C.c_double),
         ("t_tile_desc_ms", C.c_double), ("t_transpose_ms", C.c_double),
     ]

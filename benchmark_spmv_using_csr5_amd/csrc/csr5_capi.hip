@@ -105,6 +105,7 @@ struct csr5hip_handle_s {
     int xwin_request = 1; // CSR5HIP_OPT_X_WINDOW: 0 off, 1 auto (default), 2 force
     int xwin_tiles = 0;   // tiles that got a window at conversion
     long long xwin_covered = 0; // non-zeros inside those windows
+    long long xwin_lines = 0;   // distinct x lines under the in-window lanes of one sampled gather, summed over those tiles
     Buffer b_tile_ptr, b_tile_desc, b_offset_ptr, b_offset, b_calibrator, b_acc, b_cnt, b_meta, b_counters, b_hdr;
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -127,12 +128,25 @@ struct csr5hip_handle_s {
 static int xwin_decision(const csr5hip_handle_s *h)
 {
     constexpr int XWIN_AUTO_COVER_PCT = 70;
+    constexpr int XWIN_AUTO_MIN_SIGMA = 16;
+    constexpr int XWIN_AUTO_MIN_LINES_F64 = 16;
     if (h->xwin_request == 2)
         return 1;
-    if (h->xwin_request != 1 || h->g.p <= 1)
+    if (h->xwin_request != 1 || h->g.p <= 1 || h->xwin_tiles <= 0)
         return 0;
-    return (long long)h->xwin_covered * 100 >=
-           (long long)(h->g.p - 1) * h->g.tile_elems * XWIN_AUTO_COVER_PCT;
+    // Staging a 4-KB slice of x costs 8 (fp64) or 16 (fp32) coalesced wave loads, LDS writes and a wave barrier
+    // per tile; it replaces sigma gather instructions.  Measured on MI355X (scripts/experiments/xwin_by_rowlen.py
+    // and the bench stand-ins), the window pays only when
+    //  (a) it covers most non-zeros,
+    //  (b) sigma is large enough to amortise the staging (sigma = 6: 8-11 % SLOWER on scircuit-/webbase-like with
+    //      80-95 % near-diagonal entries; sigma = 16: faster), and
+    //  (c) for fp64, a gather instruction is spread over many 128-byte lines of x (nd24k-like: 25 lines, +9 %;
+    //      columns within +-64 of the diagonal: 8 lines, -2 %); fp32 gains at any spread (nd24k-like 1.45x).
+    const bool covered = (long long)h->xwin_covered * 100 >=
+                         (long long)(h->g.p - 1) * h->g.tile_elems * XWIN_AUTO_COVER_PCT;
+    const bool spread = h->value_type == CSR5HIP_F32 ||
+                        h->xwin_lines >= (long long)XWIN_AUTO_MIN_LINES_F64 * h->xwin_tiles;
+    return covered && h->g.sigma >= XWIN_AUTO_MIN_SIGMA && spread;
 }
 
 // y segments through LDS (coalesced flush): pays when a tile holds many rows.  Measured on MI355X:
@@ -320,6 +334,7 @@ static int derive_geometry(csr5hip_handle h, int sigma)
     h->num_offsets = 0;
     h->xwin_tiles = 0;
     h->xwin_covered = 0;
+    h->xwin_lines = 0;
     h->opt.long_runs = 0;
     h->t_malloc = h->t_tile_ptr = h->t_tile_desc = h->t_transpose = 0;
     h->drop_graphs();
@@ -369,11 +384,12 @@ static int derive_kernel_tables(csr5hip_handle h)
     HIP_TRY(launch_carry_meta(g, h->d, s));
     HIP_TRY(launch_tile_window(g, h->d, (int)h->vsize(), s));
     HIP_TRY(launch_tile_hdr(g, h->d, s));
-    uint32_t stats[4] = {0, 0, 0, 0}; // x-window tiles, covered non-zeros, long runs
+    uint32_t stats[4] = {0, 0, 0, 0}; // x-window tiles, covered non-zeros, long runs, gather lines
     HIP_TRY(hipMemcpyAsync(stats, h->d.counters, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     h->xwin_tiles = (int)stats[0];
     h->xwin_covered = (long long)stats[1];
+    h->xwin_lines = (long long)stats[3];
     h->opt.long_runs = stats[2] != 0;
     return CSR5HIP_SUCCESS;
 }
@@ -768,6 +784,7 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
         info->d_offset = h->d.offset;
     }
     info->x_window_tiles = h->xwin_tiles;
+    info->x_window_lines = h->xwin_tiles > 0 ? (int)(h->xwin_lines / h->xwin_tiles) : 0;
     info->x_window_cover_pct = h->g.p > 1 ? (int)(h->xwin_covered * 100 / ((long long)(h->g.p - 1) * h->g.tile_elems)) : 0;
     info->x_window_active = h->opt.x_window;
     info->t_malloc_ms = h->t_malloc;

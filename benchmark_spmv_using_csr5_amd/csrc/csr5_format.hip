@@ -360,7 +360,8 @@ __device__ __forceinline__ int wave_sum_i32(int v)
 
 __global__ void __launch_bounds__(FMT_BLOCK) k_tile_window(Geometry g, const int32_t *__restrict__ col,
                                                        uint4 *__restrict__ carry_meta,
-                                                       uint32_t *__restrict__ covered, int XWIN_ELEMS)
+                                                       uint32_t *__restrict__ covered, int XWIN_ELEMS,
+                                                       int line_shift)
 {
     const int lane = threadIdx.x & (OMEGA - 1);
     const int t = blockIdx.x * FMT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
@@ -392,30 +393,47 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_window(Geometry g, const int
     for (int i = 0; i < g.sigma; i++)
         inside += (unsigned)(c[i * OMEGA] - lo) < (unsigned)XWIN_ELEMS;
     inside = wave_sum_i32(inside);
+    // How many distinct 128-byte lines of x do the in-window lanes of ONE gather instruction (the 64 samples) touch?
+    // That is what the window replaces: a gather spread over 30+ lines costs 60+ clk in the vector-memory path,
+    // one that sits on a handful of lines is cheap and the staging would cost more than it saves.
+    const bool in_win = (unsigned)(sample - lo) < (unsigned)XWIN_ELEMS;
+    const int line = sample >> line_shift;
+    bool first = in_win;
+#pragma unroll
+    for (int j = 0; j < OMEGA - 1; j++) {
+        const int other = __builtin_amdgcn_readlane(line, j);
+        const bool other_in = (__builtin_amdgcn_readlane((int)in_win, j) != 0);
+        first = first && !(j < lane && other_in && other == line);
+    }
+    const int lines = __popcll(__ballot(first));
     if (lane == 0) {
         const bool on = inside * 100 >= g.tile_elems * XWIN_MIN_COVER_PCT;
         reinterpret_cast<unsigned *>(&carry_meta[t])[3] = on ? (unsigned)lo + 1u : 0u;
         // per-tile result, summed by k_window_stats: two global atomics per tile on the same two words
-        // serialised the whole kernel (646 us for 28 k tiles)
-        covered[t] = on ? (unsigned)inside : 0u;
+        // serialised the whole kernel (646 us for 28 k tiles).  bits 0..15 covered non-zeros, 16..31 lines
+        covered[t] = on ? ((unsigned)inside | ((unsigned)lines << 16)) : 0u;
     }
 }
 
-// counters[0] += tiles with a window, counters[1] += non-zeros inside those windows
+// counters[0] += tiles with a window, counters[1] += non-zeros inside those windows,
+// counters[3] += distinct x lines under the in-window lanes of the sampled gather
 __global__ void __launch_bounds__(256) k_window_stats(int tiles, const uint32_t *__restrict__ covered,
                                                       uint32_t *__restrict__ counters)
 {
-    unsigned on = 0, in = 0;
+    unsigned on = 0, in = 0, lines = 0;
     for (int t = blockIdx.x * 256 + threadIdx.x; t < tiles; t += gridDim.x * 256) {
         const unsigned v = covered[t];
         on += v != 0;
-        in += v;
+        in += v & 0xFFFFu;
+        lines += v >> 16;
     }
     on = (unsigned)wave_sum_i32((int)on);
     in = (unsigned)wave_sum_i32((int)in);
+    lines = (unsigned)wave_sum_i32((int)lines);
     if ((threadIdx.x & (OMEGA - 1)) == 0 && (on | in)) {
         atomicAdd(counters + 0, on);
         atomicAdd(counters + 1, in);
+        atomicAdd(counters + 3, lines);
     }
 }
 
@@ -526,7 +544,8 @@ hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int valu
         return hipSuccess;
     // the per-tile coverage words live in tile_hdr until k_tile_hdr (launched afterwards) overwrites them
     hipLaunchKernelGGL(k_tile_window, dim3(div_up(g.p - 1, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g,
-                       d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.tile_hdr, xwin_elems(value_size));
+                       d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.tile_hdr, xwin_elems(value_size),
+                       value_size == 8 ? 4 : 5);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;

@@ -53,7 +53,8 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
 #define CSR5HIP_OPT_XCD_REMAP   2  /* 1 = contiguous tile ranges per XCD (default), 0 = round robin */
 #define CSR5HIP_OPT_X_WINDOW    3  /* fused mode: stage a per-tile slice of x in LDS and gather from it.
                                       0 = off, 1 = auto (default: on when the per-tile 4-KB windows of x
-                                      chosen at conversion cover >= 70 % of the non-zeros), 2 = force */
+                                      chosen at conversion cover >= 70 % of the non-zeros, sigma >= 16 and,
+                                      for fp64, a gather spreads over >= 16 lines of x), 2 = force */
 
 #define CSR5HIP_OPT_LDS_Y       4  /* compact a tile's y segments in LDS and flush them with coalesced
                                       stores: 0 = off, 1 = auto (default: on at <= 32 non-zeros per row),
@@ -85,6 +86,7 @@ typedef struct csr5hip_info {
     int x_window_tiles;            /* tiles that were given an LDS x-window at conversion (ours)      */
     int x_window_active;           /* 1 if spmv() launches the x-window variant                        */
     int x_window_cover_pct;        /* share of the non-zeros (tiles 0..p-2) inside their tile's window */
+    int x_window_lines;            /* mean number of distinct 128-B lines of x under the in-window lanes of one gather */
     double t_malloc_ms, t_tile_ptr_ms, t_tile_desc_ms, t_transpose_ms; /* asCSR5 phase timers (:211-214) */
 } csr5hip_info;
 

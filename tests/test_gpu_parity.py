@@ -196,10 +196,14 @@ def test_two_pass_lds_y_on_off(oracle, ldsy):
 
 
 def test_x_window_auto_selection():
-    """Banded matrix -> windows on; uniformly random columns -> off (csr5hip_info.x_window_*)."""
+    """Wide band (a gather spreads over ~25 lines of x) -> windows on; uniformly random columns -> off (no coverage);
+    columns within +-64 of the diagonal -> off as well in fp64 (covered, but a gather touches <= 8 lines: the window
+    would cost more than it saves) (csr5hip_info.x_window_*)."""
     banded = M.nd24k_like(scale=0.02, dtype=np.float64)
     rnd = zoo.small_zoo()[5]  # half-empty, uniform columns over 5000
-    for mat, expect in ((banded, 1), (rnd, 0)):
+    rng = np.random.default_rng(4)
+    tight = M.csr_from_row_lengths(rng.poisson(8, size=20000).astype(np.int64), 20000, rng, band=1.0, name="tight-band")
+    for mat, expect in ((banded, 1), (rnd, 0), (tight, 0)):
         val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=2, mode="int")
         rp, ci, va = _device_csr(mat, val, np.float64)
         xd = torch.from_numpy(x).to(DEV)
