@@ -149,15 +149,16 @@ static int xwin_decision(const csr5hip_handle_s *h)
     return covered && h->g.sigma >= XWIN_AUTO_MIN_SIGMA && spread;
 }
 
-// y segments through LDS (coalesced flush): pays when a tile holds many rows.  Measured on MI355X:
-// +3..5 % at <= 16 non-zeros per row (webbase-, R-MAT-like), -4..6 % at 399 per row (nd24k-like).
+// y segments through LDS (coalesced flush): pays when a tile holds many rows.  Measured on MI355X
+// (scripts/experiments/ldsy_by_rowlen.py): 5-15 % faster at 2-8 non-zeros per row, 1-3 % at 16, even at 20-32,
+// 1-3 % slower beyond (one or two segments per tile: the compaction is pure overhead).
 static int ldsy_decision(const csr5hip_handle_s *h)
 {
     if (h->ldsy_request == 2)
         return 1;
     if (h->ldsy_request != 1 || h->g.m <= 0)
         return 0;
-    return (long long)h->g.nnz <= 32LL * h->g.m;
+    return (long long)h->g.nnz <= 20LL * h->g.m;
 }
 
 // Non-temporal stream loads: measured on MI355X +5 % on R-MAT 22 (0.8 GB of streams) and -18..25 % on matrices

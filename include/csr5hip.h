@@ -57,7 +57,7 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       for fp64, a gather spreads over >= 16 lines of x), 2 = force */
 
 #define CSR5HIP_OPT_LDS_Y       4  /* compact a tile's y segments in LDS and flush them with coalesced
-                                      stores: 0 = off, 1 = auto (default: on at <= 32 non-zeros per row),
+                                      stores: 0 = off, 1 = auto (default: on at <= 20 non-zeros per row),
                                       2 = force (applies while 64*sigma*sizeof(vT) <= 8 KiB) */
 
 #define CSR5HIP_OPT_STREAM_NT   5  /* non-temporal loads for the column/value streams: 0 = off, 1 = auto (default: on
