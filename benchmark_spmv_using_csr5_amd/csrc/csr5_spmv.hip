@@ -167,7 +167,19 @@ __device__ __forceinline__ VT sum_run(const VT *calibrator, int slot, int len, b
     if (len <= RUN_SERIAL_MAX) {
         if (lane == leader) {
             total = has_first ? first + load(0) : load(0);
-            for (int k = 1; k < len; k++)
+            // same left-to-right association as before, but eight loads are in flight at a time: a one-lane
+            // chain of dependent round trips (up to 64 of them) was the whole cost of rows spanning 8-64 tiles
+            int k = 1;
+            for (; k + 8 <= len; k += 8) {
+                VT part[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    part[j] = load(k + j);
+#pragma unroll
+                for (int j = 0; j < 8; j++)
+                    total += part[j];
+            }
+            for (; k < len; k++)
                 total += load(k);
         }
     } else {
