@@ -65,6 +65,8 @@ def parse_args():
     ap.add_argument("--xcd-remap", type=int, default=1, choices=[0, 1])
     ap.add_argument("--lds-y", default="auto", choices=["auto", "off", "force"])
     ap.add_argument("--stream-nt", default="auto", choices=["auto", "off", "force"])
+    ap.add_argument("--slabs", default="auto", help="column slabs: auto (default), 0 = off, 2..64 = that many")
+    ap.add_argument("--slab-shift", type=int, default=None)
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = one fixed-size row block per GPU (default); strong = ONE global matrix "
                          "cut into nnz-balanced row blocks (BASELINE config: rmat24 over 8 GPUs)")
@@ -189,6 +191,9 @@ def main():
     assert A.setOption(2, args.xcd_remap) == 0  # CSR5HIP_OPT_XCD_REMAP
     assert A.setLdsY({"off": 0, "auto": 1, "force": 2}[args.lds_y]) == 0
     assert A.setStreamNT({"off": 0, "auto": 1, "force": 2}[args.stream_nt]) == 0
+    assert A.setColumnSlabs(1 if args.slabs == "auto" else int(args.slabs)) == 0
+    if args.slab_shift is not None:
+        assert A.setSlabShift(args.slab_shift) == 0
     A.warmup()
     torch.cuda.synchronize()
     if tuned:  # setup, outside every timed region (like asCSR5)
@@ -287,6 +292,8 @@ def main():
                 "clock_spinup_s": args.spinup_seconds,
                 "ingest_ms": ingest_ms,
                 "csr_to_csr5_ms": round(convert_ms, 3),
+                "column_slabs": info.column_slabs, "slab_shift": info.slab_shift, "slab_segments": info.slab_segments,
+                "slab_sigma": info.slab_sigma, "slab_build_ms": round(info.t_slab_ms, 3),
             },
             "roofline": {
                 "bound": "hbm",

@@ -32,6 +32,9 @@ OPT_XCD_REMAP = 2
 OPT_X_WINDOW = 3
 OPT_LDS_Y = 4
 OPT_STREAM_NT = 5
+OPT_COLUMN_SLABS = 6
+OPT_SLAB_SHIFT = 7
+OPT_ZERO_EMPTY_ROWS = 8
 
 
 class Csr5Info(C.Structure):
@@ -46,6 +49,8 @@ class Csr5Info(C.Structure):
         ("x_window_lines", C.c_int),
         ("t_malloc_ms", C.c_double), ("t_tile_ptr_ms", C.c_double),
         ("t_tile_desc_ms", C.c_double), ("t_transpose_ms", C.c_double),
+        ("column_slabs", C.c_int), ("slab_shift", C.c_int), ("slab_segments", C.c_int),
+        ("slab_sigma", C.c_int), ("slab_tiles", C.c_int), ("t_slab_ms", C.c_double),
     ]
 
 
@@ -88,6 +93,7 @@ SYMBOLS = [
     ("csr5hip_as_csr", C.c_int, [_H]),
     ("csr5hip_spmv", C.c_int, [_H, C.c_double, C.c_void_p]),
     ("csr5hip_spmv_repeat", C.c_int, [_H, C.c_double, C.c_void_p, C.c_int]),
+    ("csr5hip_spmv_rotate", C.c_int, [C.POINTER(_H), C.POINTER(C.c_void_p), C.c_int, C.c_double, C.c_int]),
     ("csr5hip_destroy", C.c_int, [_H]),
     ("csr5hip_autotune_sigma", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("csr5hip_set_option", C.c_int, [_H, C.c_int, C.c_int]),

@@ -111,6 +111,20 @@ struct csr5hip_handle_s {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t phase[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // asCSR5 phase boundaries
     std::unordered_map<GraphKey, hipGraphExec_t, GraphKeyHash> graphs;
+    // column slabs (csr5_slab.hip): the stacked matrix lives in an internal child handle
+    int slab_request = 1;  // CSR5HIP_OPT_COLUMN_SLABS: 0 off, 1 auto, 2..64 = S
+    int slab_shift = 4;    // CSR5HIP_OPT_SLAB_SHIFT
+    int zero_empty = 0;    // CSR5HIP_OPT_ZERO_EMPTY_ROWS
+    bool is_child = false; // internal handle of a slab structure: never builds slabs itself
+    int slab_S = 0;        // > 0: spmv() runs child + combine
+    int slab_m2 = 0;
+    double t_slab = 0;
+    csr5hip_handle_s *slab_child = nullptr;
+    Buffer b_row_ptr2, b_col2, b_val2, b_P, b_mask, b_base;
+
+    // csr5hip_spmv_rotate: one graph over several handles (cold-cache measurement protocol)
+    hipGraphExec_t rotate_exec = nullptr;
+    std::vector<void *> rotate_key;
 
     size_t vsize() const { return value_type == CSR5HIP_F64 ? 8 : 4; }
     void drop_graphs()
@@ -118,6 +132,10 @@ struct csr5hip_handle_s {
         for (auto &kv : graphs)
             (void)hipGraphExecDestroy(kv.second);
         graphs.clear();
+        if (rotate_exec)
+            (void)hipGraphExecDestroy(rotate_exec);
+        rotate_exec = nullptr;
+        rotate_key.clear();
     }
 };
 
@@ -192,11 +210,14 @@ int csr5hip_create(csr5hip_handle *out, int m, int n, int value_type)
     return CSR5HIP_SUCCESS;
 }
 
+static void release_slabs(csr5hip_handle h);
+
 int csr5hip_free(csr5hip_handle h)
 {
     if (!h)
         return CSR5HIP_INVALID_ARGUMENT;
     h->drop_graphs();
+    release_slabs(h);
     for (Buffer *b : {&h->b_tile_ptr, &h->b_tile_desc, &h->b_offset_ptr, &h->b_offset,
                       &h->b_calibrator, &h->b_acc, &h->b_cnt, &h->b_meta, &h->b_counters, &h->b_hdr})
         b->release();
@@ -277,6 +298,8 @@ int csr5hip_set_sigma(csr5hip_handle h, int sigma)
     return CSR5HIP_SUCCESS;
 }
 
+static int build_slabs(csr5hip_handle h);
+
 int csr5hip_set_option(csr5hip_handle h, int option, int value)
 {
     if (!h)
@@ -311,9 +334,32 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         if (h->format == CSR5HIP_FORMAT_CSR5)
             h->opt.x_window = xwin_decision(h);
         break;
+    case CSR5HIP_OPT_COLUMN_SLABS:
+        if (value < 0 || value > 64 || (value & (value - 1)))
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->slab_request = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5) {
+            h->drop_graphs();
+            return build_slabs(h);
+        }
+        break;
+    case CSR5HIP_OPT_SLAB_SHIFT:
+        if (value < 0 || value > 24)
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->slab_shift = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5) {
+            h->drop_graphs();
+            return build_slabs(h);
+        }
+        break;
+    case CSR5HIP_OPT_ZERO_EMPTY_ROWS:
+        h->zero_empty = value ? 1 : 0;
+        break;
     default:
         return CSR5HIP_INVALID_ARGUMENT;
     }
+    if (h->slab_child && (option == CSR5HIP_OPT_SPMV_MODE || option == CSR5HIP_OPT_LDS_Y || option == CSR5HIP_OPT_STREAM_NT))
+        csr5hip_set_option(h->slab_child, option, value);
     h->drop_graphs();
     return CSR5HIP_SUCCESS;
 }
@@ -395,6 +441,54 @@ static int derive_kernel_tables(csr5hip_handle h)
     return CSR5HIP_SUCCESS;
 }
 
+// steps 1-2 of the conversion: everything that is derived from row_ptr alone (tile_ptr, tile_desc, offset_ptr,
+// offset).  Contains the first of the two host round trips of asCSR5: the two words the host needs -- tail start and
+// number of offsets, as in the reference (anonymouslib_cuda.h:165-167, format_cuda.h:331-343).
+static int build_format_arrays(csr5hip_handle h)
+{
+    Geometry &g = h->g;
+    hipStream_t s = h->stream;
+    for (hipEvent_t &e : h->phase)
+        if (!e)
+            HIP_TRY(hipEventCreate(&e));
+    // step 1: tile_ptr (+ empty-row marks) -- flag scatter shares the row pass
+    HIP_TRY(hipEventRecord(h->phase[0], s));
+    HIP_TRY(launch_tile_ptr(g, h->d, s));
+    HIP_TRY(launch_row_scan(g, h->d, s));
+    HIP_TRY(hipEventRecord(h->phase[1], s));
+
+    // step 2: tile_desc, offset_ptr scan, then the two 4-byte reads
+    HIP_TRY(launch_tile_desc(g, h->d, s));
+    HIP_TRY(launch_offset_scan(g, h->d, s));
+    uint32_t tail_word = 0;
+    int32_t num_offsets = 0;
+    HIP_TRY(hipMemcpyAsync(&tail_word, h->d.tile_ptr + (g.p - 1), 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&num_offsets, h->d.offset_ptr + g.p, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    g.tail_start = (int)(tail_word & ROW_MASK);
+    h->num_offsets = num_offsets;
+
+    if (num_offsets > 0) {
+        const double t0 = now_ms();
+        HIP_TRY(h->b_offset.reserve((size_t)num_offsets * 4));
+        h->d.offset = (int32_t *)h->b_offset.ptr;
+        h->t_malloc += now_ms() - t0;
+        // one slot per flagged tile is never written (lane 0's forced flag, format_cuda.h:391-399): keep the array
+        // deterministic so that a checkpoint can be compared with a re-derived copy
+        HIP_TRY(hipMemsetAsync(h->d.offset, 0, (size_t)num_offsets * 4, s));
+        HIP_TRY(launch_desc_offset(g, h->d, s));
+    }
+    HIP_TRY(hipEventRecord(h->phase[2], s));
+    return CSR5HIP_SUCCESS;
+}
+
+static void resolve_variants(csr5hip_handle h)
+{
+    h->opt.x_window = xwin_decision(h);
+    h->opt.lds_y = ldsy_decision(h);
+    h->opt.stream_nt = nt_decision(h);
+}
+
 int csr5hip_as_csr5(csr5hip_handle h)
 {
     if (!h)
@@ -413,12 +507,8 @@ int csr5hip_as_csr5(csr5hip_handle h)
     hipStream_t s = h->stream;
 
     // Two host round trips in all (the reference synchronises after every phase, anonymouslib_cuda.h:161-208):
-    // one for the two words the host needs -- tail start and number of offsets, as in the reference
-    // (anonymouslib_cuda.h:165-167, format_cuda.h:331-343) -- and one at the end.  The four phase times the
-    // reference prints are taken from events on the stream instead of host timers around synchronisations.
-    for (hipEvent_t &e : h->phase)
-        if (!e)
-            HIP_TRY(hipEventCreate(&e));
+    // one inside build_format_arrays and one at the end.  The four phase times the reference prints are taken
+    // from events on the stream instead of host timers around synchronisations.
     double t0 = now_ms();
     rc = reserve_aux(h);
     if (rc != CSR5HIP_SUCCESS)
@@ -426,53 +516,177 @@ int csr5hip_as_csr5(csr5hip_handle h)
     h->t_malloc += now_ms() - t0;
 
     if (g.p > 0) {
-        // step 1: tile_ptr (+ empty-row marks) -- flag scatter shares the row pass
-        HIP_TRY(hipEventRecord(h->phase[0], s));
-        HIP_TRY(launch_tile_ptr(g, h->d, s));
-        HIP_TRY(launch_row_scan(g, h->d, s));
-        HIP_TRY(hipEventRecord(h->phase[1], s));
-
-        // step 2: tile_desc, offset_ptr scan, then the two 4-byte reads
-        HIP_TRY(launch_tile_desc(g, h->d, s));
-        HIP_TRY(launch_offset_scan(g, h->d, s));
-        uint32_t tail_word = 0;
-        int32_t num_offsets = 0;
-        HIP_TRY(hipMemcpyAsync(&tail_word, h->d.tile_ptr + (g.p - 1), 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipMemcpyAsync(&num_offsets, h->d.offset_ptr + g.p, 4, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        g.tail_start = (int)(tail_word & ROW_MASK);
-        h->num_offsets = num_offsets;
-
-        if (num_offsets > 0) {
-            t0 = now_ms();
-            HIP_TRY(h->b_offset.reserve((size_t)num_offsets * 4));
-            h->d.offset = (int32_t *)h->b_offset.ptr;
-            h->t_malloc += now_ms() - t0;
-            HIP_TRY(launch_desc_offset(g, h->d, s));
-        }
-        HIP_TRY(hipEventRecord(h->phase[2], s));
-
-        // step 3: in-place tile transpose of column_index and value, then the kernel-side tables
-        HIP_TRY(launch_transpose(g, h->d, h->value_type, true, s));
-        HIP_TRY(hipEventRecord(h->phase[3], s));
-        rc = derive_kernel_tables(h); // ends with the second (last) synchronisation
+        rc = build_format_arrays(h);
         if (rc != CSR5HIP_SUCCESS)
             return rc;
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, h->phase[0], h->phase[1]));
-        h->t_tile_ptr += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, h->phase[1], h->phase[2]));
-        h->t_tile_desc += ms;
-        HIP_TRY(hipEventElapsedTime(&ms, h->phase[2], h->phase[3]));
-        h->t_transpose += ms;
+        // step 3: in-place tile transpose of column_index and value, then the kernel-side tables
+        HIP_TRY(launch_transpose(g, h->d, h->value_type, true, s));
+        // From here on the caller's arrays are in tile order while the handle still says CSR: a failure must
+        // put them back (a retry would transpose them a second time).
+        auto finish = [&]() -> int {
+            HIP_TRY(hipEventRecord(h->phase[3], s));
+            int r = derive_kernel_tables(h); // ends with the second (last) synchronisation
+            if (r != CSR5HIP_SUCCESS)
+                return r;
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, h->phase[0], h->phase[1]));
+            h->t_tile_ptr += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, h->phase[1], h->phase[2]));
+            h->t_tile_desc += ms;
+            HIP_TRY(hipEventElapsedTime(&ms, h->phase[2], h->phase[3]));
+            h->t_transpose += ms;
+            return CSR5HIP_SUCCESS;
+        };
+        rc = finish();
+        if (rc != CSR5HIP_SUCCESS) {
+            const std::string why = g_last_error;
+            if (launch_transpose(g, h->d, h->value_type, false, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                h->format = -1; // the arrays could not be restored: the handle is unusable until inputCSR
+            g_last_error = why;
+            return rc;
+        }
     } else {
         HIP_TRY(hipStreamSynchronize(s));
     }
-    h->opt.x_window = xwin_decision(h);
-    h->opt.lds_y = ldsy_decision(h);
-    h->opt.stream_nt = nt_decision(h);
+    resolve_variants(h);
     h->format = CSR5HIP_FORMAT_CSR5;
+    return build_slabs(h);
+}
+
+// ---- column slabs (csr5_slab.hip) ------------------------------------------------------------------
+static void release_slabs(csr5hip_handle h)
+{
+    if (h->slab_child) {
+        csr5hip_free(h->slab_child);
+        h->slab_child = nullptr;
+    }
+    for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_mask, &h->b_base})
+        b->release();
+    h->slab_S = 0;
+    h->slab_m2 = 0;
+}
+
+// Number of slabs spmv() should use (0 = none).  Auto rule (measured on MI355X, scripts/experiments/slab_*):
+// the structure pays when x is larger than one XCD's 4-MB L2 AND the columns are scattered (the per-tile x windows
+// found at conversion cover less than half of the non-zeros); a banded matrix keeps its x lines in L2 anyway and
+// would only pay for the partial sums.
+static int slab_count_for(const csr5hip_handle_s *h)
+{
+    if (h->is_child || h->slab_request == 0 || h->g.p < 2 || h->g.nnz <= 0 || h->g.m <= 0)
+        return 0;
+    if (h->slab_request >= 2)
+        return h->slab_request;
+    const long long xbytes = (long long)h->g.n * (long long)h->vsize();
+    if (xbytes < 4LL * 1024 * 1024 || h->g.p < 2 * 256)
+        return 0;
+    const long long covered_pct = h->xwin_covered * 100 / ((long long)(h->g.p - 1) * h->g.tile_elems);
+    if (covered_pct >= 50)
+        return 0;
+    return xbytes < 16LL * 1024 * 1024 ? 8 : (xbytes < 64LL * 1024 * 1024 ? 16 : 32);
+}
+
+static int build_slabs(csr5hip_handle h)
+{
+    release_slabs(h);
+    h->t_slab = 0;
+    const int S = slab_count_for(h);
+    if (!S)
+        return CSR5HIP_SUCCESS;
+    const double t0 = now_ms();
+    const Geometry &g = h->g;
+    hipStream_t s = h->stream;
+    int bits = 0;
+    while ((1 << bits) < S)
+        bits++;
+    struct Temps {
+        void *hist = nullptr, *scan_tmp = nullptr, *key = nullptr, *count = nullptr, *sel_tmp = nullptr;
+        ~Temps()
+        {
+            for (void *p : {hist, scan_tmp, key, count, sel_tmp})
+                if (p)
+                    (void)hipFree(p);
+        }
+    } t;
+    size_t scan_bytes = 0, sel_bytes = 0;
+    HIP_TRY(slab_scan_tmp_bytes((size_t)S * g.p, &scan_bytes));
+    HIP_TRY(slab_select_tmp_bytes(g.nnz, &sel_bytes));
+    HIP_TRY(hipMalloc(&t.hist, (size_t)S * g.p * 4));
+    HIP_TRY(hipMalloc(&t.scan_tmp, scan_bytes ? scan_bytes : 4));
+    HIP_TRY(hipMalloc(&t.key, (size_t)g.nnz * 8));
+    HIP_TRY(hipMalloc(&t.count, 4));
+    HIP_TRY(hipMalloc(&t.sel_tmp, sel_bytes ? sel_bytes : 4));
+    HIP_TRY(h->b_col2.reserve((size_t)g.nnz * 4));
+    HIP_TRY(h->b_val2.reserve((size_t)g.nnz * h->vsize()));
+    HIP_TRY(slab_partition(g, h->d, h->value_type, S, bits, h->slab_shift, (uint32_t *)t.hist, t.scan_tmp, scan_bytes,
+                           (int32_t *)h->b_col2.ptr, h->b_val2.ptr, (unsigned long long *)t.key, s));
+    HIP_TRY(slab_count_segments(g.nnz, (const unsigned long long *)t.key, (unsigned int *)t.count, s));
+    unsigned int m2 = 0;
+    HIP_TRY(hipMemcpyAsync(&m2, t.count, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(h->b_row_ptr2.reserve(((size_t)m2 + 1) * 4));
+    HIP_TRY(slab_segments(g.nnz, (const unsigned long long *)t.key, t.sel_tmp, sel_bytes, (int32_t *)h->b_row_ptr2.ptr,
+                          (unsigned int *)t.count, s));
+    const size_t mask_words = ((size_t)g.m * S + 31) / 32 + 1;
+    const size_t base_words = ((size_t)g.m + OMEGA - 1) / OMEGA * S;
+    HIP_TRY(h->b_mask.reserve(mask_words * 4));
+    HIP_TRY(h->b_base.reserve(base_words * 4));
+    HIP_TRY(hipMemsetAsync(h->b_mask.ptr, 0, mask_words * 4, s));
+    HIP_TRY(hipMemsetAsync(h->b_base.ptr, 0, base_words * 4, s));
+    HIP_TRY(slab_tables((int)m2, g.nnz, S, (int32_t *)h->b_row_ptr2.ptr, (const unsigned long long *)t.key,
+                        (uint32_t *)h->b_mask.ptr, (uint32_t *)h->b_base.ptr, s));
+    HIP_TRY(h->b_P.reserve(((size_t)m2 + 1) * h->vsize()));
+    HIP_TRY(hipMemsetAsync(h->b_P.ptr, 0, ((size_t)m2 + 1) * h->vsize(), s));
+    HIP_TRY(hipStreamSynchronize(s)); // the temporaries are released when `t` goes out of scope
+
+    // the stacked matrix: an ordinary CSR matrix with m2 rows, converted and multiplied by the ordinary kernels
+    csr5hip_handle c = new csr5hip_handle_s();
+    c->is_child = true;
+    c->g.m = (int)m2;
+    c->g.n = g.n;
+    c->value_type = h->value_type;
+    c->stream = s;
+    c->opt.mode = h->opt.mode;
+    c->opt.xcd_remap = 1;
+    c->xwin_request = 0;
+    c->slab_request = 0;
+    c->ldsy_request = h->ldsy_request;
+    c->nt_request = h->nt_request;
+    int rc = csr5hip_input_csr(c, g.nnz, (int32_t *)h->b_row_ptr2.ptr, (int32_t *)h->b_col2.ptr, h->b_val2.ptr);
+    c->sigma_request = g.sigma;
+    if (rc == CSR5HIP_SUCCESS)
+        rc = csr5hip_as_csr5(c);
+    if (rc != CSR5HIP_SUCCESS) {
+        csr5hip_free(c);
+        release_slabs(h);
+        return rc;
+    }
+    h->slab_child = c;
+    h->slab_S = S;
+    h->slab_m2 = (int)m2;
+    h->t_slab = now_ms() - t0;
     return CSR5HIP_SUCCESS;
+}
+
+// one SpMV on stream s: the tile kernel on the matrix itself, or -- with column slabs -- on the stacked matrix
+// followed by the combine kernel
+static hipError_t enqueue_spmv(csr5hip_handle h, void *d_y, hipStream_t s)
+{
+    if (h->slab_S > 0) {
+        csr5hip_handle c = h->slab_child;
+        hipError_t e = launch_spmv(c->g, c->d, c->value_type, h->x, h->b_P.ptr, c->opt, s);
+        if (e != hipSuccess)
+            return e;
+        return launch_slab_combine(h->g.m, h->g.tail_start, h->zero_empty, h->slab_S, h->value_type,
+                                   (const uint32_t *)h->b_mask.ptr, (const uint32_t *)h->b_base.ptr, h->b_P.ptr, d_y, s);
+    }
+    if (h->zero_empty && h->g.m > 0) {
+        // every row that owns a non-zero is overwritten by the kernel; this defines the others
+        hipError_t e = hipMemsetAsync(d_y, 0, (size_t)h->g.m * h->vsize(), s);
+        if (e != hipSuccess)
+            return e;
+    }
+    return launch_spmv(h->g, h->d, h->value_type, h->x, d_y, h->opt, s);
 }
 
 // ---- serialise / deserialise (checkpoint of the converted matrix) ----------
@@ -565,6 +779,25 @@ int csr5hip_load(const char *path, csr5hip_handle *out, csr5hip_csr *arrays)
         return CSR5HIP_INVALID_ARGUMENT;
     }
     const size_t vs = hd.value_type == CSR5HIP_F64 ? 8 : 4;
+    // the file must be exactly as long as its header implies (a truncated or padded file is rejected before any
+    // nnz-sized allocation)
+    {
+        const long long expect = (long long)sizeof hd + ((long long)hd.m + 1) * 4 + (long long)hd.nnz * (4 + (long long)vs) +
+                                 ((long long)hd.p + 1) * 8 + (long long)hd.p * OMEGA * hd.num_packet * 4 +
+                                 (long long)hd.num_offsets * 4;
+        long long have = -1;
+        const long pos = ftell(f);
+        if (pos >= 0 && fseek(f, 0, SEEK_END) == 0) {
+            have = ftell(f);
+            if (fseek(f, pos, SEEK_SET) != 0)
+                have = -1;
+        }
+        if (have != expect) {
+            fclose(f);
+            g_last_error = std::string("csr5hip_load: file size does not match its header: ") + path;
+            return CSR5HIP_INVALID_ARGUMENT;
+        }
+    }
     csr5hip_handle h = nullptr;
     int rc = csr5hip_create(&h, hd.m, hd.n, hd.value_type);
     auto fail_with = [&](int code, const char *msg) {
@@ -596,29 +829,70 @@ int csr5hip_load(const char *path, csr5hip_handle *out, csr5hip_csr *arrays)
         rc = reserve_aux(h);
     if (rc != CSR5HIP_SUCCESS)
         return fail_with(rc, nullptr);
-    h->g.tail_start = hd.tail_start;
-    h->num_offsets = hd.num_offsets;
-    if (hd.num_offsets > 0) {
-        if (h->b_offset.reserve((size_t)hd.num_offsets * 4) != hipSuccess)
-            return fail_with(CSR5HIP_HIP_ERROR, "device allocation failed");
-        h->d.offset = (int32_t *)h->b_offset.ptr;
+    // row_ptr and column_index are used as addresses by every kernel: check them on the device before anything
+    // reads through them (row_ptr monotone from 0 to nnz, columns inside [0, n))
+    {
+        uint32_t bad = 0;
+        hipError_t e = hipMemsetAsync(h->d.counters, 0, 16, h->stream);
+        if (e == hipSuccess)
+            e = launch_validate_csr(hd.m, hd.n, hd.nnz, arrays->d_row_ptr, arrays->d_col_idx, h->d.counters, h->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(&bad, h->d.counters, 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess)
+            e = hipMemsetAsync(h->d.counters, 0, 16, h->stream);
+        if (e != hipSuccess)
+            return fail_with(fail_hip(e, "csr5hip_load: validation"), nullptr);
+        if (bad)
+            return fail_with(CSR5HIP_INVALID_ARGUMENT, bad & 1u ? "row_ptr is not a monotone pointer array ending at nnz"
+                                                                 : "a column index lies outside [0, n)");
     }
-    ok = read_dev(f, h->d.tile_ptr, ((size_t)hd.p + 1) * 4, stage);
-    ok = ok && read_dev(f, h->d.tile_desc, (size_t)hd.p * OMEGA * hd.num_packet * 4, stage);
-    ok = ok && read_dev(f, h->d.offset_ptr, ((size_t)hd.p + 1) * 4, stage);
-    ok = ok && read_dev(f, h->d.offset, (size_t)hd.num_offsets * 4, stage);
-    if (!ok)
-        return fail_with(CSR5HIP_INVALID_ARGUMENT, "truncated file");
+    // The four format arrays are a pure function of row_ptr and sigma: they are RE-DERIVED here (cheap: no transpose)
+    // and the file's copies only have to match -- nothing read from the file is ever used as an index unchecked.
+    if (hd.p > 0) {
+        rc = build_format_arrays(h);
+        if (rc != CSR5HIP_SUCCESS)
+            return fail_with(rc, nullptr);
+        if (h->g.tail_start != hd.tail_start || h->num_offsets != hd.num_offsets)
+            return fail_with(CSR5HIP_INVALID_ARGUMENT, "format arrays do not belong to this row_ptr (tail start / offsets)");
+    } else if (hd.num_offsets != 0) {
+        return fail_with(CSR5HIP_INVALID_ARGUMENT, "format arrays do not belong to this row_ptr");
+    }
+    {
+        std::vector<char> mine;
+        auto same = [&](const void *dptr, size_t bytes) -> bool {
+            if (!bytes)
+                return true;
+            stage.resize(bytes);
+            mine.resize(bytes);
+            if (fread(stage.data(), 1, bytes, f) != bytes)
+                return false;
+            if (hipMemcpy(mine.data(), dptr, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+                return false;
+            return memcmp(stage.data(), mine.data(), bytes) == 0;
+        };
+        ok = same(h->d.tile_ptr, ((size_t)hd.p + 1) * 4);
+        ok = ok && same(h->d.tile_desc, (size_t)hd.p * OMEGA * hd.num_packet * 4);
+        ok = ok && same(h->d.offset_ptr, ((size_t)hd.p + 1) * 4);
+        ok = ok && same(h->d.offset, (size_t)hd.num_offsets * 4);
+        if (!ok)
+            return fail_with(CSR5HIP_INVALID_ARGUMENT, "format arrays in the file do not match the ones derived from its row_ptr");
+    }
     if (hd.p > 0) {
         rc = derive_kernel_tables(h);
         if (rc != CSR5HIP_SUCCESS)
             return fail_with(rc, nullptr);
     }
     fclose(f);
-    h->opt.x_window = xwin_decision(h);
-    h->opt.lds_y = ldsy_decision(h);
-    h->opt.stream_nt = nt_decision(h);
+    resolve_variants(h);
     h->format = CSR5HIP_FORMAT_CSR5;
+    rc = build_slabs(h);
+    if (rc != CSR5HIP_SUCCESS) {
+        csr5hip_free(h);
+        csr5hip_csr_release(arrays);
+        return rc;
+    }
     *out = h;
     return CSR5HIP_SUCCESS;
 }
@@ -632,6 +906,7 @@ int csr5hip_as_csr(csr5hip_handle h)
     if (h->format != CSR5HIP_FORMAT_CSR5)
         return CSR5HIP_UNKOWN_FORMAT;
     h->drop_graphs();
+    release_slabs(h);
     HIP_TRY(launch_transpose(h->g, h->d, h->value_type, false, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     // the aux buffers stay cached in the handle (capacity only grows) until csr5hip_free
@@ -652,7 +927,7 @@ int csr5hip_spmv(csr5hip_handle h, double alpha, void *d_y)
         return CSR5HIP_UNKOWN_FORMAT;
     if (!h->x)
         return CSR5HIP_INVALID_ARGUMENT;
-    HIP_TRY(launch_spmv(h->g, h->d, h->value_type, h->x, d_y, h->opt, h->stream));
+    HIP_TRY(enqueue_spmv(h, d_y, h->stream));
     return CSR5HIP_SUCCESS;
 }
 
@@ -664,6 +939,8 @@ int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count)
         return CSR5HIP_UNSUPPORTED_CSR_SPMV;
     if (h->format != CSR5HIP_FORMAT_CSR5)
         return CSR5HIP_UNKOWN_FORMAT;
+    if (!h->x)
+        return CSR5HIP_INVALID_ARGUMENT;
     if (count == 0)
         return CSR5HIP_SUCCESS;
     GraphKey key{d_y, count, h->opt.mode};
@@ -677,7 +954,7 @@ int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count)
         int rc = CSR5HIP_SUCCESS;
         if (e == hipSuccess) {
             for (int i = 0; i < count && e == hipSuccess; i++)
-                e = launch_spmv(h->g, h->d, h->value_type, h->x, d_y, h->opt, cs);
+                e = enqueue_spmv(h, d_y, cs);
             hipError_t e2 = hipStreamEndCapture(cs, &graph);
             if (e == hipSuccess)
                 e = e2;
@@ -698,6 +975,59 @@ int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count)
     }
     HIP_TRY(hipGraphLaunch(it->second, h->stream));
     (void)alpha;
+    return CSR5HIP_SUCCESS;
+}
+
+int csr5hip_spmv_rotate(csr5hip_handle *hs, void **d_ys, int k, double alpha, int count)
+{
+    (void)alpha;
+    if (!hs || !d_ys || k < 1 || count < 0)
+        return CSR5HIP_INVALID_ARGUMENT;
+    for (int i = 0; i < k; i++) {
+        if (!hs[i] || !d_ys[i] || !hs[i]->x)
+            return CSR5HIP_INVALID_ARGUMENT;
+        if (hs[i]->format == CSR5HIP_FORMAT_CSR)
+            return CSR5HIP_UNSUPPORTED_CSR_SPMV;
+        if (hs[i]->format != CSR5HIP_FORMAT_CSR5)
+            return CSR5HIP_UNKOWN_FORMAT;
+    }
+    if (count == 0)
+        return CSR5HIP_SUCCESS;
+    csr5hip_handle h0 = hs[0];
+    std::vector<void *> key;
+    key.push_back((void *)(intptr_t)count);
+    for (int i = 0; i < k; i++) {
+        key.push_back(hs[i]);
+        key.push_back(d_ys[i]);
+    }
+    if (!h0->rotate_exec || h0->rotate_key != key) {
+        if (h0->rotate_exec)
+            (void)hipGraphExecDestroy(h0->rotate_exec);
+        h0->rotate_exec = nullptr;
+        h0->rotate_key.clear();
+        hipStream_t cs = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            for (int i = 0; i < count && e == hipSuccess; i++)
+                e = enqueue_spmv(hs[i % k], d_ys[i % k], cs);
+            hipError_t e2 = hipStreamEndCapture(cs, &graph);
+            if (e == hipSuccess)
+                e = e2;
+        }
+        hipGraphExec_t exec = nullptr;
+        if (e == hipSuccess)
+            e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph)
+            (void)hipGraphDestroy(graph);
+        (void)hipStreamDestroy(cs);
+        if (e != hipSuccess)
+            return fail_hip(e, "hipGraph capture of rotating spmv");
+        h0->rotate_exec = exec;
+        h0->rotate_key = key;
+    }
+    HIP_TRY(hipGraphLaunch(h0->rotate_exec, h0->stream));
     return CSR5HIP_SUCCESS;
 }
 
@@ -792,6 +1122,12 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->t_tile_ptr_ms = h->t_tile_ptr;
     info->t_tile_desc_ms = h->t_tile_desc;
     info->t_transpose_ms = h->t_transpose;
+    info->column_slabs = h->slab_S;
+    info->slab_shift = h->slab_shift;
+    info->slab_segments = h->slab_m2;
+    info->slab_sigma = h->slab_child ? h->slab_child->g.sigma : 0;
+    info->slab_tiles = h->slab_child ? h->slab_child->g.p : 0;
+    info->t_slab_ms = h->t_slab;
     return CSR5HIP_SUCCESS;
 }
 

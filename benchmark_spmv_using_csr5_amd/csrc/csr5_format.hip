@@ -456,6 +456,26 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_hdr(Geometry g, const uint32
     reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t + 1] = hi;
 }
 
+// checkpoint loading: the index arrays come from a file and are used as addresses by every later kernel
+__global__ void __launch_bounds__(256) k_validate_csr(int m, int n, int nnz, const int32_t *__restrict__ row_ptr,
+                                                      const int32_t *__restrict__ col, uint32_t *__restrict__ flag)
+{
+    uint32_t bad = 0;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i <= (size_t)m; i += stride) {
+        const int a = row_ptr[i];
+        if (i == 0 && a != 0)
+            bad |= 1u;
+        if (i == (size_t)m ? a != nnz : (a > row_ptr[i + 1] || a < 0))
+            bad |= 1u;
+    }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)nnz; i += stride)
+        if ((uint32_t)col[i] >= (uint32_t)n)
+            bad |= 2u;
+    if (bad)
+        atomicOr(flag, bad);
+}
+
 __global__ void k_warmup(int *out)
 {
     __shared__ int s[OMEGA];
@@ -561,6 +581,15 @@ hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, hipStream_t
         return hipSuccess;
     hipLaunchKernelGGL(k_tile_hdr, dim3(div_up(g.p, FMT_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.tile_ptr,
                        reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr);
+    return hipGetLastError();
+}
+
+hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,
+                               hipStream_t s)
+{
+    long long blocks = ((long long)(nnz > m ? nnz : m + 1) + 256 * 8 - 1) / (256 * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks);
+    hipLaunchKernelGGL(k_validate_csr, dim3((unsigned)blocks), dim3(256), 0, s, m, n, nnz, row_ptr, col, flag);
     return hipGetLastError();
 }
 

@@ -81,6 +81,23 @@ hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream
 hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int value_size, hipStream_t s);
 hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_warmup(hipStream_t s);
+// flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)
+hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,
+                               hipStream_t s);
+
+// ---- column slabs (csr5_slab.hip) ----
+hipError_t slab_scan_tmp_bytes(size_t items, size_t *bytes);
+hipError_t slab_select_tmp_bytes(int nnz, size_t *bytes);
+hipError_t slab_partition(const Geometry &g, const DeviceArrays &d, int value_type, int S, int bits, int shift,
+                          uint32_t *hist, void *scan_tmp, size_t scan_tmp_bytes, int32_t *col2, void *val2,
+                          unsigned long long *key2, hipStream_t s);
+hipError_t slab_count_segments(int nnz, const unsigned long long *key2, unsigned int *d_count, hipStream_t s);
+hipError_t slab_segments(int nnz, const unsigned long long *key2, void *tmp, size_t tmp_bytes, int32_t *row_ptr2,
+                         unsigned int *d_count, hipStream_t s);
+hipError_t slab_tables(int m2, int nnz, int S, int32_t *row_ptr2, const unsigned long long *key2, uint32_t *mask,
+                       uint32_t *base, hipStream_t s);
+hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int value_type, const uint32_t *mask,
+                               const uint32_t *base, const void *P, void *y, hipStream_t s);
 
 // ---- SpMV (csr5_spmv.hip) ----
 struct SpmvOptions {

@@ -135,8 +135,8 @@ __device__ __forceinline__ VT lane_above(VT v)
 //   1  the partial IS the row (row starts on the tile boundary and ends inside the tile): plain store.
 //   2  exchange handshake, ONE returning atomic per party: each party swaps the bit-inverted value
 //      into the slot (0 = empty, the memset state); whoever gets a non-zero word back is second, adds
-//      the two partials (a+b == b+a: bit-reproducible), stores y and re-arms the slot.  (Only the
-//      all-ones NaN payload would collide with "empty"; arithmetic never produces it.)
+//      the two partials (a+b == b+a: bit-reproducible), stores y and re-arms the slot.  (The
+//      all-ones NaN payload, whose inverse would read as "empty", is published as the default quiet NaN.)
 //   >2 rows spanning several tiles: every party parks its partial in its OWN word (leading partial of
 //      tile t -> calibrator[t], closing partial of tile h-1 -> acc[h]) with a write-through agent-scope
 //      store, drains it (s_waitcnt vmcnt(0)), then bumps the arrival counter.  The last arriver reads the
@@ -214,7 +214,13 @@ __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, VT *calibra
         *row_y = v;
     } else if (expected == 2u) {
         bits_t *s = reinterpret_cast<bits_t *>(&acc[slot]);
-        const bits_t mine = ~__builtin_bit_cast(bits_t, v);
+        // 0 marks the empty slot, so the one payload whose inverse is 0 -- the all-ones NaN that poisoned
+        // inputs (0xFF fill) propagate through the FMAs -- is published as the default quiet NaN instead:
+        // both parties would otherwise believe they came first and the slot would stay armed for good.
+        bits_t vb = __builtin_bit_cast(bits_t, v);
+        if (vb == ~(bits_t)0)
+            vb = sizeof(VT) == 8 ? (bits_t)0x7FF8000000000000ull : (bits_t)0x7FC00000u;
+        const bits_t mine = ~vb;
         const bits_t other = __hip_atomic_exchange(s, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (other != 0) {
             *row_y = v + __builtin_bit_cast(VT, (bits_t)~other);

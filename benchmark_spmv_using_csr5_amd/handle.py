@@ -93,6 +93,14 @@ class anonymouslibHandle:
     def spmv_repeat(self, alpha, y, count: int) -> int:
         return self._lib.csr5hip_spmv_repeat(self._h, float(alpha), _ptr(y), int(count))
 
+    @staticmethod
+    def spmv_rotate(handles, ys, count: int) -> int:
+        """`count` SpMVs from one hipGraph, the i-th on handles[i % k] into ys[i % k] (cold-cache protocol, csr5hip.h)."""
+        k = len(handles)
+        hs = (C.c_void_p * k)(*[h._h.value for h in handles])
+        yp = (C.c_void_p * k)(*[_ptr(y) for y in ys])
+        return handles[0]._lib.csr5hip_spmv_rotate(hs, yp, k, 1.0, int(count))
+
     def autotuneSigma(self, y):
         """Measured sigma selection: returns (err, sigma, us_per_spmv); leaves the matrix in CSR5."""
         sigma, us = C.c_int(0), C.c_double(0.0)
@@ -120,6 +128,17 @@ class anonymouslibHandle:
     def setStreamNT(self, value: int) -> int:
         """0 off, 1 auto (non-temporal column/value loads when the streams exceed the Infinity Cache), 2 force"""
         return self.setOption(_capi.OPT_STREAM_NT, int(value))
+
+    def setColumnSlabs(self, value: int) -> int:
+        """0 off, 1 auto (default), 2..64 (power of two) = that many column slabs (kernel-side structure, csr5hip.h)"""
+        return self.setOption(_capi.OPT_COLUMN_SLABS, int(value))
+
+    def setSlabShift(self, value: int) -> int:
+        return self.setOption(_capi.OPT_SLAB_SHIFT, int(value))
+
+    def setZeroEmptyRows(self, value: int) -> int:
+        """1 = spmv() also stores 0 into rows without non-zeros (solver coupling); 0 = reference behaviour"""
+        return self.setOption(_capi.OPT_ZERO_EMPTY_ROWS, int(value))
 
     def info(self) -> _capi.Csr5Info:
         info = _capi.Csr5Info()

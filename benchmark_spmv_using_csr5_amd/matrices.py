@@ -311,3 +311,69 @@ def rmat_device(scale: int, edge_factor: int, seed: int, rank: int, world: int, 
     row_ptr[1:] = torch.cumsum(counts, 0)
     return DeviceCsr(n_local, n_local * world, int(ne), row_ptr.to(torch.int32), cols.contiguous(),
                      f"rmat{scale}(synthetic)")
+
+
+def rmat_device_shard(scale: int, edge_factor: int, seed: int, rank: int, world: int, device,
+                      abcd=(0.57, 0.19, 0.19, 0.05), chunk_log2: int = 24) -> DeviceCsr:
+    """Row block `rank` of ONE global 2^scale R-MAT cut into `world` nnz-balanced row blocks (strong scaling,
+    BASELINE config 3), generated PER SHARD: the edge list is produced in fixed seeded chunks (the same for every
+    world size, so N = 1 and N = 8 see the same matrix), pass 1 only histograms the rows to find the cuts
+    (sharding.partition_rows_by_nnz semantics), pass 2 regenerates the chunks and keeps the rows of this rank.
+    The full matrix is never materialised on a rank that owns 1/world of it."""
+    import torch
+
+    n = 1 << scale
+    ne = n * edge_factor
+    chunk = min(ne, 1 << chunk_log2)
+    nchunks = (ne + chunk - 1) // chunk
+    a, b, c, _ = abcd
+
+    def gen_chunk(ci: int):
+        cnt = min(chunk, ne - ci * chunk)
+        g = torch.Generator(device=device).manual_seed(seed * 1000003 + 7919 * ci)
+        rows = torch.zeros(cnt, dtype=torch.int32, device=device)
+        cols = torch.zeros(cnt, dtype=torch.int32, device=device)
+        for _lvl in range(scale):
+            r = torch.rand(cnt, generator=g, device=device)
+            rows = (rows << 1) | (r >= (a + b)).to(torch.int32)
+            cols = (cols << 1) | (((r >= a) & (r < a + b)) | (r >= a + b + c)).to(torch.int32)
+        return rows, cols
+
+    lo, hi = 0, n
+    if world > 1:
+        hist = torch.zeros(n, dtype=torch.int64, device=device)
+        for ci in range(nchunks):
+            rows, _ = gen_chunk(ci)
+            hist += torch.bincount(rows, minlength=n)
+        ptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+        ptr[1:] = torch.cumsum(hist, 0)
+        del hist
+        cuts = [0]
+        for gidx in range(1, world):
+            target = (gidx * ne) // world
+            r = int(torch.searchsorted(ptr, torch.tensor([target], device=device), right=True)[0]) - 1
+            cuts.append(min(max(r, cuts[-1]), n))
+        cuts.append(n)
+        lo, hi = cuts[rank], cuts[rank + 1]
+        del ptr
+    keep_r, keep_c = [], []
+    for ci in range(nchunks):
+        rows, cols = gen_chunk(ci)
+        if world > 1:
+            sel = (rows >= lo) & (rows < hi)
+            rows, cols = rows[sel] - lo, cols[sel]
+        keep_r.append(rows)
+        keep_c.append(cols)
+    rows = torch.cat(keep_r)
+    cols = torch.cat(keep_c)
+    del keep_r, keep_c
+    rows, order = torch.sort(rows, stable=True)  # file order inside a row is kept (the reference's counting sort)
+    cols = cols[order].contiguous()
+    del order
+    mloc = hi - lo
+    counts = torch.bincount(rows, minlength=mloc)
+    del rows
+    row_ptr = torch.zeros(mloc + 1, dtype=torch.int64, device=device)
+    row_ptr[1:] = torch.cumsum(counts, 0)
+    name = f"rmat{scale}(synthetic)" if world == 1 else f"rmat{scale}(synthetic) rows {lo}:{hi} of {world} nnz-balanced blocks"
+    return DeviceCsr(mloc, n, int(cols.numel()), row_ptr.to(torch.int32), cols, name)

