@@ -354,44 +354,24 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
 // ---- tiles 0..p-2 ------------------------------------------------------------------------------
 // SIGMA > 0: compile-time sigma (loads hoisted into registers, flag walk fully unrolled).
 // SIGMA == 0: run-time sigma (any 1..32), same code shape, used for sigma < 4 and as a cross-check.
-template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false>
-__global__ void __launch_bounds__(BLOCK)
-k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-       const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
-       const uint32_t *__restrict__ tile_desc, const int32_t *__restrict__ offset_ptr,
-       const int32_t *__restrict__ offset, VT *__restrict__ calibrator, VT *__restrict__ y,
-       int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta,
-       const uint32_t *__restrict__ hdr)
+// One tile, one wavefront.  `wave_lds` = this wavefront's private LDS region (x-window / y segments).
+// HOT (column-slab child only, csr5_slab.hip): column words with bit 31 set index the workgroup's LDS table of hot
+// x entries (`hot`) instead of x itself.
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT, bool HOT>
+__device__ __forceinline__ void
+tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restrict__ col, const VT *__restrict__ val,
+          const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc,
+          const int32_t *__restrict__ offset_ptr, const int32_t *__restrict__ offset, VT *__restrict__ calibrator,
+          VT *__restrict__ y, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta, const uint32_t *__restrict__ hdr,
+          char *wave_lds, const VT *hot)
 {
-    // Pull EVERY kernel argument into SGPRs with the first batch of scalar loads: an argument that is
-    // first touched further down would otherwise cost its own kernarg round trip on the critical path.
-    asm volatile("" ::"s"(row_ptr), "s"(col), "s"(val), "s"(x), "s"(tile_ptr), "s"(tile_desc),
-                 "s"(offset_ptr), "s"(offset), "s"(calibrator), "s"(y), "s"(acc), "s"(cnt), "s"(meta), "s"(hdr),
-                 "s"(g.nnz), "s"(g.p), "s"(g.m), "s"(g.sigma), "s"(g.tail_start), "s"(g.tile_elems),
-                 "s"(g.bit_y), "s"(g.num_packet), "s"(tile_blocks), "s"(xcd_remap));
-    // dynamic LDS: the tail's product buffer (T elements) or, XWIN, one x-window per wavefront
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int blk = blockIdx.x;
-    if (blk >= tile_blocks) {
-#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 4)
-        return;
-#endif
-        tail_rows<VT, SIGMA, FUSED>(g, row_ptr, col, val, x, calibrator, y, blk - tile_blocks, acc, cnt,
-                             meta, tile_ptr, reinterpret_cast<VT *>(smem));
-        return;
-    }
-    if (xcd_remap) {
-        // workgroup b runs on XCD b % 8 (observed dispatch order; used for L2 locality only):
-        // give every XCD one contiguous range of tiles instead of every 8th workgroup.
-        const int q = tile_blocks / NUM_XCD, rem = tile_blocks % NUM_XCD;
-        const int xcd = blk % NUM_XCD;
-        blk = xcd * q + (xcd < rem ? xcd : rem) + blk / NUM_XCD;
-    }
-    const int lane = threadIdx.x & (OMEGA - 1);
-    const int t = __builtin_amdgcn_readfirstlane(blk * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6));
-    if (t >= g.p - 1)
-        return;
-
+    // one x gather: from the LDS hot table when the column word carries bit 31 (HOT), else from memory
+    auto gather = [&](int32_t cw) -> VT {
+        if constexpr (HOT)
+            return cw < 0 ? hot[cw & 0x7FFFFFFF] : x[(uint32_t)cw];
+        else
+            return x[(uint32_t)cw];
+    };
     CSR5_TSTAMP(t, 0);
     const int sigma = SIGMA > 0 ? SIGMA : g.sigma;
     const int bit_y = SIGMA > 0 ? bit_y_of(SIGMA > 0 ? SIGMA : 1) : g.bit_y;
