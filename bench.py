@@ -89,6 +89,7 @@ def parse_args():
     ap.add_argument("--stream-nt", default="auto", choices=["auto", "off", "force"])
     ap.add_argument("--slabs", default="auto", help="column slabs: auto (default), 0 = off, 2..64 = that many")
     ap.add_argument("--slab-shift", type=int, default=None)
+    ap.add_argument("--slab-hot", default="auto", choices=["auto", "off", "force"], help="LDS hot table of the slab kernel")
     ap.add_argument("--scaling", default=None, choices=[None, "weak", "strong"],
                     help="N > 1: strong (default for R-MAT) = ONE global matrix cut into nnz-balanced row blocks; "
                          "weak = one fixed-size row block per GPU")
@@ -184,6 +185,7 @@ class Problem:
         _ck(A.setColumnSlabs(1 if args.slabs == "auto" else int(args.slabs)), "setColumnSlabs")
         if args.slab_shift is not None:
             _ck(A.setSlabShift(args.slab_shift), "setSlabShift")
+        _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
         A.warmup()
         torch.cuda.synchronize()
         if tuned:  # setup, outside every timed region (like asCSR5)
@@ -268,7 +270,8 @@ def roofline_dict(prob, ev_ms_per_step, wall_ms_per_step, extra=None):
         "clock": "HIP events on the launch stream around the K timed steps (frac_wall: the same from the wall clock)",
         "frac_wall": round(prob.b_alg / (wall_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "traffic": None,
-        "kernel": "csr5::k_spmv" + (" + csr5::k_slab_combine (both inside the step time)" if info.column_slabs else ""),
+        "kernel": ("csr5::k_spmv_hot" if info.slab_hot else "csr5::k_spmv") +
+                  (" + csr5::k_slab_combine (both inside the step time)" if info.column_slabs else ""),
         "algorithmic_bytes_per_launch": prob.b_alg,
         # diagnostic: bytes the CSR5 kernel actually streams = B_alg with row_ptr replaced by
         # tile_ptr + tile_desc (x and y still counted once)
@@ -291,6 +294,7 @@ def config_dict(prob, args, ingest_ms=None):
         "lds_x_window": bool(info.x_window_active), "x_window_cover_pct": info.x_window_cover_pct,
         "column_slabs": info.column_slabs, "slab_shift": info.slab_shift, "slab_segments": info.slab_segments,
         "slab_sigma": info.slab_sigma, "slab_build_ms": round(info.t_slab_ms, 3),
+        "slab_hot_table": bool(info.slab_hot), "slab_hot_cover_pct": info.slab_hot_cover_pct,
         "values": "rand()%10 integers (reference CLI data, exact in fp)" if args.values == "int" else "uniform(-1,1)",
         "ingest_ms": ingest_ms,
         "csr_to_csr5_ms": round(prob.convert_ms, 3),
@@ -309,7 +313,7 @@ def sub_config(name, args, dev):
     """One of the other BASELINE GPU configs on this GPU: warm and cold figures (N = 1 only)."""
     import copy
     a = copy.copy(args)
-    a.sigma, a.slabs, a.slab_shift, a.values = "-1", "auto", None, "int"
+    a.sigma, a.slabs, a.slab_shift, a.values, a.slab_hot = "-1", "auto", None, "int", "auto"
     dtype_name = "f32" if name == "nd24k" else "f64"
     np_dtype = np.float32 if dtype_name == "f32" else np.float64
     mat, label = make_shard(name, 0, 1, args.seed, np_dtype, dev, 1.0, False, None)
@@ -442,7 +446,8 @@ def main():
         info = prob.info
         roof = roofline_dict(prob, ev_per_step, ms_per_step)
         if world == 1:
-            key = f"{label}|{dtype_name}|sigma={info.sigma}|{args.mode}|slabs={info.column_slabs}/{info.slab_shift}"
+            key = (f"{label}|{dtype_name}|sigma={info.sigma}|{args.mode}|slabs={info.column_slabs}/{info.slab_shift}"
+                   f"/hot={info.slab_hot}")
             roof["traffic"], roof["traffic_source"] = profiled_traffic(key)
         else:
             roof["per_gpu_note"] = ("achieved/frac: rank 0's shard bytes (incl. the whole x it reads) over the "

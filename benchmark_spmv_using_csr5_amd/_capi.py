@@ -35,6 +35,7 @@ OPT_STREAM_NT = 5
 OPT_COLUMN_SLABS = 6
 OPT_SLAB_SHIFT = 7
 OPT_ZERO_EMPTY_ROWS = 8
+OPT_SLAB_HOT = 9
 
 
 class Csr5Info(C.Structure):
@@ -51,6 +52,7 @@ class Csr5Info(C.Structure):
         ("t_tile_desc_ms", C.c_double), ("t_transpose_ms", C.c_double),
         ("column_slabs", C.c_int), ("slab_shift", C.c_int), ("slab_segments", C.c_int),
         ("slab_sigma", C.c_int), ("slab_tiles", C.c_int), ("t_slab_ms", C.c_double),
+        ("slab_hot", C.c_int), ("slab_hot_cover_pct", C.c_int),
     ]
 
 

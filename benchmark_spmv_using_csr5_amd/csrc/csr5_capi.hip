@@ -121,6 +121,11 @@ struct csr5hip_handle_s {
     double t_slab = 0;
     csr5hip_handle_s *slab_child = nullptr;
     Buffer b_row_ptr2, b_col2, b_val2, b_P, b_mask, b_base;
+    // LDS hot table of the slab child (k_spmv_hot): chosen at conversion, see csr5_slab.hip
+    int hot_request = 1;      // CSR5HIP_OPT_SLAB_HOT: 0 off, 1 auto, 2 force
+    bool hot_enabled = false; // (child) column words are hot-encoded: spmv must use the persistent hot kernel
+    int hot_cover_pct = 0;    // (parent) share of the non-zeros whose column got a table slot
+    Buffer b_hot_cols, b_hot_count, b_hot_tile0, b_slab_off;
 
     // csr5hip_spmv_rotate: one graph over several handles (cold-cache measurement protocol)
     hipGraphExec_t rotate_exec = nullptr;
@@ -352,6 +357,15 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
             return build_slabs(h);
         }
         break;
+    case CSR5HIP_OPT_SLAB_HOT:
+        if (value < 0 || value > 2)
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->hot_request = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5) {
+            h->drop_graphs();
+            return build_slabs(h);
+        }
+        break;
     case CSR5HIP_OPT_ZERO_EMPTY_ROWS:
         h->zero_empty = value ? 1 : 0;
         break;
@@ -487,6 +501,7 @@ static void resolve_variants(csr5hip_handle h)
     h->opt.x_window = xwin_decision(h);
     h->opt.lds_y = ldsy_decision(h);
     h->opt.stream_nt = nt_decision(h);
+    h->opt.hot = h->hot_enabled ? 1 : 0;
 }
 
 int csr5hip_as_csr5(csr5hip_handle h)
@@ -561,10 +576,12 @@ static void release_slabs(csr5hip_handle h)
         csr5hip_free(h->slab_child);
         h->slab_child = nullptr;
     }
-    for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_mask, &h->b_base})
+    for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_mask, &h->b_base, &h->b_hot_cols,
+                      &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off})
         b->release();
     h->slab_S = 0;
     h->slab_m2 = 0;
+    h->hot_cover_pct = 0;
 }
 
 // Number of slabs spmv() should use (0 = none).  Auto rule (measured on MI355X, scripts/experiments/slab_*):
@@ -637,7 +654,61 @@ static int build_slabs(csr5hip_handle h)
                         (uint32_t *)h->b_mask.ptr, (uint32_t *)h->b_base.ptr, s));
     HIP_TRY(h->b_P.reserve(((size_t)m2 + 1) * h->vsize()));
     HIP_TRY(hipMemsetAsync(h->b_P.ptr, 0, ((size_t)m2 + 1) * h->vsize(), s));
-    HIP_TRY(hipStreamSynchronize(s)); // the temporaries are released when `t` goes out of scope
+    HIP_TRY(hipStreamSynchronize(s));
+
+    // LDS hot table for the persistent kernel (fused mode, S a multiple of the 8 XCDs, register budget of 16 waves/CU)
+    bool hot = false;
+    int hot_capacity = 0;
+    if (h->hot_request != 0 && S % NUM_XCD == 0 && h->opt.mode == 1 && g.sigma >= 4 &&
+        g.sigma <= (h->value_type == CSR5HIP_F64 ? 20 : 32) && (long long)g.n * (long long)h->vsize() <= 0x7FFFFFFFLL) {
+        int dev = 0, lds_max = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+        int lds = HOT_LDS_BYTES < lds_max ? HOT_LDS_BYTES : lds_max;
+        hot_capacity = lds / (int)h->vsize();
+        const int min_count = 48; // a slot is staged by each of the ~32 workgroups of the slab's XCD in every SpMV
+        struct HotTemps {
+            void *cnt = nullptr, *hotmap = nullptr, *chist = nullptr, *thr = nullptr, *covered = nullptr;
+            ~HotTemps()
+            {
+                for (void *p : {cnt, hotmap, chist, thr, covered})
+                    if (p)
+                        (void)hipFree(p);
+            }
+        } ht;
+        const size_t nb = (size_t)(g.n > 0 ? g.n : 1) * 4, hb = (size_t)S * slab_hot_buckets() * 4;
+        HIP_TRY(hipMalloc(&ht.cnt, nb));
+        HIP_TRY(hipMalloc(&ht.hotmap, nb));
+        HIP_TRY(hipMalloc(&ht.chist, hb));
+        HIP_TRY(hipMalloc(&ht.thr, (size_t)S * 4));
+        HIP_TRY(hipMalloc(&ht.covered, 8));
+        HIP_TRY(h->b_hot_cols.reserve((size_t)S * hot_capacity * 4));
+        HIP_TRY(h->b_hot_count.reserve((size_t)S * 4));
+        HIP_TRY(h->b_hot_tile0.reserve(((size_t)S + 1) * 4));
+        HIP_TRY(h->b_slab_off.reserve(((size_t)S + 1) * 4));
+        HIP_TRY(hipMemsetAsync(ht.cnt, 0, nb, s));
+        HIP_TRY(hipMemsetAsync(ht.hotmap, 0xFF, nb, s));
+        HIP_TRY(hipMemsetAsync(ht.chist, 0, hb, s));
+        HIP_TRY(hipMemsetAsync(ht.covered, 0, 8, s));
+        HIP_TRY(hipMemsetAsync(h->b_hot_cols.ptr, 0, (size_t)S * hot_capacity * 4, s));
+        HIP_TRY(slab_hot_select(g.n, g.nnz, g.p, g.tile_elems, S, bits, h->slab_shift, hot_capacity, min_count,
+                                (const int32_t *)h->b_col2.ptr, (const uint32_t *)t.hist, (uint32_t *)ht.cnt,
+                                (int32_t *)ht.hotmap, (uint32_t *)ht.chist, (uint32_t *)ht.thr, (int32_t *)h->b_hot_cols.ptr,
+                                (int32_t *)h->b_hot_count.ptr, (int32_t *)h->b_hot_tile0.ptr, (int32_t *)h->b_slab_off.ptr,
+                                (unsigned long long *)ht.covered, s));
+        unsigned long long covered = 0;
+        HIP_TRY(hipMemcpyAsync(&covered, ht.covered, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        h->hot_cover_pct = (int)(covered * 100 / (unsigned long long)g.nnz);
+        // worth it when a good part of the gathers leaves the vector memory path (measured, scripts/gpu_hot.sh)
+        hot = h->hot_request == 2 || h->hot_cover_pct >= 25;
+        if (hot) {
+            HIP_TRY(slab_hot_encode(g.nnz, g.tile_elems, g.p, S, (const int32_t *)h->b_slab_off.ptr,
+                                    (const int32_t *)h->b_hot_tile0.ptr, (const int32_t *)ht.hotmap, (int32_t *)h->b_col2.ptr, s));
+            HIP_TRY(hipStreamSynchronize(s));
+        }
+    }
+    // (the temporaries are released when `t` goes out of scope)
 
     // the stacked matrix: an ordinary CSR matrix with m2 rows, converted and multiplied by the ordinary kernels
     csr5hip_handle c = new csr5hip_handle_s();
@@ -652,6 +723,12 @@ static int build_slabs(csr5hip_handle h)
     c->slab_request = 0;
     c->ldsy_request = h->ldsy_request;
     c->nt_request = h->nt_request;
+    c->hot_enabled = hot;
+    c->d.hot_cols = (const int32_t *)h->b_hot_cols.ptr;
+    c->d.hot_count = (const int32_t *)h->b_hot_count.ptr;
+    c->d.hot_tile0 = (const int32_t *)h->b_hot_tile0.ptr;
+    c->d.hot_slabs = S;
+    c->d.hot_capacity = hot_capacity;
     int rc = csr5hip_input_csr(c, g.nnz, (int32_t *)h->b_row_ptr2.ptr, (int32_t *)h->b_col2.ptr, h->b_val2.ptr);
     c->sigma_request = g.sigma;
     if (rc == CSR5HIP_SUCCESS)
@@ -1128,6 +1205,8 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_sigma = h->slab_child ? h->slab_child->g.sigma : 0;
     info->slab_tiles = h->slab_child ? h->slab_child->g.p : 0;
     info->t_slab_ms = h->t_slab;
+    info->slab_hot = h->slab_child && h->slab_child->hot_enabled ? 1 : 0;
+    info->slab_hot_cover_pct = h->hot_cover_pct;
     return CSR5HIP_SUCCESS;
 }
 

@@ -67,6 +67,11 @@ struct DeviceArrays {
     uint32_t *carry_meta;   // [p] x uint4 per tile: see k_carry_meta in csr5_format.hip
     uint32_t *tile_hdr;     // [8p] fused kernel: carry_meta[t], carry_meta[t+1].x and the tile_ptr pair in ONE 32-B record
     uint32_t *counters;     // [4] conversion statistics: x-window tiles, covered non-zeros, long runs
+    // column-slab child with an LDS hot table (csr5_slab.hip / k_spmv_hot): column words with bit 31 set index the table
+    const int32_t *hot_cols;   // [hot_slabs * hot_capacity]
+    const int32_t *hot_count;  // [hot_slabs]
+    const int32_t *hot_tile0;  // [hot_slabs + 1]
+    int hot_slabs, hot_capacity;
 };
 
 // ---- conversion (csr5_format.hip) ----
@@ -96,6 +101,13 @@ hipError_t slab_segments(int nnz, const unsigned long long *key2, void *tmp, siz
                          unsigned int *d_count, hipStream_t s);
 hipError_t slab_tables(int m2, int nnz, int S, int32_t *row_ptr2, const unsigned long long *key2, uint32_t *mask,
                        uint32_t *base, hipStream_t s);
+hipError_t slab_hot_select(int n, int nnz, int p, int T, int S, int bits, int shift, int capacity, int min_count,
+                           const int32_t *col2, const uint32_t *chunk_start, uint32_t *cnt, int32_t *hotmap,
+                           uint32_t *chist, uint32_t *thr, int32_t *hot_cols, int32_t *hot_count, int32_t *tile0,
+                           int32_t *slab_off, unsigned long long *covered, hipStream_t s);
+hipError_t slab_hot_encode(int nnz, int T, int p, int S, const int32_t *slab_off, const int32_t *tile0,
+                           const int32_t *hotmap, int32_t *col2, hipStream_t s);
+int slab_hot_buckets();
 hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int value_type, const uint32_t *mask,
                                const uint32_t *base, const void *P, void *y, hipStream_t s);
 
@@ -107,7 +119,9 @@ struct SpmvOptions {
     int lds_y;       // resolved: 1 = compact y segments through LDS before storing them
     int stream_nt;   // resolved: 1 = column/value streams use non-temporal loads
     int long_runs;   // resolved: the matrix has rows spanning > RUN_SERIAL_MAX tiles (fused mode adds k_calibrate)
+    int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_hot + tail launch
 };
+constexpr int HOT_LDS_BYTES = 128 * 1024;  // LDS table of hot x entries per workgroup (k_spmv_hot)
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s);
 

@@ -259,6 +259,125 @@ k_slab_combine(int m, int tail_start, int zero_empty, const uint32_t *__restrict
         y[r] = 0;
 }
 
+// ---- hot columns of every slab (LDS table of the persistent kernel k_spmv_hot, csr5_spmv.hip) ---------------------
+// Power-law inputs concentrate their non-zeros on few columns: the HOT_CAPACITY most used columns of a slab (those
+// used at least `min_count` times -- a table entry is staged once per workgroup and SpMV, so a rarely used column
+// would cost more than it saves) get a slot in the slab's table and their column words are rewritten to
+// 0x80000000 | slot in the child's column_index.  Selection: per-slab histogram of the column use counts, threshold =
+// the smallest count whose columns all fit, the remaining room goes to columns of the next lower count.
+constexpr int HOT_BUCKETS = 2048;
+
+__global__ void __launch_bounds__(SLAB_BLOCK)
+k_col_count(int nnz, const int32_t *__restrict__ col, uint32_t *__restrict__ cnt)
+{
+    for (size_t i = (size_t)blockIdx.x * SLAB_BLOCK + threadIdx.x; i < (size_t)nnz; i += (size_t)gridDim.x * SLAB_BLOCK)
+        atomicAdd(&cnt[(uint32_t)col[i]], 1u);
+}
+
+__global__ void __launch_bounds__(SLAB_BLOCK)
+k_hot_hist(int n, const uint32_t *__restrict__ cnt, int bits, int shift, uint32_t *__restrict__ chist)
+{
+    const int c = blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    if (c >= n)
+        return;
+    const uint32_t v = cnt[c];
+    if (v)
+        atomicAdd(&chist[(size_t)slab_of((uint32_t)c, shift, bits) * HOT_BUCKETS + (v < HOT_BUCKETS - 1 ? v : HOT_BUCKETS - 1)], 1u);
+}
+
+// one workgroup per slab: thr[k] = smallest bucket b >= min_count such that the columns with count >= b fit
+__global__ void __launch_bounds__(64)
+k_hot_threshold(int capacity, int min_count, const uint32_t *__restrict__ chist, uint32_t *__restrict__ thr)
+{
+    if (threadIdx.x != 0)
+        return;
+    const uint32_t *h = chist + (size_t)blockIdx.x * HOT_BUCKETS;
+    uint32_t total = 0;
+    int b = HOT_BUCKETS;
+    while (b - 1 >= min_count && total + h[b - 1] <= (uint32_t)(capacity - 1)) { // slot 0 is reserved
+        b--;
+        total += h[b];
+    }
+    thr[blockIdx.x] = (uint32_t)b;
+}
+
+// pass 0: every column with count >= thr gets a slot; pass 1: columns of the next lower count fill what is left
+__global__ void __launch_bounds__(SLAB_BLOCK)
+k_hot_assign(int n, const uint32_t *__restrict__ cnt, int bits, int shift, const uint32_t *__restrict__ thr,
+             int capacity, int min_count, int pass, int32_t *__restrict__ hot_count, int32_t *__restrict__ hot_cols,
+             int32_t *__restrict__ hotmap, unsigned long long *__restrict__ covered)
+{
+    const int c = blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    if (c >= n)
+        return;
+    const uint32_t v = cnt[c];
+    if (!v)
+        return;
+    const uint32_t k = slab_of((uint32_t)c, shift, bits);
+    const uint32_t bucket = v < HOT_BUCKETS - 1 ? v : HOT_BUCKETS - 1;
+    const uint32_t b = thr[k];
+    const bool take = pass == 0 ? bucket >= b : (bucket + 1 == b && (int)bucket >= min_count);
+    if (!take)
+        return;
+    const int slot = atomicAdd(&hot_count[k], 1);
+    if (slot < capacity) {
+        hot_cols[(size_t)k * capacity + slot] = c;
+        hotmap[c] = slot;
+        atomicAdd(covered, (unsigned long long)v);
+    }
+}
+
+// clamp the slot counts; first tile OWNED by every slab (a tile belongs to the slab of its first element)
+__global__ void __launch_bounds__(SLAB_MAX + 1)
+k_hot_finish(int S, int p, int T, int nnz, int capacity, const uint32_t *__restrict__ chunk_start,
+             int32_t *__restrict__ hot_count, int32_t *__restrict__ tile0, int32_t *__restrict__ slab_off)
+{
+    const int k = threadIdx.x;
+    if (k > S)
+        return;
+    const long long off = k < S ? (long long)chunk_start[(size_t)k * p] : (long long)nnz;
+    slab_off[k] = (int32_t)off;
+    long long t = (off + T - 1) / T;
+    tile0[k] = (int32_t)(t < p - 1 ? t : p - 1);
+    if (k < S && hot_count[k] > capacity)
+        hot_count[k] = capacity;
+}
+
+__global__ void __launch_bounds__(SLAB_BLOCK)
+k_hot_encode(int nnz, int T, int p, int S, const int32_t *__restrict__ slab_off, const int32_t *__restrict__ tile0,
+             const int32_t *__restrict__ hotmap, int32_t *__restrict__ col2)
+{
+    __shared__ int32_t soff[SLAB_MAX + 1];
+    if ((int)threadIdx.x <= S)
+        soff[threadIdx.x] = slab_off[threadIdx.x];
+    __syncthreads();
+    const size_t pos = (size_t)blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    if (pos >= (size_t)nnz)
+        return;
+    const int t = (int)(pos / T);
+    if (t >= p - 1)
+        return; // the CSR tail is processed by the ordinary kernel: plain column words
+    auto slab_at = [&](long long q) { // largest k with slab_off[k] <= q
+        int lo = 0, hi = S;
+        while (lo + 1 < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((long long)soff[mid] <= q)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        return lo;
+    };
+    const int mine = slab_at((long long)pos);
+    if (slab_at((long long)t * T) != mine)
+        return; // element of the NEXT slab inside a tile owned by the previous one: that tile holds another table
+    if (t == tile0[mine] && pos - (size_t)t * T < (size_t)OMEGA)
+        return; // the previous slab's last tile may read these as its short spill
+    const int h = hotmap[(uint32_t)col2[pos]];
+    if (h >= 0)
+        col2[pos] = (int32_t)(0x80000000u | (uint32_t)h);
+}
+
 // ---- host side -----------------------------------------------------------------------------------------
 size_t slab_scatter_lds(const Geometry &g, int S, size_t vsize)
 {
@@ -355,5 +474,45 @@ hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int
     return value_type == CSR5HIP_F64 ? combine_typed<double>(m, tail_start, zero_empty, S, mask, base, P, y, s)
                                      : combine_typed<float>(m, tail_start, zero_empty, S, mask, base, P, y, s);
 }
+
+} // namespace csr5
+
+namespace csr5 {
+
+// Selects the hot columns of every slab and fills hot_cols / hot_count / tile0 / slab_off; *covered = non-zeros whose
+// column got a slot.  cnt, hotmap, chist, thr: caller-provided scratch (n, n, S*HOT_BUCKETS, S words; cnt and chist
+// zeroed, hotmap set to -1).
+hipError_t slab_hot_select(int n, int nnz, int p, int T, int S, int bits, int shift, int capacity, int min_count,
+                           const int32_t *col2, const uint32_t *chunk_start, uint32_t *cnt, int32_t *hotmap,
+                           uint32_t *chist, uint32_t *thr, int32_t *hot_cols, int32_t *hot_count, int32_t *tile0,
+                           int32_t *slab_off, unsigned long long *covered, hipStream_t s)
+{
+    long long blocks = ((long long)nnz + SLAB_BLOCK * 8 - 1) / (SLAB_BLOCK * 8);
+    blocks = blocks < 1 ? 1 : (blocks > 65536 ? 65536 : blocks);
+    // slot 0 of every table is reserved (it holds +0.0, see k_spmv_hot): slots are handed out from 1
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)hot_count, 1, (size_t)S, s);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(k_col_count, dim3((unsigned)blocks), dim3(SLAB_BLOCK), 0, s, nnz, col2, cnt);
+    const dim3 cols_grid((n + SLAB_BLOCK - 1) / SLAB_BLOCK);
+    hipLaunchKernelGGL(k_hot_hist, cols_grid, dim3(SLAB_BLOCK), 0, s, n, cnt, bits, shift, chist);
+    hipLaunchKernelGGL(k_hot_threshold, dim3(S), dim3(64), 0, s, capacity, min_count, chist, thr);
+    for (int pass = 0; pass < 2; pass++)
+        hipLaunchKernelGGL(k_hot_assign, cols_grid, dim3(SLAB_BLOCK), 0, s, n, cnt, bits, shift, thr, capacity, min_count,
+                           pass, hot_count, hot_cols, hotmap, covered);
+    hipLaunchKernelGGL(k_hot_finish, dim3(1), dim3(SLAB_MAX + 1), 0, s, S, p, T, nnz, capacity, chunk_start, hot_count,
+                       tile0, slab_off);
+    return hipGetLastError();
+}
+
+hipError_t slab_hot_encode(int nnz, int T, int p, int S, const int32_t *slab_off, const int32_t *tile0,
+                           const int32_t *hotmap, int32_t *col2, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_hot_encode, dim3((unsigned)(((size_t)nnz + SLAB_BLOCK - 1) / SLAB_BLOCK)), dim3(SLAB_BLOCK), 0, s,
+                       nnz, T, p, S, slab_off, tile0, hotmap, col2);
+    return hipGetLastError();
+}
+
+int slab_hot_buckets() { return HOT_BUCKETS; }
 
 } // namespace csr5

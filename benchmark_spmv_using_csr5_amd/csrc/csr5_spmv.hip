@@ -363,7 +363,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
           const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc,
           const int32_t *__restrict__ offset_ptr, const int32_t *__restrict__ offset, VT *__restrict__ calibrator,
           VT *__restrict__ y, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta, const uint32_t *__restrict__ hdr,
-          char *wave_lds, const VT *hot)
+          char *wave_lds, const __attribute__((address_space(3))) VT *hot)
 {
     // one x gather: from the LDS hot table when the column word carries bit 31 (HOT), else from memory
     auto gather = [&](int32_t cw) -> VT {
@@ -478,7 +478,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             // gather from LDS (a ds_read costs a few cycles; a divergent global gather >= 34 clk per
             // wave instruction even on L1 hits); the others gather from memory as before and are
             // issued FIRST, so they overlap the window fetch.
-            VT *win = reinterpret_cast<VT *>(smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>());
+            VT *win = reinterpret_cast<VT *>(wave_lds);
             const int wlo = (int)__builtin_amdgcn_readfirstlane(mt.w) - 1;
             if (wlo >= 0) {
                 // stage the window: 16 coalesced wave loads -> 16 LDS stores (private to this wave)
@@ -499,21 +499,47 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
                 for (int i = 0; i < SIGMA; i++)
                     xv[i] = x[(uint32_t)c[i]];
             }
-        } else {
+        } else if constexpr (!HOT) {
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
 #if defined(CSR5_ABLATE) && (CSR5_ABLATE & 1)
                 xv[i] = (VT)c[i]; // experiment build only: no x gather
 #else
-                xv[i] = x[(uint32_t)c[i]];
+                xv[i] = gather(c[i]);
 #endif
+        }
+        if constexpr (HOT) {
+            // Branch-free hot/cold gather.  Cold lanes (plain column word) read x through a raw buffer load; hot lanes
+            // (bit 31 set) get the byte offset 0xFFFFFFFF there, which the buffer's range check turns into "return 0,
+            // touch no memory".  Every lane then reads the LDS table: hot lanes their slot, cold lanes slot 0, which
+            // always holds +0.0 (reserved at conversion).  One of the two words is therefore all-zero bits and a
+            // bitwise OR merges them exactly (no select, no control flow: exec-masked branches per element made the
+            // compiler drain the vector memory counter in front of every table read).
+            const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(x), (short)0, g.n * (int)sizeof(VT), 0x00020000);
+            using word_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
+            word_t xg[SIGMA];
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++) {
+                const unsigned off = c[i] < 0 ? 0xFFFFFFFFu : (unsigned)c[i] * (unsigned)sizeof(VT);
+                if constexpr (sizeof(VT) == 8)
+                    xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
+                else
+                    xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b32(xbuf, off, 0, 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++) {
+                const unsigned slot = c[i] < 0 ? (unsigned)c[i] & 0x7FFFFFFFu : 0u;
+                const word_t xl = __builtin_bit_cast(word_t, hot[slot]);
+                xv[i] = __builtin_bit_cast(VT, (word_t)(xg[i] | xl));
+            }
         }
         if constexpr (FUSED) {
             // the closing row of this tile spills mt.z <= 64 elements into tile t+1 and ends there:
             // gather x for exactly those lanes; the other lanes re-read x[0] (one cache line), so the
             // gather is unconditional and rides in the same round trip as the tile's own gathers
             const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
-            const VT sx = x[lane < L ? (uint32_t)spill_c : 0u];
+            const VT sx = gather(lane < L ? spill_c : 0);
             lead_next = lane < L ? spill_v * sx : (VT)0;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -534,21 +560,21 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         tp0 = __builtin_amdgcn_readlane(hw, 5);
         tp1 = __builtin_amdgcn_readlane(hw, 6);
         const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
-        const VT sx = x[lane < L ? spill_c : 0];
+        const VT sx = gather(lane < L ? spill_c : 0);
         lead_next = lane < L ? spill_v * sx : (VT)0;
     }
     auto product = [&](int i) -> VT {
         if constexpr (SIGMA > 0)
             return mv[i] * mx[i];
         else
-            return vt[i * OMEGA] * x[ct[i * OMEGA]];
+            return vt[i * OMEGA] * gather(ct[i * OMEGA]);
     };
     // acc + element i as ONE fused multiply-add
     auto accumulate = [&](int i, VT acc) -> VT {
         if constexpr (SIGMA > 0)
             return __builtin_fma(mv[i], mx[i], acc);
         else
-            return __builtin_fma(vt[i * OMEGA], x[ct[i * OMEGA]], acc);
+            return __builtin_fma(vt[i * OMEGA], gather(ct[i * OMEGA]), acc);
     };
 
     // Decode the descriptor and reduce the spill HERE, in the entry block, before any data-dependent
@@ -594,7 +620,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
 
     CSR5_TSTAMP(t, 4);
     constexpr bool LDSY = use_ldsy<VT, SIGMA, LDSY_REQ>();
-    VT *seg = reinterpret_cast<VT *>(smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>());
+    VT *seg = reinterpret_cast<VT *>(wave_lds);
     // store of the segment that owns slot `idx` of this tile's row range
     auto put = [&](int idx, VT v) {
         if constexpr (LDSY)
@@ -722,6 +748,97 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     CSR5_TSTAMP(t, 7);
 }
 
+// One tile per wavefront, WAVES_PER_BLOCK tiles per workgroup; the CSR tail = extra workgroups of the same grid.
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false>
+__global__ void __launch_bounds__(BLOCK)
+k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+       const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
+       const uint32_t *__restrict__ tile_desc, const int32_t *__restrict__ offset_ptr,
+       const int32_t *__restrict__ offset, VT *__restrict__ calibrator, VT *__restrict__ y,
+       int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta,
+       const uint32_t *__restrict__ hdr)
+{
+    // Pull EVERY kernel argument into SGPRs with the first batch of scalar loads: an argument that is
+    // first touched further down would otherwise cost its own kernarg round trip on the critical path.
+    asm volatile("" ::"s"(row_ptr), "s"(col), "s"(val), "s"(x), "s"(tile_ptr), "s"(tile_desc),
+                 "s"(offset_ptr), "s"(offset), "s"(calibrator), "s"(y), "s"(acc), "s"(cnt), "s"(meta), "s"(hdr),
+                 "s"(g.nnz), "s"(g.p), "s"(g.m), "s"(g.sigma), "s"(g.tail_start), "s"(g.tile_elems),
+                 "s"(g.bit_y), "s"(g.num_packet), "s"(tile_blocks), "s"(xcd_remap));
+    // dynamic LDS: the tail's product buffer (T elements) or one x-window / y-segment region per wavefront
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int blk = blockIdx.x;
+    if (blk >= tile_blocks) {
+#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 4)
+        return;
+#endif
+        tail_rows<VT, SIGMA, FUSED>(g, row_ptr, col, val, x, calibrator, y, blk - tile_blocks, acc, cnt,
+                             meta, tile_ptr, reinterpret_cast<VT *>(smem));
+        return;
+    }
+    if (xcd_remap) {
+        // workgroup b runs on XCD b % 8 (observed dispatch order; used for L2 locality only):
+        // give every XCD one contiguous range of tiles instead of every 8th workgroup.
+        const int q = tile_blocks / NUM_XCD, rem = tile_blocks % NUM_XCD;
+        const int xcd = blk % NUM_XCD;
+        blk = xcd * q + (xcd < rem ? xcd : rem) + blk / NUM_XCD;
+    }
+    const int lane = threadIdx.x & (OMEGA - 1);
+    const int t = __builtin_amdgcn_readfirstlane(blk * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6));
+    if (t >= g.p - 1)
+        return;
+    tile_body<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, false>(
+        g, t, lane, col, val, x, tile_ptr, tile_desc, offset_ptr, offset, calibrator, y, acc, cnt, meta, hdr,
+        smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>(), nullptr);
+}
+
+// ---- persistent hot-set kernel (column-slab child, csr5_slab.hip) --------------------------------------------------
+// One 1024-thread workgroup per CU stays resident for the whole SpMV.  XCD x (= workgroup index % 8, observed
+// placement, used for locality only) walks its `rounds` slabs in order; for every slab the workgroup first stages the
+// slab's hot x entries -- the columns that carry most of the slab's non-zeros, chosen at conversion -- into a
+// 128-KB LDS table, then its 16 wavefronts take the slab's tiles round robin (tiles have equal work by construction,
+// so a static split balances).  Hot gathers become ds_read_b64 (a few cycles per wave instruction instead of a
+// 128-byte L2->L1 line per lane); only the cold remainder goes through the vector memory path.
+// Correct under ANY placement or scheduling: the table only depends on the slab, every tile is processed by exactly
+// one wavefront, and the carry protocol never waits.
+struct HotParams {
+    int slabs, rounds, capacity;     // S, S / 8, table capacity in elements
+    const int32_t *cols;             // [slabs * capacity] hot column of every table slot
+    const int32_t *count;            // [slabs] slots in use
+    const int32_t *tile0;            // [slabs + 1] first tile owned by each slab (tile0[S] = p - 1)
+};
+constexpr int HOT_BLOCK = 1024;
+
+template <typename VT, int SIGMA, bool NT>
+__global__ void __launch_bounds__(HOT_BLOCK)
+k_spmv_hot(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__ val, const VT *__restrict__ x,
+           const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc,
+           const int32_t *__restrict__ offset_ptr, const int32_t *__restrict__ offset, VT *__restrict__ calibrator,
+           VT *__restrict__ y, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta, const uint32_t *__restrict__ hdr,
+           HotParams hp)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // typed LDS pointer: keeps the table reads on ds_read (a generic pointer would merge the hot/cold select into one
+    // flat_load)
+    auto *hot = (__attribute__((address_space(3))) VT *)(smem);
+    const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, nwg = gridDim.x / NUM_XCD;
+    const int lane = threadIdx.x & (OMEGA - 1), wave = threadIdx.x >> 6;
+    constexpr int WAVES = HOT_BLOCK / OMEGA;
+    for (int r = 0; r < hp.rounds; r++) {
+        const int k = xcd * hp.rounds + r;
+        const int nhot = hp.count[k];
+        const int32_t *hc = hp.cols + (size_t)k * hp.capacity;
+        __syncthreads(); // every wavefront is done with the previous slab's table
+        for (int j = threadIdx.x; j < nhot; j += HOT_BLOCK)
+            hot[j] = j ? x[(uint32_t)hc[j]] : (VT)0; // slot 0 = +0.0: what the cold lanes read (tile_body)
+        __syncthreads();
+        const int t1 = hp.tile0[k + 1];
+        for (int t = hp.tile0[k] + wg * WAVES + wave; t < t1; t += nwg * WAVES)
+            tile_body<VT, SIGMA, true, false, false, NT, true>(g, __builtin_amdgcn_readfirstlane(t), lane, col, val, x,
+                                                               tile_ptr, tile_desc, offset_ptr, offset, calibrator, y,
+                                                               acc, cnt, meta, hdr, nullptr, hot);
+    }
+}
+
 // ---- carry resolution by a second launch ---------------------------------------------------------
 // One thread per run head (carry_meta[t].y == t).
 //   LONG_ONLY = false (two-pass mode): every run.  The first carry of a row that begins exactly on a tile
@@ -804,6 +921,46 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
     return hipGetLastError();
 }
 
+// hot child: persistent tile kernel, then the CSR tail (the ordinary kernel with zero tile workgroups), then -- only
+// for matrices with such rows -- the long-run calibrate
+template <typename VT, int SIGMA, bool NT>
+static hipError_t launch_hot(const Geometry &g, const DeviceArrays &d, const void *x, void *y, const SpmvOptions &opt,
+                             hipStream_t s)
+{
+    HotParams hp{d.hot_slabs, d.hot_slabs / NUM_XCD, d.hot_capacity, d.hot_cols, d.hot_count, d.hot_tile0};
+    const size_t lds = (size_t)d.hot_capacity * sizeof(VT);
+    auto kern = k_spmv_hot<VT, SIGMA, NT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess)
+        return e;
+    if (g.p > 1) {
+        hipLaunchKernelGGL(kern, dim3(NUM_XCD * 32), dim3(HOT_BLOCK), lds, s, g, d.col, (const VT *)d.val, (const VT *)x,
+                           d.tile_ptr, d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y,
+                           (VT *)d.carry_acc, d.carry_cnt, reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr, hp);
+        e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    const int tail_rows_n = g.m - g.tail_start;
+    const int tail_blocks = tail_rows_n > 0 ? (tail_rows_n + BLOCK - 1) / BLOCK : 0;
+    if (tail_blocks > 0) {
+        hipLaunchKernelGGL((k_spmv<VT, SIGMA, true, false, false, NT>), dim3(tail_blocks), dim3(BLOCK),
+                           (size_t)g.tile_elems * sizeof(VT), s, g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x,
+                           d.tile_ptr, d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, 0, 0,
+                           (VT *)d.carry_acc, d.carry_cnt, reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr);
+        e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    if (!opt.long_runs)
+        return hipSuccess;
+    hipLaunchKernelGGL((k_calibrate<VT, true>), dim3((g.p + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, g, d.tile_ptr,
+                       reinterpret_cast<const uint4 *>(d.carry_meta), (const VT *)d.calibrator, (const VT *)d.carry_acc,
+                       (VT *)y);
+    return hipGetLastError();
+}
+
 template <typename VT, bool FUSED>
 static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
                                const SpmvOptions &opt, hipStream_t s)
@@ -812,6 +969,9 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
 #define CSR5_CASE(S)                                                                               \
     case S:                                                                                        \
         if constexpr (FUSED) {                                                                     \
+            if (opt.hot)                                                                           \
+                return opt.stream_nt ? launch_hot<VT, S, true>(g, d, x, y, opt, s)                 \
+                                     : launch_hot<VT, S, false>(g, d, x, y, opt, s);               \
             if (opt.x_window)                                                                      \
                 return opt.lds_y ? launch_one<VT, S, FUSED, true, true>(g, d, x, y, opt, s)        \
                                  : launch_one<VT, S, FUSED, true, false>(g, d, x, y, opt, s);      \

@@ -136,6 +136,10 @@ class anonymouslibHandle:
     def setSlabShift(self, value: int) -> int:
         return self.setOption(_capi.OPT_SLAB_SHIFT, int(value))
 
+    def setSlabHot(self, value: int) -> int:
+        """column slabs: 0 = no LDS hot table, 1 = auto (default), 2 = force (csr5hip.h CSR5HIP_OPT_SLAB_HOT)"""
+        return self.setOption(_capi.OPT_SLAB_HOT, int(value))
+
     def setZeroEmptyRows(self, value: int) -> int:
         """1 = spmv() also stores 0 into rows without non-zeros (solver coupling); 0 = reference behaviour"""
         return self.setOption(_capi.OPT_ZERO_EMPTY_ROWS, int(value))

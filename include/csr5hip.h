@@ -73,6 +73,9 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       0 = off, 1 = auto (default), 2/4/8/16/32/64 = that many slabs */
 #define CSR5HIP_OPT_SLAB_SHIFT  7  /* log2 of the number of adjacent columns hashed to the same slab (default 4 =
                                       one 128-byte line of fp64 x) */
+#define CSR5HIP_OPT_SLAB_HOT    9  /* column slabs only: keep each slab's most used columns of x in a 128-KB LDS table of a
+                                      persistent kernel (power-law inputs put most non-zeros on few columns): 0 = off,
+                                      1 = auto (default: on when the table covers >= 25 % of the non-zeros), 2 = force */
 #define CSR5HIP_OPT_ZERO_EMPTY_ROWS 8 /* 1 = spmv() also stores 0 into rows without non-zeros (so y is fully defined
                                       without the caller zeroing it -- what a solver that feeds y back as x needs);
                                       0 = reference behaviour (default): empty rows before the tail are left untouched */
@@ -106,6 +109,8 @@ typedef struct csr5hip_info {
     int slab_segments;             /* number of (row, slab) segments = rows of the stacked matrix         */
     int slab_sigma, slab_tiles;    /* geometry of the stacked matrix' CSR5 form                           */
     double t_slab_ms;              /* time asCSR5 spent building the slab structure                       */
+    int slab_hot;                  /* 1 if the slab kernel gathers hot columns from an LDS table          */
+    int slab_hot_cover_pct;        /* share of the non-zeros whose column has a slot in its slab's table  */
 } csr5hip_info;
 
 /* anonymouslibHandle(m, n) -- anonymouslib_cuda.h:15.  Uses the current HIP device. */

@@ -29,7 +29,7 @@ def _device_csr(mat, val, dtype):
 
 
 def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None, nt=None,
-         slabs=None, slab_shift=None, zero_empty=None, info_out=None):
+         slabs=None, slab_shift=None, zero_empty=None, info_out=None, hot=None):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
@@ -51,13 +51,16 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         assert A.setSlabShift(slab_shift) == 0
     if zero_empty is not None:
         assert A.setZeroEmptyRows(zero_empty) == 0
+    if hot is not None:
+        assert A.setSlabHot(hot) == 0
     assert A.spmv(1.0, yd) == H.ANONYMOUSLIB_UNSUPPORTED_CSR_SPMV  # still CSR (anonymouslib_cuda.h:268-271)
     assert A.asCSR5() == 0, _capi.last_error()
     arrays = A.csr5_arrays()
     if info_out is not None:
         i = A.info()
         info_out.update(column_slabs=i.column_slabs, slab_segments=i.slab_segments, slab_sigma=i.slab_sigma,
-                        slab_tiles=i.slab_tiles, sigma=i.sigma)
+                        slab_tiles=i.slab_tiles, sigma=i.sigma, slab_hot=i.slab_hot,
+                        slab_hot_cover_pct=i.slab_hot_cover_pct)
     col_t = ci.cpu().numpy().copy()
     val_t = va.cpu().numpy().copy()
     ys = []

@@ -151,3 +151,83 @@ def test_slabs_rmat_device(scale):
         torch.cuda.synchronize()
         assert torch.equal(mat.col, col0)
         A.close()
+
+
+def _hub_columns_matrix(m, n, nnz_per_row, hubs, seed, share=0.8):
+    """Rows of `nnz_per_row` entries whose columns fall on `hubs` popular columns with probability `share`
+    (a crude power-law column profile: what the LDS hot table is for)."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 2 * nnz_per_row + 1, size=m)
+    mat = M.csr_from_row_lengths(lens, n, rng, band=0.0, name=f"hubcols{seed}")
+    hub_ids = rng.choice(n, size=hubs, replace=False)
+    pick = rng.random(mat.nnz) < share
+    mat.col = np.where(pick, hub_ids[rng.integers(0, hubs, size=mat.nnz)], mat.col).astype(np.int32)
+    return mat
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("slabs,shift,sigma", [(8, 4, 16), (16, 0, 6), (8, 2, 20), (32, 4, 4)])
+def test_slab_hot_table_bit_exact(oracle, slabs, shift, sigma, dtype):
+    """Persistent hot-table kernel (forced): exact on integer data, format arrays untouched, bit-reproducible, and the
+    untouched-row contract holds.  Matrices: popular hub columns (most gathers hit the table), a few zoo shapes with
+    long rows / empty rows / tiny sizes (tables nearly empty: everything goes the cold way)."""
+    mats = [_hub_columns_matrix(3000, 50000, 12, 300, 1), _hub_columns_matrix(20000, 8000, 5, 2000, 2, share=0.5)]
+    mats += [zoo.small_zoo()[i] for i in (1, 5, 6, 11, 14, 16)]
+    for mat in mats:
+        val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=5, mode="int")
+        if dtype == np.float32:
+            val, x = (val % 3).astype(np.float32), (x % 3).astype(np.float32)
+        fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+        info = {}
+        arrays, col_t, val_t, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=slabs, slab_shift=shift,
+                                        hot=2, repeat=2, info_out=info)
+        _check_format(arrays, col_t, val_t, fmt)
+        if fmt.p >= 2:
+            assert info["slab_hot"] == 1, info
+        exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+        for y in ys:
+            assert np.array_equal(y, exp), (mat.name, slabs, shift, sigma, np.flatnonzero(y != exp)[:8])
+    assert info is not None
+
+
+def test_slab_hot_real_data_and_auto(oracle):
+    """Real-valued data: the hot path only changes WHERE x is read from, so it must agree bit for bit with the plain
+    slab path (same association) and with the oracle to rounding; auto turns the table on for hub columns and leaves
+    it off when no column is popular."""
+    mat = _hub_columns_matrix(40000, 600000, 10, 500, 3)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=9, mode="real")
+    fmt = oracle.convert(64, 16, mat.m, mat.row_ptr, mat.col, val)
+    exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+    scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
+    info = {}
+    _, _, _, y_hot = _run(mat, val, x, 16, H.SPMV_FUSED, slabs=8, hot=1, info_out=info)
+    assert info["slab_hot"] == 1 and info["slab_hot_cover_pct"] >= 60, info
+    _, _, _, y_plain = _run(mat, val, x, 16, H.SPMV_FUSED, slabs=8, hot=0)
+    assert np.array_equal(y_hot[0], y_plain[0])
+    assert np.all(np.abs(y_hot[0] - exp) <= 1e-12 * np.maximum(scale, 1.0))
+    flat = M.webbase_like(scale=0.3)
+    val, x = M.fill_values(flat.nnz, flat.n, np.float64, seed=9, mode="int")
+    info = {}
+    _run(flat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, slabs=8, hot=1, info_out=info, y0=0.0)
+    assert info["slab_hot"] == 0, "uniformly used columns: nothing worth a table slot"
+
+
+def test_slab_hot_rmat_device():
+    mat = M.rmat_device(20, 16, seed=5, rank=0, world=1, device=DEV)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    val = torch.randint(0, 10, (mat.nnz,), generator=g, device=DEV).to(torch.float64)
+    x = torch.randint(0, 10, (mat.n,), generator=g, device=DEV).to(torch.float64)
+    ref = torch.sparse_csr_tensor(mat.row_ptr.to(torch.int64), mat.col.to(torch.int64), val, size=(mat.m, mat.n)) @ x
+    nonempty = mat.row_ptr[1:] > mat.row_ptr[:-1]
+    A = H.anonymouslibHandle(mat.m, mat.n)
+    assert A.inputCSR(mat.nnz, mat.row_ptr, mat.col, val) == 0 and A.setX(x) == 0
+    assert A.setSigma(H.ANONYMOUSLIB_AUTO_TUNED_SIGMA) == 0 and A.setColumnSlabs(16) == 0 and A.setSlabHot(1) == 0
+    assert A.asCSR5() == 0
+    i = A.info()
+    assert i.slab_hot == 1 and i.slab_hot_cover_pct >= 50, (i.slab_hot, i.slab_hot_cover_pct)
+    y = torch.full((mat.m,), -3.0, dtype=torch.float64, device=DEV)
+    assert A.spmv_repeat(1.0, y, 3) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y[nonempty], ref[nonempty])
+    assert A.destroy() == 0
+    A.close()
