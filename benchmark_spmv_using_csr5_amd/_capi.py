@@ -81,6 +81,11 @@ class DeviceCsrStruct(C.Structure):  # csr5hip_csr
     ]
 
 
+class Shard(C.Structure):  # csr5hip_shard
+    _fields_ = [("device", C.c_int), ("row_lo", C.c_int), ("row_hi", C.c_int), ("nnz", C.c_int),
+                ("d_y", C.c_void_p), ("handle", C.c_void_p), ("x_broadcast", C.c_int)]
+
+
 # every symbol include/csr5hip.h declares: (name, restype, argtypes)
 _H = C.c_void_p
 SYMBOLS = [
@@ -120,6 +125,22 @@ SYMBOLS = [
                                      C.c_int, C.c_int, C.POINTER(DeviceCsrStruct)]),
     ("csr5hip_csr_release", C.c_int, [C.POINTER(DeviceCsrStruct)]),
     ("csr5hip_mtx_load", C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(DeviceCsrStruct)]),
+    ("csr5hip_multi_create", C.c_int, [C.POINTER(_H), C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("csr5hip_multi_free", C.c_int, [_H]),
+    ("csr5hip_multi_input_csr", C.c_int, [_H, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("csr5hip_multi_set_sigma", C.c_int, [_H, C.c_int]),
+    ("csr5hip_multi_set_option", C.c_int, [_H, C.c_int, C.c_int]),
+    ("csr5hip_multi_as_csr5", C.c_int, [_H]),
+    ("csr5hip_multi_set_x", C.c_int, [_H, C.c_void_p]),
+    ("csr5hip_multi_spmv", C.c_int, [_H, C.c_double]),
+    ("csr5hip_multi_spmv_repeat", C.c_int, [_H, C.c_double, C.c_int]),
+    ("csr5hip_multi_synchronize", C.c_int, [_H]),
+    ("csr5hip_multi_timer_start", C.c_int, [_H]),
+    ("csr5hip_multi_timer_stop", C.c_int, [_H, C.POINTER(C.c_double)]),
+    ("csr5hip_multi_shard", C.c_int, [_H, C.c_int, C.POINTER(Shard)]),
+    ("csr5hip_multi_gather_y", C.c_int, [_H, C.c_void_p]),
+    ("csr5hip_multi_fill_y", C.c_int, [_H, C.c_int]),
+    ("csr5hip_multi_destroy", C.c_int, [_H]),
     ("csr5hip_save", C.c_int, [_H, C.c_char_p]),
     ("csr5hip_load", C.c_int, [C.c_char_p, C.POINTER(_H), C.POINTER(DeviceCsrStruct)]),
 ]

@@ -106,7 +106,12 @@ struct csr5hip_handle_s {
     int xwin_tiles = 0;   // tiles that got a window at conversion
     long long xwin_covered = 0; // non-zeros inside those windows
     long long xwin_lines = 0;   // distinct x lines under the in-window lanes of one sampled gather, summed over those tiles
-    Buffer b_tile_ptr, b_tile_desc, b_offset_ptr, b_offset, b_calibrator, b_acc, b_cnt, b_meta, b_counters, b_hdr;
+    // every auxiliary array of the conversion lives in ONE allocation (one hipMalloc, one memset per asCSR5 instead
+    // of ten and six: the small-matrix conversion is launch-bound)
+    Buffer b_arena;
+    void *scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    uint32_t scalar_words[2] = {0, 0}; // landing zone of the two 4-byte reads of the conversion
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t phase[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // asCSR5 phase boundaries
@@ -223,9 +228,7 @@ int csr5hip_free(csr5hip_handle h)
         return CSR5HIP_INVALID_ARGUMENT;
     h->drop_graphs();
     release_slabs(h);
-    for (Buffer *b : {&h->b_tile_ptr, &h->b_tile_desc, &h->b_offset_ptr, &h->b_offset,
-                      &h->b_calibrator, &h->b_acc, &h->b_cnt, &h->b_meta, &h->b_counters, &h->b_hdr})
-        b->release();
+    h->b_arena.release();
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->phase)
@@ -402,39 +405,67 @@ static int derive_geometry(csr5hip_handle h, int sigma)
     return CSR5HIP_SUCCESS;
 }
 
-// the auxiliary arrays of the handle (anonymouslib_cuda.h:142-151) plus the carry state, zeroed
+// the auxiliary arrays of the handle (anonymouslib_cuda.h:142-151) plus the carry state: one arena, its zero-initialised
+// part cleared by ONE memset.  `offset` is sized by its upper bound (one slot per row start plus one per tile), so the
+// conversion does not have to stop for the host to read num_offsets before it can continue (format_cuda.h:331-343
+// does; that read now rides with the final one).
 static int reserve_aux(csr5hip_handle h)
 {
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
     const size_t p1 = (size_t)g.p + 1;
     const size_t desc_words = (size_t)(g.p > 0 ? g.p : 1) * OMEGA * g.num_packet;
-    HIP_TRY(h->b_tile_ptr.reserve(p1 * 4));
-    HIP_TRY(h->b_tile_desc.reserve(desc_words * 4));
-    HIP_TRY(h->b_offset_ptr.reserve(p1 * 4));
-    HIP_TRY(h->b_calibrator.reserve(p1 * h->vsize()));
-    HIP_TRY(h->b_acc.reserve(p1 * h->vsize()));
-    HIP_TRY(h->b_cnt.reserve(p1 * 4));
-    HIP_TRY(h->b_meta.reserve(p1 * 16));
-    HIP_TRY(h->b_counters.reserve(16));
-    HIP_TRY(h->b_hdr.reserve(p1 * 32));
-    h->d.tile_ptr = (uint32_t *)h->b_tile_ptr.ptr;
-    h->d.tile_desc = (uint32_t *)h->b_tile_desc.ptr;
-    h->d.offset_ptr = (int32_t *)h->b_offset_ptr.ptr;
-    h->d.calibrator = h->b_calibrator.ptr;
-    h->d.carry_acc = h->b_acc.ptr;
-    h->d.carry_cnt = (uint32_t *)h->b_cnt.ptr;
-    h->d.carry_meta = (uint32_t *)h->b_meta.ptr;
-    h->d.counters = (uint32_t *)h->b_counters.ptr;
-    h->d.tile_hdr = (uint32_t *)h->b_hdr.ptr;
-    h->d.offset = nullptr;
-    HIP_TRY(hipMemsetAsync(h->d.tile_desc, 0, desc_words * 4, s));
-    HIP_TRY(hipMemsetAsync(h->d.offset_ptr, 0, p1 * 4, s));
-    HIP_TRY(hipMemsetAsync(h->d.calibrator, 0, p1 * h->vsize(), s));
-    HIP_TRY(hipMemsetAsync(h->d.carry_acc, 0, p1 * h->vsize(), s));
-    HIP_TRY(hipMemsetAsync(h->d.carry_cnt, 0, p1 * 4, s));
-    HIP_TRY(hipMemsetAsync(h->d.counters, 0, 16, s));
+    const size_t offset_cap = h->is_child ? p1 : (size_t)g.m + p1; // (a slab child has no empty rows)
+    h->scan_tmp_bytes = offset_scan_tmp_bytes((int)p1);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    // zero-initialised part first
+    const size_t o_desc = take(desc_words * 4), o_offp = take(p1 * 4), o_cal = take(p1 * h->vsize()),
+                 o_acc = take(p1 * h->vsize()), o_cnt = take(p1 * 4), o_counters = take(16), o_offset = take(offset_cap * 4);
+    const size_t zero_bytes = off;
+    const size_t o_tp = take(p1 * 4), o_meta = take(p1 * 16), o_hdr = take(p1 * 32), o_scan = take(h->scan_tmp_bytes);
+    HIP_TRY(h->b_arena.reserve(off));
+    char *base = (char *)h->b_arena.ptr;
+    h->d.tile_desc = (uint32_t *)(base + o_desc);
+    h->d.offset_ptr = (int32_t *)(base + o_offp);
+    h->d.calibrator = base + o_cal;
+    h->d.carry_acc = base + o_acc;
+    h->d.carry_cnt = (uint32_t *)(base + o_cnt);
+    h->d.counters = (uint32_t *)(base + o_counters);
+    h->d.offset = (int32_t *)(base + o_offset);
+    h->d.tile_ptr = (uint32_t *)(base + o_tp);
+    h->d.carry_meta = (uint32_t *)(base + o_meta);
+    h->d.tile_hdr = (uint32_t *)(base + o_hdr);
+    h->scan_tmp = base + o_scan;
+    HIP_TRY(hipMemsetAsync(base, 0, zero_bytes, s));
     return CSR5HIP_SUCCESS; // stream-ordered: the conversion kernels follow on the same stream
+}
+
+// the two words the host needs from the conversion -- tail start and number of offsets, as in the reference
+// (anonymouslib_cuda.h:165-167, format_cuda.h:331-343) -- copied asynchronously; valid after the next synchronisation
+static hipError_t read_format_scalars(csr5hip_handle h, bool sync)
+{
+    const Geometry &g = h->g;
+    h->scalar_words[0] = h->scalar_words[1] = 0;
+    if (g.p <= 0)
+        return hipSuccess;
+    hipError_t e = hipMemcpyAsync(&h->scalar_words[0], h->d.tile_ptr + (g.p - 1), 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&h->scalar_words[1], h->d.offset_ptr + g.p, 4, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && sync)
+        e = hipStreamSynchronize(h->stream);
+    return e;
+}
+static void finish_format_scalars(csr5hip_handle h)
+{
+    if (h->g.p <= 0)
+        return;
+    h->g.tail_start = (int)(h->scalar_words[0] & ROW_MASK);
+    h->num_offsets = (int)h->scalar_words[1];
 }
 
 // what the fused kernel needs on top of the reference's format arrays: carry meta, x windows, tile headers
@@ -447,7 +478,9 @@ static int derive_kernel_tables(csr5hip_handle h)
     HIP_TRY(launch_tile_hdr(g, h->d, s));
     uint32_t stats[4] = {0, 0, 0, 0}; // x-window tiles, covered non-zeros, long runs, gather lines
     HIP_TRY(hipMemcpyAsync(stats, h->d.counters, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(read_format_scalars(h, false)); // tail start, number of offsets: same host round trip
     HIP_TRY(hipStreamSynchronize(s));
+    finish_format_scalars(h);
     h->xwin_tiles = (int)stats[0];
     h->xwin_covered = (long long)stats[1];
     h->xwin_lines = (long long)stats[3];
@@ -456,8 +489,7 @@ static int derive_kernel_tables(csr5hip_handle h)
 }
 
 // steps 1-2 of the conversion: everything that is derived from row_ptr alone (tile_ptr, tile_desc, offset_ptr,
-// offset).  Contains the first of the two host round trips of asCSR5: the two words the host needs -- tail start and
-// number of offsets, as in the reference (anonymouslib_cuda.h:165-167, format_cuda.h:331-343).
+// offset).  Stream-ordered, no host round trip (see reserve_aux).
 static int build_format_arrays(csr5hip_handle h)
 {
     Geometry &g = h->g;
@@ -471,27 +503,10 @@ static int build_format_arrays(csr5hip_handle h)
     HIP_TRY(launch_row_scan(g, h->d, s));
     HIP_TRY(hipEventRecord(h->phase[1], s));
 
-    // step 2: tile_desc, offset_ptr scan, then the two 4-byte reads
+    // step 2: tile_desc, offset_ptr scan, empty-row offsets (the kernel leaves unflagged tiles at once)
     HIP_TRY(launch_tile_desc(g, h->d, s));
-    HIP_TRY(launch_offset_scan(g, h->d, s));
-    uint32_t tail_word = 0;
-    int32_t num_offsets = 0;
-    HIP_TRY(hipMemcpyAsync(&tail_word, h->d.tile_ptr + (g.p - 1), 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipMemcpyAsync(&num_offsets, h->d.offset_ptr + g.p, 4, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    g.tail_start = (int)(tail_word & ROW_MASK);
-    h->num_offsets = num_offsets;
-
-    if (num_offsets > 0) {
-        const double t0 = now_ms();
-        HIP_TRY(h->b_offset.reserve((size_t)num_offsets * 4));
-        h->d.offset = (int32_t *)h->b_offset.ptr;
-        h->t_malloc += now_ms() - t0;
-        // one slot per flagged tile is never written (lane 0's forced flag, format_cuda.h:391-399): keep the array
-        // deterministic so that a checkpoint can be compared with a re-derived copy
-        HIP_TRY(hipMemsetAsync(h->d.offset, 0, (size_t)num_offsets * 4, s));
-        HIP_TRY(launch_desc_offset(g, h->d, s));
-    }
+    HIP_TRY(launch_offset_scan(g, h->d, h->scan_tmp, h->scan_tmp_bytes, s));
+    HIP_TRY(launch_desc_offset(g, h->d, s));
     HIP_TRY(hipEventRecord(h->phase[2], s));
     return CSR5HIP_SUCCESS;
 }
@@ -521,9 +536,9 @@ int csr5hip_as_csr5(csr5hip_handle h)
     Geometry &g = h->g;
     hipStream_t s = h->stream;
 
-    // Two host round trips in all (the reference synchronises after every phase, anonymouslib_cuda.h:161-208):
-    // one inside build_format_arrays and one at the end.  The four phase times the reference prints are taken
-    // from events on the stream instead of host timers around synchronisations.
+    // ONE host round trip in all, at the end (the reference synchronises after every phase and reads two words in
+    // between, anonymouslib_cuda.h:161-208).  The four phase times the reference prints are taken from events on
+    // the stream instead of host timers around synchronisations.
     double t0 = now_ms();
     rc = reserve_aux(h);
     if (rc != CSR5HIP_SUCCESS)
@@ -931,6 +946,9 @@ int csr5hip_load(const char *path, csr5hip_handle *out, csr5hip_csr *arrays)
         rc = build_format_arrays(h);
         if (rc != CSR5HIP_SUCCESS)
             return fail_with(rc, nullptr);
+        if (read_format_scalars(h, true) != hipSuccess)
+            return fail_with(CSR5HIP_HIP_ERROR, "reading the conversion scalars failed");
+        finish_format_scalars(h);
         if (h->g.tail_start != hd.tail_start || h->num_offsets != hd.num_offsets)
             return fail_with(CSR5HIP_INVALID_ARGUMENT, "format arrays do not belong to this row_ptr (tail start / offsets)");
     } else if (hd.num_offsets != 0) {

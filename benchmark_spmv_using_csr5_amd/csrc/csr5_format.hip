@@ -17,6 +17,8 @@
 //      two launches (col, val), 29 sigma instantiations              in one launch, runtime sigma, padded LDS
 #include "csr5_internal.h"
 
+#include <rocprim/device/device_scan.hpp>
+
 namespace csr5 {
 
 // number of entries of a[0..size) that are <= key (the reference's
@@ -139,44 +141,9 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_desc(Geometry g, const uint3
 }
 
 // ---------------------------------------------------------------------------------------------
-// K6: exclusive scan of offset_ptr[0..p] in place, single workgroup (p+1 <= a few 10^5 entries).
+// K6: exclusive scan of offset_ptr[0..p] in place (format_cuda.h:269-300 runs it in ONE 256-thread block; at
+// p = 262 k that single workgroup took ~0.3 ms here).  Device-wide decoupled look-back scan (rocprim).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_offset_scan(int32_t *__restrict__ a, int n)
-{
-    __shared__ int wave_tot[16];
-    __shared__ int carry_s;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    if (tid == 0)
-        carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
-        const int i = base + tid;
-        const int v = i < n ? a[i] : 0;
-        int incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int u = __shfl_up(incl, d, 64);
-            if (lane >= d)
-                incl += u;
-        }
-        if (lane == 63)
-            wave_tot[wave] = incl;
-        __syncthreads();
-        int wave_off = 0;
-        for (int w = 0; w < wave; w++)
-            wave_off += wave_tot[w];
-        const int carry = carry_s;
-        if (i < n)
-            a[i] = carry + wave_off + incl - v;
-        __syncthreads();
-        if (tid == 1023)
-            carry_s = carry + wave_off + incl;
-        __syncthreads();
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // K7: tiles whose tile_ptr carries bit 31: the k-th store slot of the tile gets the row index
 // (relative to row_start+1) of the segment that starts there.
@@ -296,17 +263,32 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_carry_meta(Geometry g, const int3
         return true;
     };
     const int r = (int)(tile_ptr[t] & ROW_MASK);
-    uint4 meta = make_uint4(0u, (unsigned)t, 0u, 0u);
+    // Run bounds by bisection on the sorted tile_ptr (a thread used to WALK its run and write the members' .y: ten
+    // thousand serial steps for a 10 M-nnz row).  head = first tile whose row is r, e = last one.
+    int lo = 0, hi = t;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)(tile_ptr[mid] & ROW_MASK) < r)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    const int head_idx = lo;
+    const bool head = head_idx == t;
+    uint4 meta = make_uint4(0u, (unsigned)head_idx, 0u, 0u);
     int len = 0;
-    const bool head = t == 0 || (int)(tile_ptr[t - 1] & ROW_MASK) != r;
     if (short_spill(t, &len)) {
         meta.x |= 1u << 28;
     } else if (head && r < g.m) {
-        int e = t;
-        while (e + 1 < g.p && (int)(tile_ptr[e + 1] & ROW_MASK) == r) {
-            e++;
-            reinterpret_cast<unsigned *>(&carry_meta[e])[1] = (unsigned)t; // .y of the run members
+        lo = t + 1, hi = g.p;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)(tile_ptr[mid] & ROW_MASK) <= r)
+                lo = mid + 1;
+            else
+                hi = mid;
         }
+        const int e = lo - 1;
         unsigned expected = (unsigned)(e - t + 1);
         if (e - t + 1 > RUN_SERIAL_MAX) {
             meta.x |= 1u << 26; // long run: partials are only parked, k_calibrate sums them
@@ -329,15 +311,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_carry_meta(Geometry g, const int3
             }
         }
     }
-    // .y of non-head run members is written by their head's thread; everything else by this one
-    if (head) {
-        carry_meta[t] = meta;
-    } else {
-        unsigned *w = reinterpret_cast<unsigned *>(&carry_meta[t]);
-        w[0] = meta.x;
-        w[2] = meta.z;
-        w[3] = 0u;
-    }
+    carry_meta[t] = meta; // .w (x-window start) is set by k_tile_window afterwards
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -518,10 +492,17 @@ hipError_t launch_tile_desc(const Geometry &g, const DeviceArrays &d, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_offset_scan(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+size_t offset_scan_tmp_bytes(int entries)
 {
-    hipLaunchKernelGGL(k_offset_scan, dim3(1), dim3(1024), 0, s, d.offset_ptr, g.p + 1);
-    return hipGetLastError();
+    size_t bytes = 0;
+    int32_t *null_i = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, bytes, null_i, null_i, 0, (size_t)entries, rocprim::plus<int32_t>(), nullptr);
+    return bytes;
+}
+
+hipError_t launch_offset_scan(const Geometry &g, const DeviceArrays &d, void *tmp, size_t tmp_bytes, hipStream_t s)
+{
+    return rocprim::exclusive_scan(tmp, tmp_bytes, d.offset_ptr, d.offset_ptr, 0, (size_t)g.p + 1, rocprim::plus<int32_t>(), s);
 }
 
 hipError_t launch_desc_offset(const Geometry &g, const DeviceArrays &d, hipStream_t s)

@@ -78,7 +78,8 @@ struct DeviceArrays {
 hipError_t launch_tile_ptr(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_row_scan(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_tile_desc(const Geometry &g, const DeviceArrays &d, hipStream_t s);
-hipError_t launch_offset_scan(const Geometry &g, const DeviceArrays &d, hipStream_t s);
+size_t offset_scan_tmp_bytes(int entries);
+hipError_t launch_offset_scan(const Geometry &g, const DeviceArrays &d, void *tmp, size_t tmp_bytes, hipStream_t s);
 hipError_t launch_desc_offset(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c,
                             hipStream_t s);

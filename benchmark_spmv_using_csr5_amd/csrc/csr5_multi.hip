@@ -121,6 +121,7 @@ struct csr5hip_multi_s {
     std::vector<csr5hip_handle> h;
     std::vector<hipStream_t> stream;
     std::vector<void *> row_ptr, col, val, x, y;
+    std::vector<char> x_owned; // x[g] was allocated here (shards on devices[0] borrow the caller's vector instead)
     std::vector<hipEvent_t> ev0, ev1;
     std::vector<void *> comm; // ncclComm_t per UNIQUE device, or empty
     bool distinct = true;     // no device id listed twice
@@ -154,6 +155,7 @@ int csr5hip_multi_create(csr5hip_multi *out, const int *devices, int G, int m, i
     mh->stream.assign(G, nullptr);
     mh->row_ptr.assign(G, nullptr), mh->col.assign(G, nullptr), mh->val.assign(G, nullptr);
     mh->x.assign(G, nullptr), mh->y.assign(G, nullptr);
+    mh->x_owned.assign(G, 0);
     mh->ev0.assign(G, nullptr), mh->ev1.assign(G, nullptr);
     mh->cut.assign(G + 1, 0), mh->shard_nnz.assign(G, 0);
     for (int g = 0; g < G; g++) {
@@ -180,7 +182,7 @@ int csr5hip_multi_free(csr5hip_multi mh)
         for (void *p : {mh->row_ptr[g], mh->col[g], mh->val[g], mh->y[g]})
             if (p)
                 (void)hipFree(p);
-        if (mh->x[g] && !(mh->dev[g] == mh->dev[0] && g != 0 && mh->x[g] == mh->x[0]))
+        if (mh->x[g] && mh->x_owned[g])
             (void)hipFree(mh->x[g]);
         if (mh->ev0[g]) (void)hipEventDestroy(mh->ev0[g]);
         if (mh->ev1[g]) (void)hipEventDestroy(mh->ev1[g]);
@@ -322,10 +324,12 @@ int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x)
                     first = q;
                     break;
                 }
-            if (first != g)
+            if (first != g) {
                 mh->x[g] = mh->x[first];
-            else if (!mh->x[g])
+            } else if (!mh->x[g]) {
                 MHIP(hipMalloc(&mh->x[g], bytes ? bytes : 4));
+                mh->x_owned[g] = 1;
+            }
         }
     }
     bool any_remote = false;

@@ -13,6 +13,9 @@
 // the rule-based sigma (tuned = measured selection); CSR5_MODE=0|1 picks two-pass/fused SpMV; three extra report lines (hipGraph replay
 // time, algorithmic-bytes roofline fraction, ingest phase times) are printed after the reference's lines; CSR5_RESULTS=<csv>
 // appends "file,GFlops,GB/s,roof fraction,m,nnz,sigma,tiles,us" per run (the avx512 backend's results.csv, extended).
+// CSR5_GPUS=G (G > 1) runs the same protocol on G GPUs through anonymouslibMultiHandle: nnz-balanced row blocks, one
+// RCCL broadcast of x, no per-SpMV collective (CSR5_GPU_LIST=0,0,.. overrides the device list, e.g. to put several
+// shards on one GPU).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -45,10 +48,111 @@ using namespace std;
 static const char *g_filename = "";
 static double g_ingest_ms[3] = {0, 0, 0};  // parse, H2D, device COO->CSR
 
+// the reference protocol (main.cu:59-104) on G GPUs
+static int call_anonymouslib_multi(const std::vector<int> &devs, int m, int n, int nnzA, int *csrRowPtrA,
+                                   int *csrColIdxA, VALUE_TYPE *csrValA, VALUE_TYPE *x, VALUE_TYPE *y, VALUE_TYPE alpha)
+{
+    const int G = (int)devs.size();
+    DEV_CHECK(csr5hip_set_device(devs[0]));
+    for (int g = 0; g < G; g++) {
+        char name[256];
+        double mhz = 0;
+        DEV_CHECK(csr5hip_device_name(devs[g], name, sizeof name, &mhz));
+        cout << "Device [" << devs[g] << "] " << name << ", " << " @ " << mhz << "MHz. " << endl;
+    }
+    const double gb = getB<int, VALUE_TYPE>(m, nnzA);
+    const double gflop = getFLOP<int>(nnzA);
+    int *d_csrRowPtrA, *d_csrColIdxA;
+    VALUE_TYPE *d_csrValA, *d_x;
+    DEV_CHECK(csr5hip_malloc((void **)&d_csrRowPtrA, (size_t)(m + 1) * sizeof(int)));
+    DEV_CHECK(csr5hip_malloc((void **)&d_csrColIdxA, (size_t)(nnzA ? nnzA : 1) * sizeof(int)));
+    DEV_CHECK(csr5hip_malloc((void **)&d_csrValA, (size_t)(nnzA ? nnzA : 1) * sizeof(VALUE_TYPE)));
+    DEV_CHECK(csr5hip_memcpy_h2d(d_csrRowPtrA, csrRowPtrA, (size_t)(m + 1) * sizeof(int)));
+    DEV_CHECK(csr5hip_memcpy_h2d(d_csrColIdxA, csrColIdxA, (size_t)nnzA * sizeof(int)));
+    DEV_CHECK(csr5hip_memcpy_h2d(d_csrValA, csrValA, (size_t)nnzA * sizeof(VALUE_TYPE)));
+    DEV_CHECK(csr5hip_malloc((void **)&d_x, (size_t)n * sizeof(VALUE_TYPE)));
+    DEV_CHECK(csr5hip_memcpy_h2d(d_x, x, (size_t)n * sizeof(VALUE_TYPE)));
+
+    anonymouslibMultiHandle<int, unsigned int, VALUE_TYPE> A(devs.data(), G, m, n);
+    int err = A.inputCSR(nnzA, d_csrRowPtrA, d_csrColIdxA, d_csrValA);
+    if (err != ANONYMOUSLIB_SUCCESS)
+        cerr << "inputCSR err = " << err << " " << csr5hip_last_error() << endl;
+    const char *sig = getenv("CSR5_SIGMA");
+    A.setSigma(sig && strcmp(sig, "tuned") ? atoi(sig) : ANONYMOUSLIB_AUTO_TUNED_SIGMA);
+    if (const char *mode = getenv("CSR5_MODE"))
+        A.setOption(CSR5HIP_OPT_SPMV_MODE, atoi(mode));
+    anonymouslib_timer asCSR5_timer;
+    asCSR5_timer.start();
+    err = A.asCSR5();
+    cout << "CSR->CSR5 time = " << asCSR5_timer.stop() << " ms." << endl;
+    if (err != ANONYMOUSLIB_SUCCESS)
+        cerr << "asCSR5 err = " << err << " " << csr5hip_last_error() << endl;
+    anonymouslib_timer bcast_timer;
+    bcast_timer.start();
+    err = A.setX(d_x); // the one collective: x replicated on every GPU
+    csr5hip_shard s0;
+    csr5hip_multi_shard(A.native(), 0, &s0);
+    cout << "x replicated on " << G << " GPUs in " << bcast_timer.stop() << " ms ("
+         << (s0.x_broadcast == 1 ? "one RCCL broadcast" : s0.x_broadcast == 2 ? "device-to-device copies" : "shared device")
+         << ")." << endl;
+
+    err = A.spmv(alpha); // correctness run
+    A.gatherY(y);
+    if (NUM_RUN)
+        for (int i = 0; i < 50; i++)
+            err = A.spmv(alpha);
+    A.synchronize();
+    anonymouslib_timer CSR5Spmv_timer;
+    CSR5Spmv_timer.start();
+    for (int i = 0; i < NUM_RUN; i++)
+        err = A.spmv(alpha);
+    A.synchronize();
+    const double CSR5Spmv_time = NUM_RUN ? CSR5Spmv_timer.stop() / (double)NUM_RUN : 0.0;
+    if (NUM_RUN) {
+        cout << "CSR5-based SpMV time = " << CSR5Spmv_time << " ms. Bandwidth = " << gb / (1.0e+6 * CSR5Spmv_time)
+             << " GB/s. GFlops = " << gflop / (1.0e+6 * CSR5Spmv_time) << " GFlops." << endl;
+        A.spmv_repeat(alpha, NUM_RUN); // instantiate + warm the per-device graphs
+        A.synchronize();
+        double ms = 0;
+        DEV_CHECK(csr5hip_multi_timer_start(A.native()));
+        A.spmv_repeat(alpha, NUM_RUN);
+        DEV_CHECK(csr5hip_multi_timer_stop(A.native(), &ms));
+        const double t = ms / NUM_RUN;
+        cout << "CSR5-based SpMV time (hipGraph replay, max over " << G << " GPUs) = " << t
+             << " ms. GFlops = " << gflop / (1.0e+6 * t) << " GFlops." << endl;
+        cout << "Ingest: parse = " << g_ingest_ms[0] << " ms, H2D = " << g_ingest_ms[1]
+             << " ms, COO->CSR on device = " << g_ingest_ms[2] << " ms." << endl;
+    }
+    A.destroy();
+    csr5hip_device_free(d_csrRowPtrA);
+    csr5hip_device_free(d_csrColIdxA);
+    csr5hip_device_free(d_csrValA);
+    csr5hip_device_free(d_x);
+    return err;
+}
+
 static int call_anonymouslib(int m, int n, int nnzA, int *csrRowPtrA, int *csrColIdxA,
                              VALUE_TYPE *csrValA, VALUE_TYPE *x, VALUE_TYPE *y, VALUE_TYPE alpha)
 {
     int err = 0;
+    // CSR5_GPUS=G / CSR5_GPU_LIST=a,b,..: several GPUs (not in the reference)
+    {
+        std::vector<int> devs;
+        if (const char *list = getenv("CSR5_GPU_LIST")) {
+            for (const char *p = list; *p;) {
+                devs.push_back(atoi(p));
+                while (*p && *p != ',')
+                    p++;
+                if (*p == ',')
+                    p++;
+            }
+        } else if (const char *gs = getenv("CSR5_GPUS")) {
+            for (int g = 0; g < atoi(gs); g++)
+                devs.push_back(g);
+        }
+        if (devs.size() > 1)
+            return call_anonymouslib_multi(devs, m, n, nnzA, csrRowPtrA, csrColIdxA, csrValA, x, y, alpha);
+    }
     const int device_id = 0;
     DEV_CHECK(csr5hip_set_device(device_id));
     char name[256];

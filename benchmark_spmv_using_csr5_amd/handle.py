@@ -222,3 +222,90 @@ class anonymouslibHandle:
             self.close()
         except Exception:
             pass
+
+
+class MultiGpuHandle:
+    """One matrix on the G GPUs of a node through the C ABI (``csr5hip_multi_*``, include/csr5hip.h): nnz-balanced row
+    blocks, one ordinary handle + stream per device, x replicated by ONE RCCL broadcast at ``setX``, y sharded.
+    ``devices`` may repeat a device id (several shards on one GPU) -- how a 1-GPU box exercises the path."""
+
+    def __init__(self, devices, m: int, n: int, dtype="float64"):
+        self._lib = _capi.load()
+        self._h = C.c_void_p()
+        self.m, self.n, self.G = int(m), int(n), len(devices)
+        self._np_dtype = np.float64 if _value_type(dtype) == _capi.F64 else np.float32
+        devs = (C.c_int * self.G)(*[int(d) for d in devices])
+        self._check(self._lib.csr5hip_multi_create(C.byref(self._h), devs, self.G, self.m, self.n, _value_type(dtype)),
+                    "csr5hip_multi_create")
+        self._keep = {}
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            raise RuntimeError(f"{what} -> {rc}: {_capi.last_error()}")
+
+    def inputCSR(self, nnz, row_ptr, col, val) -> int:
+        """device arrays on devices[0]; copied into the shards (the caller's arrays stay untouched)"""
+        return self._lib.csr5hip_multi_input_csr(self._h, int(nnz), _ptr(row_ptr), _ptr(col), _ptr(val))
+
+    def setSigma(self, sigma: int) -> int:
+        return self._lib.csr5hip_multi_set_sigma(self._h, int(sigma))
+
+    def setOption(self, option: int, value: int) -> int:
+        return self._lib.csr5hip_multi_set_option(self._h, int(option), int(value))
+
+    def asCSR5(self) -> int:
+        return self._lib.csr5hip_multi_as_csr5(self._h)
+
+    def setX(self, x) -> int:
+        self._keep["x"] = x
+        return self._lib.csr5hip_multi_set_x(self._h, _ptr(x))
+
+    def spmv(self, alpha=1.0) -> int:
+        return self._lib.csr5hip_multi_spmv(self._h, float(alpha))
+
+    def spmv_repeat(self, alpha, count: int) -> int:
+        return self._lib.csr5hip_multi_spmv_repeat(self._h, float(alpha), int(count))
+
+    def synchronize(self) -> int:
+        return self._lib.csr5hip_multi_synchronize(self._h)
+
+    def timer_start(self) -> int:
+        return self._lib.csr5hip_multi_timer_start(self._h)
+
+    def timer_stop(self) -> float:
+        ms = C.c_double(0.0)
+        self._check(self._lib.csr5hip_multi_timer_stop(self._h, C.byref(ms)), "csr5hip_multi_timer_stop")
+        return ms.value
+
+    def shard(self, g: int) -> _capi.Shard:
+        s = _capi.Shard()
+        self._check(self._lib.csr5hip_multi_shard(self._h, int(g), C.byref(s)), "csr5hip_multi_shard")
+        return s
+
+    def shard_info(self, g: int) -> _capi.Csr5Info:
+        info = _capi.Csr5Info()
+        self._check(self._lib.csr5hip_get_info(C.c_void_p(self.shard(g).handle), C.byref(info)), "csr5hip_get_info")
+        return info
+
+    def fill_y(self, byte_value: int) -> int:
+        return self._lib.csr5hip_multi_fill_y(self._h, int(byte_value))
+
+    def gather_y(self) -> np.ndarray:
+        out = np.empty(self.m, dtype=self._np_dtype)
+        self._check(self._lib.csr5hip_multi_gather_y(self._h, out.ctypes.data), "csr5hip_multi_gather_y")
+        return out
+
+    def destroy(self) -> int:
+        return self._lib.csr5hip_multi_destroy(self._h)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.csr5hip_multi_free(self._h)
+            self._h = C.c_void_p()
+        self._keep = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

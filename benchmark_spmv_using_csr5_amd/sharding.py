@@ -99,8 +99,17 @@ class ShardedSpmv:
         return local_spmv(self.block, x)
 
 
+def _check(rc: int, what: str) -> None:
+    """State-changing handle calls must run (and fail loudly) under ``python -O`` too: never inside an assert."""
+    if rc != 0:
+        from . import _capi
+        raise RuntimeError(f"{what} -> {rc}: {_capi.last_error()}")
+
+
 def hip_local_spmv(device, sigma: int = -1, mode: int = 1):
-    """Factory for ShardedSpmv.run on a GPU: converts the block to CSR5 once, returns y (device)."""
+    """Factory for ShardedSpmv.run on a GPU: converts the block to CSR5 once, returns y (device).
+    (One process per GPU over torch.distributed; the single-process form of the same sharding lives behind the C ABI,
+    ``csr5hip_multi_*`` / ``handle.MultiGpuHandle``.)"""
     import torch
 
     from . import handle as H
@@ -114,16 +123,18 @@ def hip_local_spmv(device, sigma: int = -1, mode: int = 1):
             ci = torch.from_numpy(block.col.astype(np.int32)).to(device)
             va = torch.from_numpy(block.val).to(device)
             A = H.anonymouslibHandle(block.m, block.n, dtype=str(block.val.dtype))
-            assert A.inputCSR(block.nnz, rp, ci, va) == 0
-            assert A.setSigma(sigma) == 0
-            assert A.setSpmvMode(mode) == 0
-            assert A.asCSR5() == 0
+            _check(A.inputCSR(block.nnz, rp, ci, va), "inputCSR")
+            _check(A.setSigma(sigma), "setSigma")
+            _check(A.setSpmvMode(mode), "setSpmvMode")
+            _check(A.setStream(torch.cuda.current_stream(device).cuda_stream), "setStream")
+            _check(A.asCSR5(), "asCSR5")
             state.update(A=A, keep=(rp, ci, va), y=torch.zeros(block.m, dtype=tdt, device=device))
         A = state["A"]
-        assert A.setX(x) == 0
-        assert A.spmv(1.0, state["y"]) == 0
+        _check(A.setX(x), "setX")
+        _check(A.spmv(1.0, state["y"]), "spmv")
         return state["y"]
 
+    run.state = state
     return run
 
 
@@ -239,15 +250,19 @@ def hip_coupled_spmv(device, sigma: int = -1, mode: int = 1):
             ci = torch.from_numpy(block.col.astype(np.int32)).to(device)
             va = torch.from_numpy(block.val).to(device)
             A = H.anonymouslibHandle(block.m, block.n, dtype=str(block.val.dtype))
-            assert A.inputCSR(block.nnz, rp, ci, va) == 0
-            assert A.setSigma(sigma) == 0
-            assert A.setSpmvMode(mode) == 0
-            assert A.setStream(torch.cuda.current_stream(device).cuda_stream) == 0
-            assert A.asCSR5() == 0
+            _check(A.inputCSR(block.nnz, rp, ci, va), "inputCSR")
+            _check(A.setSigma(sigma), "setSigma")
+            _check(A.setSpmvMode(mode), "setSpmvMode")
+            _check(A.setStream(torch.cuda.current_stream(device).cuda_stream), "setStream")
+            # y becomes the next x: EVERY entry of the slot must be defined by the SpMV.  The reference semantics leave
+            # rows without non-zeros untouched (csr5hip.h), which would keep values from two iterations ago in the
+            # ping-pong buffer (R-MAT: half the rows), so the library is asked to store 0 there.
+            _check(A.setZeroEmptyRows(1), "setZeroEmptyRows")
+            _check(A.asCSR5(), "asCSR5")
             state.update(A=A, keep=(rp, ci, va))
         A = state["A"]
-        assert A.setX(x_padded) == 0
-        assert A.spmv(1.0, y_slot) == 0
+        _check(A.setX(x_padded), "setX")
+        _check(A.spmv(1.0, y_slot), "spmv")
         return y_slot
 
     run.state = state

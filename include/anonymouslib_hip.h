@@ -141,4 +141,55 @@ private:
     bool _quiet;
 };
 
+// One matrix on the G GPUs of a node (not in the reference, which is single-device: main.cu:25-26): same member
+// names as anonymouslibHandle over csr5hip_multi_*.  inputCSR / setX take DEVICE pointers on devices[0]; y lives
+// sharded on the devices (gatherY copies it to a host vector for checks).
+template <class ANONYMOUSLIB_IT, class ANONYMOUSLIB_UIT, class ANONYMOUSLIB_VT>
+class anonymouslibMultiHandle
+{
+public:
+    anonymouslibMultiHandle(const int *devices, int ngpus, ANONYMOUSLIB_IT m, ANONYMOUSLIB_IT n) : _h(0)
+    {
+        const int vt = std::is_same<ANONYMOUSLIB_VT, double>::value ? CSR5HIP_F64
+                     : std::is_same<ANONYMOUSLIB_VT, float>::value  ? CSR5HIP_F32 : -1;
+        _err = vt < 0 ? ANONYMOUSLIB_UNSUPPORTED_VALUE_TYPE : csr5hip_multi_create(&_h, devices, ngpus, (int)m, (int)n, vt);
+        _g = ngpus;
+    }
+    ~anonymouslibMultiHandle() { if (_h) csr5hip_multi_free(_h); }
+    int inputCSR(ANONYMOUSLIB_IT nnz, ANONYMOUSLIB_IT *row_ptr, ANONYMOUSLIB_IT *col_idx, ANONYMOUSLIB_VT *val)
+    {
+        return _h ? csr5hip_multi_input_csr(_h, (int)nnz, (const int32_t *)row_ptr, (const int32_t *)col_idx, val) : _err;
+    }
+    void setSigma(int sigma) { if (_h) csr5hip_multi_set_sigma(_h, sigma); }
+    int setOption(int option, int value) { return _h ? csr5hip_multi_set_option(_h, option, value) : _err; }
+    int asCSR5()
+    {
+        if (!_h) return _err;
+        const int err = csr5hip_multi_as_csr5(_h);
+        for (int g = 0; g < _g && err == ANONYMOUSLIB_SUCCESS; g++) {
+            csr5hip_shard s;
+            csr5hip_info i;
+            csr5hip_multi_shard(_h, g, &s);
+            csr5hip_get_info(s.handle, &i);
+            std::cout << "GPU shard " << g << " on device " << s.device << ": rows [" << s.row_lo << ", " << s.row_hi
+                      << "), nnz = " << s.nnz << ", omega = " << ANONYMOUSLIB_CSR5_OMEGA << ", sigma = " << i.sigma
+                      << ", tiles = " << i.p << std::endl;
+        }
+        return err;
+    }
+    int setX(ANONYMOUSLIB_VT *x) { return _h ? csr5hip_multi_set_x(_h, x) : _err; }
+    int spmv(const ANONYMOUSLIB_VT alpha) { return _h ? csr5hip_multi_spmv(_h, (double)alpha) : _err; }
+    int spmv_repeat(const ANONYMOUSLIB_VT alpha, int count) { return _h ? csr5hip_multi_spmv_repeat(_h, (double)alpha, count) : _err; }
+    int synchronize() { return _h ? csr5hip_multi_synchronize(_h) : _err; }
+    int gatherY(ANONYMOUSLIB_VT *host_y) { return _h ? csr5hip_multi_gather_y(_h, host_y) : _err; }
+    int destroy() { return _h ? csr5hip_multi_destroy(_h) : _err; }
+    csr5hip_multi native() const { return _h; }
+
+private:
+    anonymouslibMultiHandle(const anonymouslibMultiHandle &);
+    anonymouslibMultiHandle &operator=(const anonymouslibMultiHandle &);
+    csr5hip_multi _h;
+    int _err, _g;
+};
+
 #endif // ANONYMOUSLIB_HIP_H

@@ -244,6 +244,51 @@ int csr5hip_mtx_load(const char *path, int threads, int value_type, csr5hip_csr 
 int csr5hip_save(csr5hip_handle h, const char *path);
 int csr5hip_load(const char *path, csr5hip_handle *h, csr5hip_csr *arrays);
 
+/* ---------------------------------------------------------------------------------------------------
+ * One matrix on the G GPUs of a node (SURVEY.md section 8, row e).  The reference is single-device
+ * (CSR5_cuda/main.cu:25-26 `cudaSetDevice(0)`): this is the MI355X addition.  The matrix is cut into G contiguous
+ * row blocks balanced by NON-ZEROS (split points = upper_bound(row_ptr, g*nnz/G) - 1, the reference's tile_ptr
+ * primitive, utils_cuda.h:25-53); every block becomes an ordinary handle on its own device and stream; x is
+ * replicated ONCE at set_x time by a single RCCL broadcast over xGMI (librccl is opened lazily; device-to-device
+ * copies when it is absent or a device is listed twice); y stays sharded; no per-SpMV collective.
+ * Single host thread, all calls asynchronous per device.  devices[] may list a device several times (several
+ * shards on one GPU), which is how a 1-GPU box exercises this path.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct csr5hip_multi_s *csr5hip_multi;
+
+typedef struct csr5hip_shard {
+    int device;              /* HIP device of the shard */
+    int row_lo, row_hi;      /* global rows [row_lo, row_hi) */
+    int nnz;
+    void *d_y;               /* the shard's result vector on `device` (row_hi - row_lo values) */
+    csr5hip_handle handle;   /* the shard's ordinary handle (csr5hip_get_info etc.) */
+    int x_broadcast;         /* how the last set_x replicated x: 0 = nothing to replicate, 1 = RCCL broadcast, 2 = copies */
+} csr5hip_shard;
+
+int csr5hip_multi_create(csr5hip_multi *out, const int *devices, int G, int m, int n, int value_type);
+int csr5hip_multi_free(csr5hip_multi mh);
+/* inputCSR for the whole matrix: device pointers on devices[0].  Unlike the single handle the arrays are COPIED into
+ * the per-device shards (and rebased); the caller's arrays are not modified by asCSR5 and may be freed afterwards. */
+int csr5hip_multi_input_csr(csr5hip_multi mh, int nnz, const int32_t *d_row_ptr, const int32_t *d_col_idx, const void *d_val);
+int csr5hip_multi_set_sigma(csr5hip_multi mh, int sigma);
+int csr5hip_multi_set_option(csr5hip_multi mh, int option, int value);
+int csr5hip_multi_as_csr5(csr5hip_multi mh);
+/* setX: d_x on devices[0], n values, borrowed by the shards that live there; ONE broadcast to the other devices */
+int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x);
+/* spmv on every shard, enqueued on the shards' streams (returns without waiting) */
+int csr5hip_multi_spmv(csr5hip_multi mh, double alpha);
+int csr5hip_multi_spmv_repeat(csr5hip_multi mh, double alpha, int count);
+int csr5hip_multi_synchronize(csr5hip_multi mh);
+/* device time between the two calls: the MAXIMUM over the shards' streams */
+int csr5hip_multi_timer_start(csr5hip_multi mh);
+int csr5hip_multi_timer_stop(csr5hip_multi mh, double *ms_max);
+int csr5hip_multi_shard(csr5hip_multi mh, int g, csr5hip_shard *out);
+/* correctness checks: the y shards collected into one HOST vector of m values; fill_y presets every y byte */
+int csr5hip_multi_gather_y(csr5hip_multi mh, void *h_y);
+int csr5hip_multi_fill_y(csr5hip_multi mh, int byte_value);
+/* destroy() on every shard (the shards' own copies go back to CSR order) */
+int csr5hip_multi_destroy(csr5hip_multi mh);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,105 @@
+"""Multi-GPU path behind the C ABI (csr5hip_multi_*): nnz-balanced row blocks, one handle per shard, x replicated
+once, y sharded.  On a 1-GPU box every shard lives on device 0 (the device list repeats it), so the whole control
+flow -- device-side row cuts, shard copies + rebase, per-shard conversion, set_x, per-stream SpMV, gather -- runs;
+the RCCL broadcast itself needs >= 2 distinct devices and is exercised where they exist."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from benchmark_spmv_using_csr5_amd import handle as H  # noqa: E402
+from benchmark_spmv_using_csr5_amd import matrices as M  # noqa: E402
+from benchmark_spmv_using_csr5_amd import sharding as S  # noqa: E402
+from tests import zoo  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _devices(G):
+    n = torch.cuda.device_count()
+    return [g % n for g in range(G)] if n >= 2 else [0] * G
+
+
+def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None):
+    rp = torch.from_numpy(mat.row_ptr.astype(np.int32)).to(DEV)
+    ci = torch.from_numpy(mat.col.astype(np.int32)).to(DEV)
+    va = torch.from_numpy(val.astype(dtype)).to(DEV)
+    xd = torch.from_numpy(x.astype(dtype)).to(DEV)
+    A = H.MultiGpuHandle(_devices(G), mat.m, mat.n, dtype=np.dtype(dtype).name)
+    assert A.inputCSR(mat.nnz, rp, ci, va) == 0
+    assert A.setSigma(sigma) == 0
+    if slabs is not None:
+        assert A.setOption(6, slabs) == 0
+    assert A.asCSR5() == 0
+    assert A.setX(xd) == 0
+    assert A.fill_y(0x7F) == 0  # a recognisable pattern in the rows SpMV must leave untouched
+    assert A.spmv(1.0) == 0 and A.synchronize() == 0
+    y = A.gather_y()
+    cuts = [A.shard(g).row_lo for g in range(G)] + [A.shard(G - 1).row_hi]
+    nnzs = [A.shard(g).nnz for g in range(G)]
+    bkind = A.shard(0).x_broadcast
+    tails = [A.shard(g).row_lo + A.shard_info(g).tail_partition_start for g in range(G)]
+    # the caller's arrays are copies-from only: still plain CSR
+    assert np.array_equal(ci.cpu().numpy(), mat.col)
+    assert A.destroy() == 0
+    A.close()
+    return y, cuts, nnzs, bkind, tails
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_multi_zoo_exact(oracle, G):
+    poison = np.frombuffer(bytes([0x7F] * 8), dtype=np.float64)[0]
+    for mat in zoo.small_zoo():
+        val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=5, mode="int")
+        ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+        y, cuts, nnzs, bkind, tails = _run_multi(mat, val, x, G)
+        assert cuts == list(S.partition_rows_by_nnz(mat.row_ptr, G)), "device-side cuts == sharding.partition_rows_by_nnz"
+        assert sum(nnzs) == mat.nnz
+        lens = np.diff(mat.row_ptr)
+        nonempty = lens > 0
+        assert np.array_equal(y[nonempty], ref[nonempty]), (mat.name, G)
+        # empty rows before a shard's tail keep the caller's bytes; rows from the tail start on are written (0)
+        rows = np.arange(mat.m)
+        for g in range(G):
+            blk = (rows >= cuts[g]) & (rows < cuts[g + 1]) & ~nonempty
+            before = blk & (rows < tails[g])
+            assert np.all(y[before] == poison), (mat.name, G, g)
+            assert np.all(y[blk & (rows >= tails[g])] == 0), (mat.name, G, g)
+        if G > 1 and torch.cuda.device_count() >= G:
+            assert bkind == 1, "distinct devices: x must travel by the RCCL broadcast"
+
+
+def test_multi_rmat20_eight_row_blocks_on_one_device(oracle):
+    """The 8 nnz-balanced row blocks of one R-MAT 20 (what 8 GPUs would hold), each through its own handle; the
+    concatenated y must equal the full-matrix product exactly, with and without column slabs in the shards."""
+    mat = M.rmat(20, 16, seed=4)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=8, mode="int")
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    nonempty = np.diff(mat.row_ptr) > 0
+    for slabs in (0, 1):
+        y, cuts, nnzs, _, _ = _run_multi(mat, val, x, 8, slabs=slabs)
+        assert np.array_equal(y[nonempty], ref[nonempty]), slabs
+        assert max(nnzs) <= 1.25 * mat.nnz / 8, "row blocks are balanced by non-zeros (power-law rows)"
+
+
+def test_multi_real_data_fp32_and_graph_replay(oracle):
+    mat = zoo.small_zoo()[14]  # scircuit-like, small
+    val, x = M.fill_values(mat.nnz, mat.n, np.float32, seed=3, mode="real")
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val.astype(np.float64), x.astype(np.float64))
+    scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val).astype(np.float64), np.abs(x).astype(np.float64))
+    rp = torch.from_numpy(mat.row_ptr).to(DEV)
+    ci = torch.from_numpy(mat.col).to(DEV)
+    va = torch.from_numpy(val).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    A = H.MultiGpuHandle(_devices(4), mat.m, mat.n, dtype="float32")
+    assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setSigma(-1) == 0 and A.asCSR5() == 0 and A.setX(xd) == 0
+    assert A.timer_start() == 0
+    assert A.spmv_repeat(1.0, 20) == 0
+    ms = A.timer_stop()
+    assert ms > 0
+    y = A.gather_y().astype(np.float64)
+    assert np.all(np.abs(y - ref) <= 1e-5 * np.maximum(scale, 1.0))  # fp32 bar of the single-GPU tests
+    A.destroy()
+    A.close()

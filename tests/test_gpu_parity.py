@@ -404,6 +404,26 @@ def test_large_rmat_size_independent_properties(scale):
             torch.cuda.synchronize()
             assert torch.equal(mat.col, col0) and torch.equal(val, val0)
             A.close()
+    # real-valued data at full size, default options (column slabs + hot table where the auto rule picks them):
+    # |y - y_ref| <= 1e-12 * sum|a x| against the independent device product, and bit-reproducible run to run
+    valr = torch.rand(mat.nnz, generator=g, device=DEV, dtype=torch.float64) * 2 - 1
+    xr = torch.rand(mat.n, generator=g, device=DEV, dtype=torch.float64) * 2 - 1
+    crow, ccol = mat.row_ptr.to(torch.int64), mat.col.to(torch.int64)
+    refr = torch.sparse_csr_tensor(crow, ccol, valr, size=(mat.m, mat.n)) @ xr
+    scale_r = torch.sparse_csr_tensor(crow, ccol, valr.abs(), size=(mat.m, mat.n)) @ xr.abs()
+    del crow, ccol
+    A = H.anonymouslibHandle(mat.m, mat.n)
+    assert A.inputCSR(mat.nnz, mat.row_ptr, mat.col, valr) == 0 and A.setX(xr) == 0
+    assert A.setSigma(H.ANONYMOUSLIB_AUTO_TUNED_SIGMA) == 0 and A.asCSR5() == 0
+    assert A.info().column_slabs >= 8, "the auto rule turns the slab structure on for R-MAT"
+    y1 = torch.zeros(mat.m, dtype=torch.float64, device=DEV)
+    y2 = torch.zeros(mat.m, dtype=torch.float64, device=DEV)
+    assert A.spmv(1.0, y1) == 0 and A.spmv(1.0, y2) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    assert bool(((y1 - refr).abs() <= 1e-12 * torch.clamp(scale_r, min=1.0))[nonempty].all())
+    assert A.destroy() == 0
+    A.close()
 
 
 def test_autotune_sigma(oracle):
@@ -565,6 +585,91 @@ def test_coupled_power_iteration_single_gpu(oracle):
     assert abs(float(lam) - lam_ref) < 1e-9 * abs(lam_ref)
     run.state["A"].destroy()
     run.state["A"].close()
+
+
+@pytest.mark.gpu
+def test_coupled_steps_without_normalisation_define_empty_rows(oracle):
+    """x_{k+1} = A x_k EXACTLY, three raw steps on a matrix whose rows are half empty, starting from ping-pong
+    buffers full of non-zero garbage: the slot of an empty row must become 0, not keep what it held two steps ago
+    (the library zeroes empty rows for the coupled path, CSR5HIP_OPT_ZERO_EMPTY_ROWS)."""
+    import torch
+    from benchmark_spmv_using_csr5_amd import sharding as S
+    dev = torch.device("cuda:0")
+    mat = M.rmat(scale=11, edge_factor=4, seed=9)
+    assert (np.diff(mat.row_ptr) == 0).mean() > 0.3
+    val, x0 = M.fill_values(mat.nnz, mat.n, np.float64, seed=6, mode="int")
+    val = (val % 3).astype(np.float64)
+    cp = S.CoupledSpmv(mat.row_ptr, mat.col, val, mat.n, 0, 1)
+    run = S.hip_coupled_spmv(dev)
+    a = torch.from_numpy(cp.layout.to_padded(x0)).to(dev)
+    b = torch.full_like(a, 12345.0)  # stale contents of the other buffer
+    xk, _ = cp.power_iteration(run, a, b, iters=3, normalise=False)
+    torch.cuda.synchronize()
+    x = x0.copy()
+    for _ in range(3):
+        x = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    assert np.array_equal(cp.layout.from_padded(xk.cpu().numpy()), x)
+    run.state["A"].destroy()
+    run.state["A"].close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("sigma", [4, 16])
+def test_fused_long_run_path_deterministic(oracle, sigma, dtype):
+    """Rows spanning MORE than 64 tiles take the parked-partial path of the fused kernel (carry_meta bit 26 +
+    k_calibrate<LONG_ONLY>): one row of 70 * 64 * sigma non-zeros between short rows, and a 10 M-nnz hub row.
+    Fused and two-pass must agree bit for bit on real data (same summation order by construction), both within the
+    tolerance of the oracle, and exactly on integer data."""
+    T = 64 * sigma
+    cases = [[3, 0, 70 * T + 17, 5, 1, 0, 2], [1] * 50 + [66 * T] + [2] * 30 + [65 * T + 1, 0, 7]]
+    if sigma == 16 and dtype == np.float64:
+        cases.append([2, 10_000_000, 1, 0, 4])
+    for k, lens in enumerate(cases):
+        rng = np.random.default_rng(100 + k)
+        mat = M.csr_from_row_lengths(np.asarray(lens), 50000, rng, band=0.0, name=f"longrun{k}")
+        for fill in ("int", "real"):
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=3, mode=fill)
+            if dtype == np.float32 and fill == "int":
+                val, x = (val % 2).astype(np.float32), (x % 2).astype(np.float32)
+            if mat.nnz > 5_000_000:
+                exp = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x).astype(np.float64)
+            else:
+                fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+                exp = _expected_y(oracle, fmt, mat, x, 0.0).astype(np.float64)
+            scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val).astype(np.float64), np.abs(x).astype(np.float64))
+            _, _, _, yf = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, y0=0.0, repeat=2, slabs=0)
+            _, _, _, yt = _run(mat, val, x, sigma, H.SPMV_TWO_PASS, dtype=dtype, y0=0.0, slabs=0)
+            assert np.array_equal(yf[0], yf[1]) and np.array_equal(yf[0], yt[0]), (k, fill, "fused == two-pass, bit for bit")
+            tol = (1e-12 if dtype == np.float64 else 2e-5) * np.maximum(scale, 1.0)
+            nonempty = np.diff(mat.row_ptr) > 0
+            if fill == "int" and (dtype == np.float64 or mat.nnz < 2 ** 23):
+                assert np.array_equal(yf[0].astype(np.float64)[nonempty], exp[nonempty]), (k, fill)
+            else:
+                assert np.all(np.abs(yf[0].astype(np.float64) - exp)[nonempty] <= tol[nonempty]), (k, fill)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["scircuit", "webbase", "nd24k"])
+def test_full_size_real_valued_within_tolerance(oracle, workload):
+    """One real-valued (uniform(-1,1)) FULL-SIZE run per single-GPU BASELINE config against the oracle's CSR5 SpMV:
+    fp64 within 1e-6 relative where the row is not ill-conditioned and 1e-12 * sum|a x| everywhere; fp32 (nd24k):
+    1e-5 * sum|a x|.  Default options (so the column-slab path where the auto rule selects it)."""
+    dtype = np.float32 if workload == "nd24k" else np.float64
+    mat = {"scircuit": M.scircuit_like, "webbase": M.webbase_like, "nd24k": M.nd24k_like}[workload]()
+    val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=21, mode="real")
+    sigma = _capi.load().csr5hip_auto_sigma(mat.m, mat.nnz, 0)
+    fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+    exp = _expected_y(oracle, fmt, mat, x, 0.0).astype(np.float64)
+    scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val).astype(np.float64), np.abs(x).astype(np.float64))
+    _, _, _, ys = _run(mat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, dtype=dtype, y0=0.0, repeat=2)
+    y = ys[0].astype(np.float64)
+    assert np.array_equal(ys[0], ys[1])
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    assert np.all(np.abs(y - exp) <= tol * np.maximum(scale, 1.0))
+    if dtype == np.float64:
+        well = np.abs(exp) >= 1e-3 * scale  # rows without heavy cancellation: the 1e-6 relative bar of north_star
+        assert np.all(np.abs(y - exp)[well] <= 1e-6 * np.abs(exp)[well])
 
 
 # ---------------------------------------------------------------------------------------------------
