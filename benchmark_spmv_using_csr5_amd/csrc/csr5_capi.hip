@@ -615,7 +615,10 @@ static int slab_count_for(const csr5hip_handle_s *h)
     const long long covered_pct = h->xwin_covered * 100 / ((long long)(h->g.p - 1) * h->g.tile_elems);
     if (covered_pct >= 50)
         return 0;
-    return xbytes < 16LL * 1024 * 1024 ? 8 : (xbytes < 64LL * 1024 * 1024 ? 16 : 32);
+    // one slab per XCD while a slab's share of x stays within a few L2 sizes; two per XCD beyond (measured with the hot
+    // table on R-MAT 20 / 22 / 24, x = 8 / 34 / 134 MB: 8 slabs 73 / 329 / 1564 us, 16 slabs 85 / 357 / 1505 us, 32 slabs
+    // 119 / 441 / 1674 us: every further round costs a table refill and a workgroup barrier)
+    return xbytes < 64LL * 1024 * 1024 ? 8 : 16;
 }
 
 static int build_slabs(csr5hip_handle h)

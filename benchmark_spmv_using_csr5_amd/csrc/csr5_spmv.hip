@@ -441,6 +441,8 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
 #if !(defined(CSR5_ABLATE) && (CSR5_ABLATE & 32))
         spill_v = val[spill_pos];
 #endif
+        if constexpr (SIGMA > 0 && !HOT)
+            __builtin_amdgcn_sched_barrier(0); // keep it AHEAD of the value stream (see the pin below)
     }
 
     // this lane's sigma elements (coalesced: lane stride 1 at every step)
@@ -469,6 +471,13 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             mt_next_x = __builtin_amdgcn_readlane(hw, 4);
             tp0 = __builtin_amdgcn_readlane(hw, 5);
             tp1 = __builtin_amdgcn_readlane(hw, 6);
+            // Pin the two spill loads to the first round trip: they are consumed only under `L > 0`, and the
+            // optimiser otherwise sinks them below that test (behind the header's arrival: a third dependent round
+            // trip for every tile with a short spill).  Costs nothing: vector loads return in order and these two
+            // were requested right after the column words the gathers below wait for anyway.
+            // (The persistent hot kernel keeps them up front by itself and runs 3-7 % slower with the pin: measured.)
+            if constexpr (!HOT)
+                asm volatile("" : "+v"(spill_c), "+v"(spill_v));
         }
         VT xv[NREG];
         if constexpr (XWIN) {
