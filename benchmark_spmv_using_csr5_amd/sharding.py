@@ -236,6 +236,43 @@ class CoupledSpmv:
         return a, rayleigh
 
 
+    def power_iteration_graph(self, local_spmv, x0_padded, scratch, iters: int, normalise: bool = True):
+        """The same iteration replayed from ONE hipGraph (torch.cuda.CUDAGraph is plumbing): two coupled steps
+        (a -> b -> a: SpMV kernels, the in-place all-gather, dot, norm, scale) are captured once on a side stream and
+        replayed iters/2 times -- no per-kernel host launch cost, no host synchronisation inside the loop.  `iters`
+        must be even.  Returns (x, rayleigh) like power_iteration.  `local_spmv` must not have been used on another
+        stream before (the handle is bound to the stream of its first call)."""
+        import torch
+
+        if iters % 2:
+            raise ValueError("power_iteration_graph replays pairs of steps: iters must be even")
+        a, b = x0_padded, scratch
+        side = torch.cuda.Stream(device=a.device)
+        side.wait_stream(torch.cuda.current_stream(a.device))
+        ray = torch.zeros((), dtype=a.dtype, device=a.device)
+
+        def pair():
+            for src, dst in ((a, b), (b, a)):
+                self.step(local_spmv, src, dst)
+                ray.copy_(torch.dot(src, dst) / torch.dot(src, src))
+                if normalise:
+                    dst.mul_(1.0 / torch.linalg.vector_norm(dst))
+
+        start = a.clone()
+        with torch.cuda.stream(side):
+            pair()  # warm-up outside the capture: binds the handle to `side`, creates its CSR5 form
+            a.copy_(start)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            pair()
+        a.copy_(start)
+        torch.cuda.synchronize(a.device)
+        for _ in range(iters // 2):
+            graph.replay()
+        return a, ray
+
+
 def hip_coupled_spmv(device, sigma: int = -1, mode: int = 1):
     """Factory for CoupledSpmv.step on a GPU: one CSR5 handle for the block, y written in place."""
     import torch

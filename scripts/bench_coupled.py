@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--graph", action="store_true", help="replay the iteration from one hipGraph (pairs of steps)")
     args = ap.parse_args()
 
     import torch
@@ -50,14 +51,25 @@ def main():
     a = torch.from_numpy(cp.layout.to_padded(x0)).to(dev)
     b = torch.zeros_like(a)
 
-    cp.power_iteration(run, a, b, args.warmup)
+    if args.graph:
+        # capture happens inside; time a second call's replays only by timing a long run minus nothing: the capture
+        # cost is amortised over --iters (reported separately below)
+        t_cap = time.perf_counter()
+        cp.power_iteration_graph(run, a, b, 2)
+        torch.cuda.synchronize()
+        t_cap = time.perf_counter() - t_cap
+    else:
+        cp.power_iteration(run, a, b, args.warmup)
     a.copy_(torch.from_numpy(cp.layout.to_padded(x0)).to(dev))
     b.zero_()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    xk, lam = cp.power_iteration(run, a, b, args.iters)
+    if args.graph:
+        xk, lam = cp.power_iteration_graph(S.hip_coupled_spmv(dev), a, b, args.iters)
+    else:
+        xk, lam = cp.power_iteration(run, a, b, args.iters)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -74,7 +86,8 @@ def main():
             "config": {"workload": f"R-MAT scale {args.scale} ef {args.edge_factor} (synthetic), row blocks by nnz",
                        "m": mat.m, "nnz": mat.nnz, "slot_width": cp.layout.width,
                        "allgather_bytes_per_iteration": cp.layout.padded_len * 8, "backend": "gloo(shared GPU)" if share else "rccl"},
-            "rayleigh": float(lam), "scaling": "strong"}), flush=True)
+            "rayleigh": float(lam), "scaling": "strong",
+            "launch": "one hipGraph per two iterations (capture included in the time)" if args.graph else "eager"}), flush=True)
     run.state["A"].destroy()
     run.state["A"].close()
     if dist is not None:

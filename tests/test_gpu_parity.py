@@ -588,6 +588,31 @@ def test_coupled_power_iteration_single_gpu(oracle):
 
 
 @pytest.mark.gpu
+def test_coupled_iteration_from_one_hipgraph(oracle):
+    """A coupled iteration (SpMV -> [all-gather] -> dot, norm, scale) captured in ONE hipGraph and replayed: same
+    result as the eager loop, bit for bit."""
+    import torch
+    from benchmark_spmv_using_csr5_amd import sharding as S
+    dev = torch.device("cuda:0")
+    mat = M.rmat(scale=12, edge_factor=8, seed=5)
+    val, x0 = M.fill_values(mat.nnz, mat.n, np.float64, seed=6, mode="pos")
+    x0 = x0 / np.linalg.norm(x0)
+    cp = S.CoupledSpmv(mat.row_ptr, mat.col, val, mat.n, 0, 1)
+    eager = S.hip_coupled_spmv(dev)
+    a = torch.from_numpy(cp.layout.to_padded(x0)).to(dev)
+    xe, lam_e = cp.power_iteration(eager, a, torch.zeros_like(a), iters=10)
+    torch.cuda.synchronize()
+    graphed = S.hip_coupled_spmv(dev)
+    a2 = torch.from_numpy(cp.layout.to_padded(x0)).to(dev)
+    xg, lam_g = cp.power_iteration_graph(graphed, a2, torch.zeros_like(a2), iters=10)
+    torch.cuda.synchronize()
+    assert torch.equal(xe, xg) and float(lam_e) == float(lam_g)
+    for run in (eager, graphed):
+        run.state["A"].destroy()
+        run.state["A"].close()
+
+
+@pytest.mark.gpu
 def test_coupled_steps_without_normalisation_define_empty_rows(oracle):
     """x_{k+1} = A x_k EXACTLY, three raw steps on a matrix whose rows are half empty, starting from ping-pong
     buffers full of non-zero garbage: the slot of an empty row must become 0, not keep what it held two steps ago
