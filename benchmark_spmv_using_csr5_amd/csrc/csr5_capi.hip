@@ -7,6 +7,7 @@
 //   asCSR / destroy undo the transpose and drop the CSR5 arrays                     (:78-102, :286-291)
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -677,14 +678,27 @@ static int build_slabs(csr5hip_handle h)
     // LDS hot table for the persistent kernel (fused mode, S a multiple of the 8 XCDs, register budget of 16 waves/CU)
     bool hot = false;
     int hot_capacity = 0;
-    if (h->hot_request != 0 && S % NUM_XCD == 0 && h->opt.mode == 1 && g.sigma >= 4 &&
-        g.sigma <= (h->value_type == CSR5HIP_F64 ? 20 : 32) && (long long)g.n * (long long)h->vsize() <= 0x7FFFFFFFLL) {
+    const int hot_sigma = hot_child_sigma(g.sigma, (int)h->vsize());
+    const int hot_T = OMEGA * hot_sigma;
+    const int hot_p = (int)(((long long)g.nnz + hot_T - 1) / hot_T);
+    if (h->hot_request != 0 && S % NUM_XCD == 0 && h->opt.mode == 1 && hot_sigma >= 4 && hot_p >= 2 &&
+        (long long)g.n * (long long)h->vsize() <= 0x7FFFFFFFLL) {
         int dev = 0, lds_max = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-        int lds = HOT_LDS_BYTES < lds_max ? HOT_LDS_BYTES : lds_max;
+        // the per-wavefront y-compaction regions sit behind the table (k_spmv_hot)
+        int lds = lds_max - HOT_WAVES * HOT_WAVE_LDS;
+        lds = lds > HOT_LDS_BYTES ? HOT_LDS_BYTES : lds;
+        if (const char *e = getenv("CSR5HIP_EXPERIMENT_HOT_BYTES")) // experiment knob (scripts/experiments), never set by the product
+            lds = atoi(e) > 1024 && atoi(e) < lds ? atoi(e) : lds;
         hot_capacity = lds / (int)h->vsize();
-        const int min_count = 48; // a slot is staged by each of the ~32 workgroups of the slab's XCD in every SpMV
+        // Column use counts come from a sample of the non-zeros (one 64-element chunk in `stride`): ~4 M samples are
+        // plenty to rank columns, and a full count serialises on the very columns it is looking for.
+        int stride = (int)(g.nnz / (4LL * 1024 * 1024));
+        stride = stride < 1 ? 1 : (stride > 32 ? 32 : stride);
+        // a slot is staged by each of the ~32 workgroups of the slab's XCD in every SpMV: it must be used more often
+        int min_count = 48 / stride;
+        min_count = min_count < 2 ? 2 : min_count;
         struct HotTemps {
             void *cnt = nullptr, *hotmap = nullptr, *chist = nullptr, *thr = nullptr, *covered = nullptr;
             ~HotTemps()
@@ -709,7 +723,7 @@ static int build_slabs(csr5hip_handle h)
         HIP_TRY(hipMemsetAsync(ht.chist, 0, hb, s));
         HIP_TRY(hipMemsetAsync(ht.covered, 0, 8, s));
         HIP_TRY(hipMemsetAsync(h->b_hot_cols.ptr, 0, (size_t)S * hot_capacity * 4, s));
-        HIP_TRY(slab_hot_select(g.n, g.nnz, g.p, g.tile_elems, S, bits, h->slab_shift, hot_capacity, min_count,
+        HIP_TRY(slab_hot_select(g.n, g.nnz, g.p, hot_p, hot_T, S, bits, h->slab_shift, hot_capacity, min_count, stride,
                                 (const int32_t *)h->b_col2.ptr, (const uint32_t *)t.hist, (uint32_t *)ht.cnt,
                                 (int32_t *)ht.hotmap, (uint32_t *)ht.chist, (uint32_t *)ht.thr, (int32_t *)h->b_hot_cols.ptr,
                                 (int32_t *)h->b_hot_count.ptr, (int32_t *)h->b_hot_tile0.ptr, (int32_t *)h->b_slab_off.ptr,
@@ -717,11 +731,12 @@ static int build_slabs(csr5hip_handle h)
         unsigned long long covered = 0;
         HIP_TRY(hipMemcpyAsync(&covered, ht.covered, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        h->hot_cover_pct = (int)(covered * 100 / (unsigned long long)g.nnz);
+        h->hot_cover_pct = (int)(covered * (unsigned long long)stride * 100 / (unsigned long long)g.nnz); // estimate
+        h->hot_cover_pct = h->hot_cover_pct > 100 ? 100 : h->hot_cover_pct;
         // worth it when a good part of the gathers leaves the vector memory path (measured, scripts/gpu_hot.sh)
         hot = h->hot_request == 2 || h->hot_cover_pct >= 25;
         if (hot) {
-            HIP_TRY(slab_hot_encode(g.nnz, g.tile_elems, g.p, S, (const int32_t *)h->b_slab_off.ptr,
+            HIP_TRY(slab_hot_encode(g.nnz, hot_T, hot_p, S, (const int32_t *)h->b_slab_off.ptr,
                                     (const int32_t *)h->b_hot_tile0.ptr, (const int32_t *)ht.hotmap, (int32_t *)h->b_col2.ptr, s));
             HIP_TRY(hipStreamSynchronize(s));
         }
@@ -748,7 +763,7 @@ static int build_slabs(csr5hip_handle h)
     c->d.hot_slabs = S;
     c->d.hot_capacity = hot_capacity;
     int rc = csr5hip_input_csr(c, g.nnz, (int32_t *)h->b_row_ptr2.ptr, (int32_t *)h->b_col2.ptr, h->b_val2.ptr);
-    c->sigma_request = g.sigma;
+    c->sigma_request = hot ? hot_sigma : g.sigma;
     if (rc == CSR5HIP_SUCCESS)
         rc = csr5hip_as_csr5(c);
     if (rc != CSR5HIP_SUCCESS) {

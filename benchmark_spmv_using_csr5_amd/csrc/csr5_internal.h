@@ -102,8 +102,8 @@ hipError_t slab_segments(int nnz, const unsigned long long *key2, void *tmp, siz
                          unsigned int *d_count, hipStream_t s);
 hipError_t slab_tables(int m2, int nnz, int S, int32_t *row_ptr2, const unsigned long long *key2, uint32_t *mask,
                        uint32_t *base, hipStream_t s);
-hipError_t slab_hot_select(int n, int nnz, int p, int T, int S, int bits, int shift, int capacity, int min_count,
-                           const int32_t *col2, const uint32_t *chunk_start, uint32_t *cnt, int32_t *hotmap,
+hipError_t slab_hot_select(int n, int nnz, int p_hist, int p, int T, int S, int bits, int shift, int capacity,
+                           int min_count, int sample_stride, const int32_t *col2, const uint32_t *chunk_start, uint32_t *cnt, int32_t *hotmap,
                            uint32_t *chist, uint32_t *thr, int32_t *hot_cols, int32_t *hot_count, int32_t *tile0,
                            int32_t *slab_off, unsigned long long *covered, hipStream_t s);
 hipError_t slab_hot_encode(int nnz, int T, int p, int S, const int32_t *slab_off, const int32_t *tile0,
@@ -122,7 +122,16 @@ struct SpmvOptions {
     int long_runs;   // resolved: the matrix has rows spanning > RUN_SERIAL_MAX tiles (fused mode adds k_calibrate)
     int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_hot + tail launch
 };
-constexpr int HOT_LDS_BYTES = 128 * 1024;  // LDS table of hot x entries per workgroup (k_spmv_hot)
+constexpr int HOT_LDS_BYTES = 128 * 1024;  // LDS table of hot x entries per workgroup (k_spmv_hot) without y compaction
+constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_hot (16 wavefronts)
+constexpr int HOT_WAVES = 16;
+// child sigma of a hot slab structure: small enough for the y-compaction region (measured: the hot kernel is flat in
+// sigma between 8 and 16, R-MAT 22 320 / 324 / 329 us at 8 / 12 / 16)
+constexpr int hot_child_sigma(int parent_sigma, int value_size)
+{
+    const int cap = HOT_WAVE_LDS / (OMEGA * value_size);
+    return parent_sigma < cap ? parent_sigma : cap;
+}
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s);
 
