@@ -208,55 +208,82 @@ k_slab_tables(int m2, int nnz, int S, const int32_t *__restrict__ row_ptr2, cons
         base[(size_t)(r >> 6) * S + k] = (uint32_t)s;
 }
 
-// y[r] = sum of the partials of row r, in slab order.  One thread per row, one wavefront per 64-row block.
+// y[r] = sum of the partials of row r, in slab order.  One wavefront per COMBINE_BLOCKS consecutive 64-row blocks, one
+// thread per row of a block: the mask and base words of all its blocks are requested first, then the partials (one
+// block per wavefront was two short dependent round trips per wave: 262 k waves of them on R-MAT 24, 200 us).
+constexpr int COMBINE_BLOCKS = 4;
+
 template <typename VT, int S>
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_slab_combine(int m, int tail_start, int zero_empty, const uint32_t *__restrict__ mask,
                const uint32_t *__restrict__ base, const VT *__restrict__ P, VT *__restrict__ y)
 {
-    const int r = blockIdx.x * SLAB_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & (OMEGA - 1);
-    const bool valid = r < m;
-    unsigned long long mk = 0;
-    if (valid) {
-        if constexpr (S == 64) {
-            mk = (unsigned long long)mask[2 * (size_t)r] | ((unsigned long long)mask[2 * (size_t)r + 1] << 32);
-        } else {
-            const unsigned long long bit = (unsigned long long)r * S;
-            const uint32_t w = mask[bit >> 5] >> (bit & 31);
-            mk = S == 32 ? w : (w & ((1u << (S & 31)) - 1u));
-        }
-    }
-    if (!__ballot(mk != 0)) {
-        if (valid && (zero_empty || r >= tail_start))
-            y[r] = 0;
-        return;
-    }
-    const uint32_t bv = lane < S ? base[(size_t)(r >> 6) * S + lane] : 0u;
+    const int wave = blockIdx.x * (SLAB_BLOCK / OMEGA) + (threadIdx.x >> 6);
+    const int r0 = wave * COMBINE_BLOCKS * OMEGA + lane;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    VT sum = 0;
-    constexpr int CH = S < 16 ? S : 16; // loads in flight per lane
+    unsigned long long mk[COMBINE_BLOCKS];
+    uint32_t bv[COMBINE_BLOCKS];
+    // every mask / base word of the wavefront's blocks in ONE round trip: unconditional loads at clamped addresses
+    // (a branch per block made the compiler wait for each block's words before it requested the next ones)
+    uint32_t w0[COMBINE_BLOCKS], w1[COMBINE_BLOCKS];
+    const int last_block = (m - 1) >> 6;
 #pragma unroll
-    for (int k0 = 0; k0 < S; k0 += CH) {
-        VT part[CH];
+    for (int b = 0; b < COMBINE_BLOCKS; b++) {
+        const int r = r0 + b * OMEGA;
+        const int rc = r < m ? r : m - 1;
+        if constexpr (S == 64) {
+            w0[b] = mask[2 * (size_t)rc];
+            w1[b] = mask[2 * (size_t)rc + 1];
+        } else {
+            w0[b] = mask[((unsigned long long)rc * S) >> 5];
+            w1[b] = 0;
+        }
+        const int blk = (r - lane) >> 6; // wave-uniform
+        bv[b] = base[(size_t)(blk < last_block ? blk : last_block) * S + (lane < S ? lane : 0)];
+    }
 #pragma unroll
-        for (int j = 0; j < CH; j++) {
-            const int k = k0 + j;
-            const bool bit = (mk >> k) & 1ull;
-            const unsigned long long b = __ballot(bit);
-            const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)bv, k) + (uint32_t)__popcll(b & lt);
-            part[j] = bit ? P[idx] : (VT)0;
+    for (int b = 0; b < COMBINE_BLOCKS; b++) {
+        const int r = r0 + b * OMEGA;
+        if constexpr (S == 64) {
+            mk[b] = (unsigned long long)w0[b] | ((unsigned long long)w1[b] << 32);
+        } else {
+            const uint32_t w = w0[b] >> (((unsigned long long)(r < m ? r : m - 1) * S) & 31);
+            mk[b] = S == 32 ? w : (w & ((1u << (S & 31)) - 1u));
+        }
+        if (r >= m)
+            mk[b] = 0;
+    }
+    // up to 32 partial loads in flight per lane: all slabs of GROUP blocks at once, no branch between them
+    constexpr int GROUP = S >= 32 ? 1 : (32 / S < COMBINE_BLOCKS ? 32 / S : COMBINE_BLOCKS);
+#pragma unroll
+    for (int b0 = 0; b0 < COMBINE_BLOCKS; b0 += GROUP) {
+        VT part[GROUP][S];
+#pragma unroll
+        for (int g = 0; g < GROUP; g++) {
+#pragma unroll
+            for (int k = 0; k < S; k++) {
+                const bool bit = (mk[b0 + g] >> k) & 1ull;
+                const unsigned long long bl = __ballot(bit);
+                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)bv[b0 + g], k) + (uint32_t)__popcll(bl & lt);
+                part[g][k] = bit ? P[idx] : (VT)0;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < CH; j++)
-            sum += part[j];
+        for (int g = 0; g < GROUP; g++) {
+            const int r = r0 + (b0 + g) * OMEGA;
+            VT sum = 0;
+#pragma unroll
+            for (int k = 0; k < S; k++)
+                sum += part[g][k];
+            if (r < m) {
+                if (mk[b0 + g])
+                    y[r] = sum;
+                else if (zero_empty || r >= tail_start)
+                    y[r] = 0;
+            }
+        }
     }
-    if (!valid)
-        return;
-    if (mk)
-        y[r] = sum;
-    else if (zero_empty || r >= tail_start)
-        y[r] = 0;
 }
 
 // ---- hot columns of every slab (LDS table of the persistent kernel k_spmv_hot, csr5_spmv.hip) ---------------------
@@ -463,7 +490,8 @@ template <typename VT>
 static hipError_t combine_typed(int m, int tail_start, int zero_empty, int S, const uint32_t *mask, const uint32_t *base,
                                 const void *P, void *y, hipStream_t s)
 {
-    const dim3 grid((m + SLAB_BLOCK - 1) / SLAB_BLOCK), block(SLAB_BLOCK);
+    const int rows_per_block = SLAB_BLOCK * COMBINE_BLOCKS;
+    const dim3 grid((m + rows_per_block - 1) / rows_per_block), block(SLAB_BLOCK);
     switch (S) {
 #define CSR5_SLAB_CASE(N)                                                                                              \
     case N:                                                                                                            \
