@@ -809,6 +809,9 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
 // 128-byte L2->L1 line per lane); only the cold remainder goes through the vector memory path.
 // Correct under ANY placement or scheduling: the table only depends on the slab, every tile is processed by exactly
 // one wavefront, and the carry protocol never waits.
+// (Tried and dropped: a software pipeline with the NEXT tile's column / value / descriptor loads in flight during the
+// current tile's computation -- 128 VGPRs, same time to the microsecond on R-MAT 22 and 24: the kernel is bound by the
+// bytes it moves, 4.1-4.6 TB/s, not by per-wave latency.)
 struct HotParams {
     int slabs, rounds, capacity;     // S, S / 8, table capacity in elements
     const int32_t *cols;             // [slabs * capacity] hot column of every table slot
@@ -1004,9 +1007,13 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
 #define CSR5_CASE(S)                                                                               \
     case S:                                                                                        \
         if constexpr (FUSED) {                                                                     \
-            if (opt.hot)                                                                           \
-                return opt.stream_nt ? launch_hot<VT, S, true>(g, d, x, y, opt, s)                 \
-                                     : launch_hot<VT, S, false>(g, d, x, y, opt, s);               \
+            if (opt.hot) {                                                                         \
+                if constexpr (hot_ldsy<VT, S>()) /* a hot child is converted at sigma <= 8 (fp64) / 16 (fp32) */ \
+                    return opt.stream_nt ? launch_hot<VT, S, true>(g, d, x, y, opt, s)             \
+                                         : launch_hot<VT, S, false>(g, d, x, y, opt, s);           \
+                else                                                                               \
+                    return hipErrorInvalidValue;                                                   \
+            }                                                                                      \
             if (opt.x_window)                                                                      \
                 return opt.lds_y ? launch_one<VT, S, FUSED, true, true>(g, d, x, y, opt, s)        \
                                  : launch_one<VT, S, FUSED, true, false>(g, d, x, y, opt, s);      \
