@@ -112,7 +112,8 @@ struct csr5hip_handle_s {
     Buffer b_arena;
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
-    uint32_t scalar_words[2] = {0, 0}; // landing zone of the two 4-byte reads of the conversion
+    uint32_t scalar_words[2] = {0, 0}; // landing zone of the two 4-byte reads of the conversion (checkpoint loading)
+    uint32_t *host_words = nullptr;    // 8 pinned, device-visible words the last conversion kernel exports into
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t phase[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // asCSR5 phase boundaries
@@ -230,6 +231,8 @@ int csr5hip_free(csr5hip_handle h)
     h->drop_graphs();
     release_slabs(h);
     h->b_arena.release();
+    if (h->host_words)
+        (void)hipHostFree(h->host_words);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t e : h->phase)
@@ -474,18 +477,22 @@ static int derive_kernel_tables(csr5hip_handle h)
 {
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
+    if (!h->host_words) {
+        HIP_TRY(hipHostMalloc((void **)&h->host_words, 32, hipHostMallocDefault));
+        memset(h->host_words, 0, 32);
+    }
     HIP_TRY(launch_carry_meta(g, h->d, s));
     HIP_TRY(launch_tile_window(g, h->d, (int)h->vsize(), s));
-    HIP_TRY(launch_tile_hdr(g, h->d, s));
-    uint32_t stats[4] = {0, 0, 0, 0}; // x-window tiles, covered non-zeros, long runs, gather lines
-    HIP_TRY(hipMemcpyAsync(stats, h->d.counters, 16, hipMemcpyDeviceToHost, s));
-    HIP_TRY(read_format_scalars(h, false)); // tail start, number of offsets: same host round trip
+    HIP_TRY(launch_tile_hdr(g, h->d, h->host_words, s)); // exports the host's six words (no device-to-host copies)
     HIP_TRY(hipStreamSynchronize(s));
+    const uint32_t *w = h->host_words;
+    h->scalar_words[0] = w[0];
+    h->scalar_words[1] = w[1];
     finish_format_scalars(h);
-    h->xwin_tiles = (int)stats[0];
-    h->xwin_covered = (long long)stats[1];
-    h->xwin_lines = (long long)stats[3];
-    h->opt.long_runs = stats[2] != 0;
+    h->xwin_tiles = (int)w[2];
+    h->xwin_covered = (long long)w[3];
+    h->xwin_lines = (long long)w[5];
+    h->opt.long_runs = w[4] != 0;
     return CSR5HIP_SUCCESS;
 }
 

@@ -416,11 +416,25 @@ __global__ void __launch_bounds__(256) k_window_stats(int tiles, const uint32_t 
 // (one vector load instead of three): words 0..3 = carry_meta[t], 4 = carry_meta[t+1].x,
 // 5..6 = tile_ptr[t], tile_ptr[t+1] (copies; the format arrays themselves stay untouched).
 // ---------------------------------------------------------------------------------------------
+// Thread 0 also exports the six words the host needs from the conversion -- tail start, number of offsets
+// (anonymouslib_cuda.h:165-167, format_cuda.h:331-343) and the four conversion statistics -- straight into pinned,
+// device-visible host memory: this is the LAST kernel of the conversion, so everything it reads is final, and the host
+// reads them after its one synchronisation without three 4-to-16-byte device-to-host copies (7.6 us each).
 __global__ void __launch_bounds__(FMT_BLOCK) k_tile_hdr(Geometry g, const uint32_t *__restrict__ tile_ptr,
                                                     const uint4 *__restrict__ carry_meta,
-                                                    uint32_t *__restrict__ hdr)
+                                                    uint32_t *__restrict__ hdr, const int32_t *__restrict__ offset_ptr,
+                                                    const uint32_t *__restrict__ counters,
+                                                    uint32_t *__restrict__ host_words)
 {
     const int t = blockIdx.x * FMT_BLOCK + threadIdx.x;
+    if (t == 0 && host_words) {
+        host_words[0] = tile_ptr[g.p - 1];
+        host_words[1] = (uint32_t)offset_ptr[g.p];
+        host_words[2] = counters[0];
+        host_words[3] = counters[1];
+        host_words[4] = counters[2];
+        host_words[5] = counters[3];
+    }
     if (t >= g.p)
         return;
     const uint4 m = carry_meta[t];
@@ -556,12 +570,12 @@ hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int valu
     return hipGetLastError();
 }
 
-hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, uint32_t *host_words, hipStream_t s)
 {
     if (g.p <= 0)
         return hipSuccess;
     hipLaunchKernelGGL(k_tile_hdr, dim3(div_up(g.p, FMT_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.tile_ptr,
-                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr);
+                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr, d.offset_ptr, d.counters, host_words);
     return hipGetLastError();
 }
 

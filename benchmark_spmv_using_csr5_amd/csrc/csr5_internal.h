@@ -85,7 +85,7 @@ hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_
                             hipStream_t s);
 hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int value_size, hipStream_t s);
-hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, hipStream_t s);
+hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, uint32_t *host_words, hipStream_t s);
 hipError_t launch_warmup(hipStream_t s);
 // flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)
 hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,

@@ -103,3 +103,23 @@ def test_multi_real_data_fp32_and_graph_replay(oracle):
     assert np.all(np.abs(y - ref) <= 1e-5 * np.maximum(scale, 1.0))  # fp32 bar of the single-GPU tests
     A.destroy()
     A.close()
+
+
+def test_sharding_hip_local_spmv_single_process(oracle):
+    """`sharding.ShardedSpmv.run` with the GPU kernel factory (the per-rank piece of the one-process-per-GPU form):
+    every nnz-balanced row block of one matrix through `hip_local_spmv`, concatenated == the full product."""
+    mat = M.scircuit_like(scale=0.2)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=2, mode="int")
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    xd = torch.from_numpy(x).to(DEV)
+    world = 4
+    parts = []
+    for rank in range(world):
+        sh = S.ShardedSpmv(mat.row_ptr, mat.col, val, mat.n, rank, world)
+        run = S.hip_local_spmv(torch.device(DEV))
+        y = sh.run(xd, run)  # no process group: broadcast_x is a no-op, as on rank 0 of a 1-rank job
+        torch.cuda.synchronize()
+        parts.append(y.cpu().numpy())
+        run.state["A"].destroy()
+        run.state["A"].close()
+    assert np.array_equal(np.concatenate(parts), ref)

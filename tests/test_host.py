@@ -289,3 +289,51 @@ def _build_c_host(out_dir) -> str:
 
 def test_plain_c_host_compiles_and_links(tmp_path):
     assert os.path.exists(_build_c_host(tmp_path))
+
+
+def test_new_option_keys_and_multi_handle_argument_checks():
+    """Host-side checks of the round-2 entry points that need no device: option ranges, multi-handle argument errors."""
+    lib = _capi.load()
+    h = C.c_void_p()
+    assert lib.csr5hip_create(C.byref(h), 10, 10, _capi.F64) == 0
+    assert lib.csr5hip_input_csr(h, 100, None, None, None) == 0
+    for bad in (3, 5, 65, 128, -1):
+        assert lib.csr5hip_set_option(h, _capi.OPT_COLUMN_SLABS, bad) == _capi.INVALID_ARGUMENT
+    for ok in (0, 1, 2, 8, 64):
+        assert lib.csr5hip_set_option(h, _capi.OPT_COLUMN_SLABS, ok) == 0
+    assert lib.csr5hip_set_option(h, _capi.OPT_SLAB_SHIFT, 25) == _capi.INVALID_ARGUMENT
+    assert lib.csr5hip_set_option(h, _capi.OPT_SLAB_SHIFT, 9) == 0
+    assert lib.csr5hip_set_option(h, _capi.OPT_SLAB_HOT, 3) == _capi.INVALID_ARGUMENT
+    assert lib.csr5hip_set_option(h, _capi.OPT_SLAB_HOT, 2) == 0
+    assert lib.csr5hip_set_option(h, _capi.OPT_ZERO_EMPTY_ROWS, 1) == 0
+    info = _capi.Csr5Info()
+    assert lib.csr5hip_get_info(h, C.byref(info)) == 0 and info.column_slabs == 0 and info.slab_hot == 0
+    assert lib.csr5hip_spmv_repeat(h, 1.0, C.c_void_p(8), 3) == _capi.UNSUPPORTED_CSR_SPMV
+    assert lib.csr5hip_free(h) == 0
+    mh = C.c_void_p()
+    devs = (C.c_int * 2)(0, 0)
+    assert lib.csr5hip_multi_create(C.byref(mh), devs, 0, 10, 10, _capi.F64) == _capi.INVALID_ARGUMENT
+    assert lib.csr5hip_multi_create(C.byref(mh), devs, 2, 10, 10, 9) == _capi.UNSUPPORTED_VALUE_TYPE
+    assert lib.csr5hip_multi_spmv(None, 1.0) == _capi.INVALID_ARGUMENT
+    assert lib.csr5hip_spmv_rotate(None, None, 2, 1.0, 4) == _capi.INVALID_ARGUMENT
+
+
+def test_rmat_shards_are_row_blocks_of_one_matrix():
+    """Strong scaling input (BASELINE config 3): the per-shard generator gives every world size the SAME global matrix;
+    the shards are its nnz-balanced row blocks (sharding.partition_rows_by_nnz), generated without materialising it."""
+    torch = pytest.importorskip("torch")
+    full = M.rmat_device_shard(11, 8, seed=3, rank=0, world=1, device="cpu", chunk_log2=12)
+    rp = full.row_ptr.numpy().astype(np.int64)
+    col = full.col.numpy()
+    assert full.m == 1 << 11 and full.nnz == (1 << 11) * 8 and rp[-1] == full.nnz
+    for world in (2, 3, 8):
+        cuts = S.partition_rows_by_nnz(rp, world)
+        lo_rows = 0
+        for rank in range(world):
+            sh = M.rmat_device_shard(11, 8, seed=3, rank=rank, world=world, device="cpu", chunk_log2=12)
+            lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+            assert sh.m == hi - lo and sh.n == full.n
+            assert np.array_equal(sh.row_ptr.numpy().astype(np.int64), rp[lo:hi + 1] - rp[lo])
+            assert np.array_equal(sh.col.numpy(), col[rp[lo]:rp[hi]])
+            lo_rows += sh.m
+        assert lo_rows == full.m
