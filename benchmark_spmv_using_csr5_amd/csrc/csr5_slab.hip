@@ -266,7 +266,11 @@ k_slab_combine(int m, int tail_start, int zero_empty, const uint32_t *__restrict
                 const bool bit = (mk[b0 + g] >> k) & 1ull;
                 const unsigned long long bl = __ballot(bit);
                 const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)bv[b0 + g], k) + (uint32_t)__popcll(bl & lt);
+#if defined(CSR5_COMBINE_ABLATE) && (CSR5_COMBINE_ABLATE & 1) // experiment build only: no partial loads
+                part[g][k] = bit ? (VT)idx : (VT)0;
+#else
                 part[g][k] = bit ? P[idx] : (VT)0;
+#endif
             }
         }
 #pragma unroll
@@ -276,7 +280,12 @@ k_slab_combine(int m, int tail_start, int zero_empty, const uint32_t *__restrict
 #pragma unroll
             for (int k = 0; k < S; k++)
                 sum += part[g][k];
+#if defined(CSR5_COMBINE_ABLATE) && (CSR5_COMBINE_ABLATE & 2) // experiment build only: no y stores
+            asm volatile("" ::"v"(sum));
+            if (r < m && sum == (VT)-12345.678) {
+#else
             if (r < m) {
+#endif
                 if (mk[b0 + g])
                     y[r] = sum;
                 else if (zero_empty || r >= tail_start)
