@@ -667,6 +667,12 @@ static int build_slabs(csr5hip_handle h)
     unsigned int m2 = 0;
     HIP_TRY(hipMemcpyAsync(&m2, t.count, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if ((unsigned long long)m2 * h->vsize() > 0x7FFFFFFFull) {
+        // the combine reads the partial sums through a raw buffer (2-GiB limit): more segments than that only occur
+        // with > 268 M (fp64) non-empty (row, slab) pairs -- fall back to the plain path
+        release_slabs(h);
+        return CSR5HIP_SUCCESS;
+    }
     HIP_TRY(h->b_row_ptr2.reserve(((size_t)m2 + 1) * 4));
     HIP_TRY(slab_segments(g.nnz, (const unsigned long long *)t.key, t.sel_tmp, sel_bytes, (int32_t *)h->b_row_ptr2.ptr,
                           (unsigned int *)t.count, s));
@@ -795,7 +801,8 @@ static hipError_t enqueue_spmv(csr5hip_handle h, void *d_y, hipStream_t s)
         if (e != hipSuccess)
             return e;
         return launch_slab_combine(h->g.m, h->g.tail_start, h->zero_empty, h->slab_S, h->value_type,
-                                   (const uint32_t *)h->b_mask.ptr, (const uint32_t *)h->b_base.ptr, h->b_P.ptr, d_y, s);
+                                   (const uint32_t *)h->b_mask.ptr, (const uint32_t *)h->b_base.ptr, h->b_P.ptr, h->slab_m2,
+                                   d_y, s);
     }
     if (h->zero_empty && h->g.m > 0) {
         // every row that owns a non-zero is overwritten by the kernel; this defines the others

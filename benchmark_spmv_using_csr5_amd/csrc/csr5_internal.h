@@ -110,7 +110,7 @@ hipError_t slab_hot_encode(int nnz, int T, int p, int S, const int32_t *slab_off
                            const int32_t *hotmap, int32_t *col2, hipStream_t s);
 int slab_hot_buckets();
 hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int value_type, const uint32_t *mask,
-                               const uint32_t *base, const void *P, void *y, hipStream_t s);
+                               const uint32_t *base, const void *P, int segments, void *y, hipStream_t s);
 
 // ---- SpMV (csr5_spmv.hip) ----
 struct SpmvOptions {

@@ -216,12 +216,11 @@ constexpr int COMBINE_BLOCKS = 4;
 template <typename VT, int S>
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_slab_combine(int m, int tail_start, int zero_empty, const uint32_t *__restrict__ mask,
-               const uint32_t *__restrict__ base, const VT *__restrict__ P, VT *__restrict__ y)
+               const uint32_t *__restrict__ base, const VT *__restrict__ P, int p_bytes, VT *__restrict__ y)
 {
     const int lane = threadIdx.x & (OMEGA - 1);
     const int wave = blockIdx.x * (SLAB_BLOCK / OMEGA) + (threadIdx.x >> 6);
     const int r0 = wave * COMBINE_BLOCKS * OMEGA + lane;
-    const unsigned long long lt = (1ull << lane) - 1ull;
     unsigned long long mk[COMBINE_BLOCKS];
     uint32_t bv[COMBINE_BLOCKS];
     // every mask / base word of the wavefront's blocks in ONE round trip: unconditional loads at clamped addresses
@@ -254,7 +253,12 @@ k_slab_combine(int m, int tail_start, int zero_empty, const uint32_t *__restrict
         if (r >= m)
             mk[b] = 0;
     }
-    // up to 32 partial loads in flight per lane: all slabs of GROUP blocks at once, no branch between them
+    // up to 32 partial loads in flight per lane: all slabs of GROUP blocks at once, no branch between them.
+    // Index arithmetic is the larger half of this kernel (ablation: 106 of 193 us on R-MAT 24), so it is kept to the
+    // minimum: one compare per (block, slab) whose result IS the ballot, v_mbcnt for the rank below the lane, one fused
+    // add-shift for the byte offset, and a raw buffer load whose inactive lanes carry the offset 0xFFFFFFFF -- the
+    // range check returns 0 for them without touching memory, so there is neither an exec-mask branch nor a select.
+    const auto pbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(P), (short)0, p_bytes, 0x00020000);
     constexpr int GROUP = S >= 32 ? 1 : (32 / S < COMBINE_BLOCKS ? 32 / S : COMBINE_BLOCKS);
 #pragma unroll
     for (int b0 = 0; b0 < COMBINE_BLOCKS; b0 += GROUP) {
@@ -265,11 +269,16 @@ k_slab_combine(int m, int tail_start, int zero_empty, const uint32_t *__restrict
             for (int k = 0; k < S; k++) {
                 const bool bit = (mk[b0 + g] >> k) & 1ull;
                 const unsigned long long bl = __ballot(bit);
-                const uint32_t idx = (uint32_t)__builtin_amdgcn_readlane((int)bv[b0 + g], k) + (uint32_t)__popcll(bl & lt);
+                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bl, 0u));
+                const unsigned off = bit ? ((unsigned)__builtin_amdgcn_readlane((int)bv[b0 + g], k) + rank) * (unsigned)sizeof(VT)
+                                         : 0xFFFFFFFFu;
 #if defined(CSR5_COMBINE_ABLATE) && (CSR5_COMBINE_ABLATE & 1) // experiment build only: no partial loads
-                part[g][k] = bit ? (VT)idx : (VT)0;
+                part[g][k] = (VT)off;
 #else
-                part[g][k] = bit ? P[idx] : (VT)0;
+                if constexpr (sizeof(VT) == 8)
+                    part[g][k] = __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b64(pbuf, off, 0, 0));
+                else
+                    part[g][k] = __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b32(pbuf, off, 0, 0));
 #endif
             }
         }
@@ -497,7 +506,7 @@ hipError_t slab_tables(int m2, int nnz, int S, int32_t *row_ptr2, const unsigned
 
 template <typename VT>
 static hipError_t combine_typed(int m, int tail_start, int zero_empty, int S, const uint32_t *mask, const uint32_t *base,
-                                const void *P, void *y, hipStream_t s)
+                                const void *P, int p_bytes, void *y, hipStream_t s)
 {
     const int rows_per_block = SLAB_BLOCK * COMBINE_BLOCKS;
     const dim3 grid((m + rows_per_block - 1) / rows_per_block), block(SLAB_BLOCK);
@@ -505,7 +514,7 @@ static hipError_t combine_typed(int m, int tail_start, int zero_empty, int S, co
 #define CSR5_SLAB_CASE(N)                                                                                              \
     case N:                                                                                                            \
         hipLaunchKernelGGL((k_slab_combine<VT, N>), grid, block, 0, s, m, tail_start, zero_empty, mask, base,          \
-                           (const VT *)P, (VT *)y);                                                                    \
+                           (const VT *)P, p_bytes, (VT *)y);                                                           \
         break;
         CSR5_SLAB_CASE(2) CSR5_SLAB_CASE(4) CSR5_SLAB_CASE(8) CSR5_SLAB_CASE(16) CSR5_SLAB_CASE(32) CSR5_SLAB_CASE(64)
 #undef CSR5_SLAB_CASE
@@ -515,12 +524,16 @@ static hipError_t combine_typed(int m, int tail_start, int zero_empty, int S, co
 }
 
 hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int value_type, const uint32_t *mask,
-                               const uint32_t *base, const void *P, void *y, hipStream_t s)
+                               const uint32_t *base, const void *P, int segments, void *y, hipStream_t s)
 {
     if (m <= 0)
         return hipSuccess;
-    return value_type == CSR5HIP_F64 ? combine_typed<double>(m, tail_start, zero_empty, S, mask, base, P, y, s)
-                                     : combine_typed<float>(m, tail_start, zero_empty, S, mask, base, P, y, s);
+    // P is read through a raw buffer (32-bit byte offsets, int record count): build_slabs keeps it below 2 GiB
+    const long long bytes = (long long)segments * (value_type == CSR5HIP_F64 ? 8 : 4);
+    if (bytes > 0x7FFFFFFFLL)
+        return hipErrorInvalidValue;
+    return value_type == CSR5HIP_F64 ? combine_typed<double>(m, tail_start, zero_empty, S, mask, base, P, (int)bytes, y, s)
+                                     : combine_typed<float>(m, tail_start, zero_empty, S, mask, base, P, (int)bytes, y, s);
 }
 
 } // namespace csr5
