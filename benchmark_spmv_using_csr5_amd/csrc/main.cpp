@@ -243,6 +243,14 @@ static int call_anonymouslib(int m, int n, int nnzA, int *csrRowPtrA, int *csrCo
              << " GB/s = " << 100.0 * b_alg / (1.0e+6 * t) / 8000.0 << " % of the 8 TB/s HBM3E roof." << endl;
         cout << "Ingest: parse = " << g_ingest_ms[0] << " ms, H2D = " << g_ingest_ms[1]
              << " ms, COO->CSR on device = " << g_ingest_ms[2] << " ms." << endl;
+        {
+            csr5hip_info si;
+            csr5hip_get_info(A.native(), &si);
+            if (si.column_slabs)
+                cout << "Column slabs = " << si.column_slabs << " (" << si.slab_segments << " row segments, built in "
+                     << si.t_slab_ms << " ms), LDS hot table " << (si.slab_hot ? "on" : "off") << " ("
+                     << si.slab_hot_cover_pct << " % of the non-zeros)." << endl;
+        }
 
         // batch harness (CSR5_avx512/main.cpp:105-110 appends "file,GFlops" to
         // results.csv): CSR5_RESULTS=<path> appends one line per run with the roofline columns added

@@ -123,3 +123,28 @@ def test_sharding_hip_local_spmv_single_process(oracle):
         run.state["A"].destroy()
         run.state["A"].close()
     assert np.array_equal(np.concatenate(parts), ref)
+
+
+def test_cli_on_several_gpus(tmp_path):
+    """`CSR5_GPU_LIST=0,0,0 ./spmv file.mtx` (or CSR5_GPUS=G with G real devices): the reference protocol through
+    anonymouslibMultiHandle -- the reference's lines, one line per shard, the x replication line, and its self-check."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "benchmark_spmv_using_csr5_amd", "csrc", "spmv")
+    mat = M.scircuit_like(scale=0.05)
+    mat.val[:] = 1.0
+    path = tmp_path / "m.mtx"
+    M.write_mtx(str(path), mat)
+    devs = _devices(3)
+    env = dict(os.environ, CSR5_SEED="7", CSR5_GPU_LIST=",".join(str(d) for d in devs))
+    out = subprocess.run([exe, str(path)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr
+    text = out.stdout
+    pos = -1
+    for token in ["PRECISION = 64-bit Double Precision", f" ) nnz = {mat.nnz}", "cpu sequential time = ", "Device [",
+                  "GPU shard 0 on device", "GPU shard 2 on device", "CSR->CSR5 time = ", "x replicated on 3 GPUs",
+                  "CSR5-based SpMV time = ", "max over 3 GPUs", "Check... PASS!"]:
+        nxt = text.find(token, pos + 1)
+        assert nxt > pos, (token, text)
+        pos = nxt
