@@ -2,7 +2,7 @@
 # usage: gpu_kstats.sh <bench args...>  -> average duration of the step kernels under rocprofv3 --kernel-trace --stats
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/ks && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o t -- python $REPO/bench.py --no-cpu-baseline --no-sub-configs "$@" > /tmp/ks.log 2>&1
+rm -rf /tmp/ks && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o t -- python $REPO/bench.py --no-cpu-baseline --no-sub-configs "$@" > /tmp/ks.log 2>&1
 grep '"metric"' /tmp/ks.log | tail -1 | python $REPO/scripts/benchline.py
 python3 - <<'PY'
 import csv, glob
