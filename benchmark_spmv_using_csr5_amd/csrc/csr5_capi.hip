@@ -113,10 +113,10 @@ struct csr5hip_handle_s {
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     uint32_t scalar_words[2] = {0, 0}; // landing zone of the two 4-byte reads of the conversion (checkpoint loading)
-    uint32_t *host_words = nullptr;    // 8 pinned, device-visible words the last conversion kernel exports into
+    uint32_t *host_words = nullptr;    // 16 pinned, device-visible words the last conversion kernel exports into
+    double wall_clock_khz = 0;         // rate of the device's constant wall clock (phase stamps)
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipEvent_t phase[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // asCSR5 phase boundaries
     std::unordered_map<GraphKey, hipGraphExec_t, GraphKeyHash> graphs;
     // column slabs (csr5_slab.hip): the stacked matrix lives in an internal child handle
     int slab_request = 1;  // CSR5HIP_OPT_COLUMN_SLABS: 0 off, 1 auto, 2..64 = S
@@ -235,8 +235,6 @@ int csr5hip_free(csr5hip_handle h)
         (void)hipHostFree(h->host_words);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
-    for (hipEvent_t e : h->phase)
-        if (e) (void)hipEventDestroy(e);
     delete h;
     return CSR5HIP_SUCCESS;
 }
@@ -429,9 +427,9 @@ static int reserve_aux(csr5hip_handle h)
     };
     // zero-initialised part first
     const size_t o_desc = take(desc_words * 4), o_offp = take(p1 * 4), o_cal = take(p1 * h->vsize()),
-                 o_acc = take(p1 * h->vsize()), o_cnt = take(p1 * 4), o_counters = take(16), o_offset = take(offset_cap * 4);
+                 o_acc = take(p1 * h->vsize()), o_cnt = take(p1 * 4), o_counters = take(COUNTER_WORDS * 4), o_tp = take(p1 * 4), o_offset = take(offset_cap * 4);
     const size_t zero_bytes = off;
-    const size_t o_tp = take(p1 * 4), o_meta = take(p1 * 16), o_hdr = take(p1 * 32), o_scan = take(h->scan_tmp_bytes);
+    const size_t o_meta = take(p1 * 16), o_hdr = take(p1 * 32), o_scan = take(h->scan_tmp_bytes);
     HIP_TRY(h->b_arena.reserve(off));
     char *base = (char *)h->b_arena.ptr;
     h->d.tile_desc = (uint32_t *)(base + o_desc);
@@ -478,12 +476,17 @@ static int derive_kernel_tables(csr5hip_handle h)
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
     if (!h->host_words) {
-        HIP_TRY(hipHostMalloc((void **)&h->host_words, 32, hipHostMallocDefault));
-        memset(h->host_words, 0, 32);
+        HIP_TRY(hipHostMalloc((void **)&h->host_words, 64, hipHostMallocDefault));
+        memset(h->host_words, 0, 64);
+        int dev = 0, khz = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0)
+            h->wall_clock_khz = khz;
+        else
+            h->wall_clock_khz = 100000.0; // gfx9: 100 MHz
     }
-    HIP_TRY(launch_carry_meta(g, h->d, s));
-    HIP_TRY(launch_tile_window(g, h->d, (int)h->vsize(), s));
-    HIP_TRY(launch_tile_hdr(g, h->d, h->host_words, s)); // exports the host's six words (no device-to-host copies)
+    // carry_meta + x-windows + fused-kernel headers in one launch, then the export of the host's words
+    HIP_TRY(launch_tile_tables(g, h->d, (int)h->vsize(), h->host_words, s));
     HIP_TRY(hipStreamSynchronize(s));
     const uint32_t *w = h->host_words;
     h->scalar_words[0] = w[0];
@@ -491,8 +494,19 @@ static int derive_kernel_tables(csr5hip_handle h)
     finish_format_scalars(h);
     h->xwin_tiles = (int)w[2];
     h->xwin_covered = (long long)w[3];
-    h->xwin_lines = (long long)w[5];
     h->opt.long_runs = w[4] != 0;
+    h->xwin_lines = (long long)w[5];
+    // phase times from the kernels' wall-clock stamps (k_row_scan, k_tile_desc, k_transpose, k_tile_tables); a phase
+    // whose kernel did not run (single-tile matrices) has no stamp and takes the next one's
+    unsigned long long st[4];
+    memcpy(st, w + 8, sizeof(st));
+    for (int i = 2; i >= 0; i--)
+        if (!st[i])
+            st[i] = st[i + 1];
+    const double per_tick_ms = 1.0 / h->wall_clock_khz;
+    h->t_tile_ptr += (double)(st[1] - st[0]) * per_tick_ms;
+    h->t_tile_desc += (double)(st[2] - st[1]) * per_tick_ms;
+    h->t_transpose += (double)(st[3] - st[2]) * per_tick_ms;
     return CSR5HIP_SUCCESS;
 }
 
@@ -502,20 +516,13 @@ static int build_format_arrays(csr5hip_handle h)
 {
     Geometry &g = h->g;
     hipStream_t s = h->stream;
-    for (hipEvent_t &e : h->phase)
-        if (!e)
-            HIP_TRY(hipEventCreate(&e));
     // step 1: tile_ptr (+ empty-row marks) -- flag scatter shares the row pass
-    HIP_TRY(hipEventRecord(h->phase[0], s));
-    HIP_TRY(launch_tile_ptr(g, h->d, s));
     HIP_TRY(launch_row_scan(g, h->d, s));
-    HIP_TRY(hipEventRecord(h->phase[1], s));
 
     // step 2: tile_desc, offset_ptr scan, empty-row offsets (the kernel leaves unflagged tiles at once)
     HIP_TRY(launch_tile_desc(g, h->d, s));
     HIP_TRY(launch_offset_scan(g, h->d, h->scan_tmp, h->scan_tmp_bytes, s));
     HIP_TRY(launch_desc_offset(g, h->d, s));
-    HIP_TRY(hipEventRecord(h->phase[2], s));
     return CSR5HIP_SUCCESS;
 }
 
@@ -545,7 +552,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
     hipStream_t s = h->stream;
 
     // ONE host round trip in all, at the end (the reference synchronises after every phase and reads two words in
-    // between, anonymouslib_cuda.h:161-208).  The four phase times the reference prints are taken from events on
+    // between, anonymouslib_cuda.h:161-208).  The four phase times the reference prints are taken from wall-clock stamps of
     // the stream instead of host timers around synchronisations.
     double t0 = now_ms();
     rc = reserve_aux(h);
@@ -562,18 +569,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
         // From here on the caller's arrays are in tile order while the handle still says CSR: a failure must
         // put them back (a retry would transpose them a second time).
         auto finish = [&]() -> int {
-            HIP_TRY(hipEventRecord(h->phase[3], s));
-            int r = derive_kernel_tables(h); // ends with the second (last) synchronisation
-            if (r != CSR5HIP_SUCCESS)
-                return r;
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, h->phase[0], h->phase[1]));
-            h->t_tile_ptr += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, h->phase[1], h->phase[2]));
-            h->t_tile_desc += ms;
-            HIP_TRY(hipEventElapsedTime(&ms, h->phase[2], h->phase[3]));
-            h->t_transpose += ms;
-            return CSR5HIP_SUCCESS;
+            return derive_kernel_tables(h); // ends with the one synchronisation; phase times from the kernels' stamps
         };
         rc = finish();
         if (rc != CSR5HIP_SUCCESS) {

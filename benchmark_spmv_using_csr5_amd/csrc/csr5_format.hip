@@ -5,13 +5,14 @@
 //
 //   reference step (CSR5_cuda/detail/cuda/format_cuda.h)           here
 //   ------------------------------------------------------------   --------------------------------------
-//   K1 generate_partition_pointer_s1  :21-41   thread / tile       k_tile_ptr        thread / tile
-//   K2 generate_partition_pointer_s2  :43-95   block / tile,       k_row_scan        thread / ROW: an empty row
-//      loops over the tile's rows                                    with pointer e marks tile (e-1)/T; no loop
+//   K1 generate_partition_pointer_s1  :21-41   thread / tile,      k_row_scan        thread / ROW: a row owns the tile
+//      one bisection of row_ptr per tile                             boundaries inside its pointer range; no search
+//   K2 generate_partition_pointer_s2  :43-95   block / tile,       (same kernel)     an empty row with pointer e marks
+//      loops over the tile's rows                                    tile (e-1)/T; no loop
 //   K4 generate_partition_descriptor_s1 :129-159 thread / row      (same kernel)     flag scatter, tiles < p-1 only
 //   K5 generate_partition_descriptor_s2 :161-267 warp / tile,      k_tile_desc       wave / tile: popcounts, DPP-free
 //      LDS scan + serial look-ahead loop                             shfl scan, ballot + ctz for scansum_offset
-//   K6 generate_partition_descriptor_s3 :269-300 1 block           k_offset_scan     1 block, wave-shuffle scan
+//   K6 generate_partition_descriptor_s3 :269-300 1 block           rocprim device scan (k_offset_scan_small: 1 block, <= 16 k tiles)
 //   K7 generate_partition_descriptor_offset :362-523               k_desc_offset     wave / flagged tile
 //   K8 aosoa_transpose_kernel_smem      :525-744 block / tile,     k_transpose       block / tile, col_idx AND value
 //      two launches (col, val), 29 sigma instantiations              in one launch, runtime sigma, padded LDS
@@ -36,53 +37,73 @@ __device__ __forceinline__ int upper_bound(const int32_t *__restrict__ a, int ke
     return lo;
 }
 
-// ---------------------------------------------------------------------------------------------
-// K1: tile_ptr[t] = (last row r in [0, m] with row_ptr[r] <= min(t*T, nnz)),  t in [0, p]
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(FMT_BLOCK) k_tile_ptr(Geometry g, const int32_t *__restrict__ row_ptr,
-                                                    uint32_t *__restrict__ tile_ptr)
+// Phase boundaries of the conversion (the four "CSR->CSR5 ... time" lines the reference prints,
+// anonymouslib_cuda.h:211-214) without events on the stream: the first thread of the first kernel of every phase
+// stores the constant-rate wall clock (s_memrealtime) into counters[8 + 2*slot]; the host turns the differences into
+// milliseconds with hipDeviceAttributeWallClockRate.  An event record costs 2-4 us of stream time each, four of them
+// were a sixth of a small matrix's conversion.
+__device__ __forceinline__ void stamp_phase(uint32_t *__restrict__ counters, int slot)
 {
-    const int t = blockIdx.x * FMT_BLOCK + threadIdx.x;
-    if (t > g.p)
-        return;
-    long long b = (long long)t * g.tile_elems;
-    int boundary = b > g.nnz ? g.nnz : (int)b;
-    tile_ptr[t] = (uint32_t)(upper_bound(row_ptr, boundary, g.m + 1) - 1);
+    if (counters && blockIdx.x == 0 && threadIdx.x == 0)
+        *reinterpret_cast<unsigned long long *>(counters + STAMP_WORD + 2 * slot) = wall_clock64();
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2 + K4 fused, one thread per row r < m, reading row_ptr once:
-//  * bit flag of the row's first element e = row_ptr[r] (tiles 0..p-2 only; the last tile is
+// K1 + K2 + K4 fused, one thread per row r < m, reading row_ptr once (tile_ptr and tile_desc start zeroed; every
+// store is an atomicOr of disjoint bits, so the three parts need no order among themselves):
+//  * K1: tile_ptr[t] = last row r in [0, m] with row_ptr[r] <= min(t*T, nnz).  For t*T < nnz that is the one
+//    NON-EMPTY row whose range [row_ptr[r], row_ptr[r+1]) holds t*T, so every row writes the boundaries inside its own
+//    range (none for most rows, thousands for a hub row: the wavefront shares those) and tile_ptr[p] = m.  The
+//    reference bisects row_ptr once per tile (format_cuda.h:21-41): p dependent 17-step chains, 7 us on a 171 k-row
+//    matrix where this pass costs nothing extra;
+//  * K4: bit flag of the row's first element e = row_ptr[r] (tiles 0..p-2 only; the last tile is
 //    processed from CSR and its descriptor stays zero, as in CSR5_avx2 format_avx2.h:98);
-//  * an EMPTY row with e > 0 lies in the row range [tile_ptr[t], tile_ptr[t+1]) of exactly one
+//  * K2: an EMPTY row with e > 0 lies in the row range [tile_ptr[t], tile_ptr[t+1]) of exactly one
 //    tile, t = (e-1)/T  (tile_ptr[t] is the last row with pointer <= t*T, so r > tile_ptr[t] iff
 //    e > t*T, and r < tile_ptr[t+1] iff e <= (t+1)*T); leading empty rows (e == 0) precede every
 //    tile.  That replaces the reference's per-tile row loop by one store per run of empty rows.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(FMT_BLOCK) k_row_scan(Geometry g, const int32_t *__restrict__ row_ptr,
                                                     uint32_t *__restrict__ tile_ptr,
-                                                    uint32_t *__restrict__ tile_desc)
+                                                    uint32_t *__restrict__ tile_desc, uint32_t *__restrict__ counters)
 {
+    stamp_phase(counters, 0);
     const int r = blockIdx.x * FMT_BLOCK + threadIdx.x;
-    if (r >= g.m)
-        return;
-    const int e = row_ptr[r];
-    const int e1 = row_ptr[r + 1];
+    const int lane = threadIdx.x & (OMEGA - 1);
+    const bool live = r < g.m;
+    const int e = live ? row_ptr[r] : 0;
+    const int e1 = live ? row_ptr[r + 1] : 0;
     const int T = g.tile_elems;
+    if (r == 0)
+        atomicOr(&tile_ptr[g.p], (uint32_t)g.m);
+    // boundaries t*T in [e, e1): t0 = ceil(e / T) .. t1 = (e1 - 1) / T  (t1 <= p-1 because e1 <= nnz)
+    const int t0 = e / T + (e % T != 0);
+    const int t1 = e1 > e ? (e1 - 1) / T : t0 - 1;
+    const int owned = t1 - t0 + 1;
+    if (owned > 0 && owned <= 2) {
+        atomicOr(&tile_ptr[t0], (uint32_t)r);
+        if (owned == 2)
+            atomicOr(&tile_ptr[t1], (uint32_t)r);
+    }
+    for (unsigned long long wide = __ballot(owned > 2); wide; wide &= wide - 1) {
+        const int src = __builtin_ctzll(wide);
+        const int a = __shfl(t0, src, OMEGA), b = __shfl(t1, src, OMEGA), row = __shfl(r, src, OMEGA);
+        for (int t = a + lane; t <= b; t += OMEGA)
+            atomicOr(&tile_ptr[t], (uint32_t)row);
+    }
     const int tile = e / T;
-    if (tile < g.p - 1) {
-        const int lane = (e / g.sigma) % OMEGA;
+    if (live && tile < g.p - 1) {
+        const int fl = (e / g.sigma) % OMEGA;
         const int gbit = e % g.sigma + g.bit_all;
-        const size_t loc = (size_t)tile * OMEGA * g.num_packet + (size_t)(gbit >> 5) * OMEGA + lane;
+        const size_t loc = (size_t)tile * OMEGA * g.num_packet + (size_t)(gbit >> 5) * OMEGA + fl;
         atomicOr(&tile_desc[loc], 1u << (31 - (gbit & 31)));
     }
     // Empty rows come in runs with the same pointer (R-MAT: half of all rows), i.e. the same target tile:
-    // only the first lane of a run marks it.  Every writer stores the same word (the row index that
-    // k_tile_ptr left there, plus bit 31), so a plain load/store replaces the contended atomicOr.
-    const int target = (e == e1 && e > 0) ? (e - 1) / T : -1;
+    // only the first lane of a run marks it.
+    const int target = (live && e == e1 && e > 0) ? (e - 1) / T : -1;
     const int before = __shfl_up(target, 1, OMEGA);
-    if (target >= 0 && ((threadIdx.x & (OMEGA - 1)) == 0 || before != target))
-        tile_ptr[target] = tile_ptr[target] | 0x80000000u;
+    if (target >= 0 && (lane == 0 || before != target))
+        atomicOr(&tile_ptr[target], 0x80000000u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -93,8 +114,9 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_row_scan(Geometry g, const int32_
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(FMT_BLOCK) k_tile_desc(Geometry g, const uint32_t *__restrict__ tile_ptr,
                                                      uint32_t *__restrict__ tile_desc,
-                                                     int32_t *__restrict__ offset_ptr)
+                                                     int32_t *__restrict__ offset_ptr, uint32_t *__restrict__ counters)
 {
+    stamp_phase(counters, 1);
     const int lane = threadIdx.x & (OMEGA - 1);
     const int t = blockIdx.x * FMT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
     if (t >= g.p - 1)
@@ -189,8 +211,9 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_desc_offset(Geometry g, const int
 template <typename VT>
 __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint32_t *__restrict__ tile_ptr,
                                                      int32_t *__restrict__ col, VT *__restrict__ val,
-                                                     int r2c)
+                                                     int r2c, uint32_t *__restrict__ counters)
 {
+    stamp_phase(counters, 2);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = blockIdx.x;
     // fast-track tiles are not transposed; the test is on the RAW words (format_cuda.h:540)
@@ -236,14 +259,10 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint3
 // for short rows), tile h-1 owns y[r] outright and nothing is communicated.  Otherwise every partial
 // of r arrives at slot h and the last arriver stores y[r] (csr5_spmv.hip carry_arrive).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(FMT_BLOCK) k_carry_meta(Geometry g, const int32_t *__restrict__ row_ptr,
-                                                      const uint32_t *__restrict__ tile_ptr,
-                                                      uint4 *__restrict__ carry_meta,
-                                                      uint32_t *__restrict__ long_run_counter)
+__device__ uint4 tile_carry_meta(const Geometry &g, const int32_t *__restrict__ row_ptr,
+                                 const uint32_t *__restrict__ tile_ptr, const int t,
+                                 uint32_t *__restrict__ long_run_counter)
 {
-    const int t = blockIdx.x * FMT_BLOCK + threadIdx.x;
-    if (t >= g.p)
-        return;
     const long long T = g.tile_elems;
     // is tile k the head of a short-spill run?  (needs k >= 1)
     auto short_spill = [&](int k, int *len) -> bool {
@@ -263,9 +282,16 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_carry_meta(Geometry g, const int3
         return true;
     };
     const int r = (int)(tile_ptr[t] & ROW_MASK);
-    // Run bounds by bisection on the sorted tile_ptr (a thread used to WALK its run and write the members' .y: ten
-    // thousand serial steps for a 10 M-nnz row).  head = first tile whose row is r, e = last one.
-    int lo = 0, hi = t;
+    // Run bounds on the sorted tile_ptr: head = first tile whose row is r, e = last one.  Galloping from t (steps 1, 2,
+    // 4, ...) and a bisection of the last stride: one dependent load for the usual run of one tile, log(run) for a hub
+    // row (a thread used to WALK its run: ten thousand serial steps for a 10 M-nnz row; a plain bisection of [0, t] is
+    // twelve dependent loads on EVERY tile of a 2 500-tile matrix, 6 us of a 60-us conversion).
+    int hi = t, lo = t - 1;
+    for (int step = 1; lo >= 0 && (int)(tile_ptr[lo] & ROW_MASK) >= r; step <<= 1) {
+        hi = lo;
+        lo -= step;
+    }
+    lo = lo < 0 ? 0 : lo + 1; // every tile below lo has a smaller row; tile hi has row r
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if ((int)(tile_ptr[mid] & ROW_MASK) < r)
@@ -280,7 +306,12 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_carry_meta(Geometry g, const int3
     if (short_spill(t, &len)) {
         meta.x |= 1u << 28;
     } else if (head && r < g.m) {
-        lo = t + 1, hi = g.p;
+        lo = t + 1, hi = t + 1; // first tile after t whose row is larger (p if none), galloping forward
+        for (int step = 1; hi < g.p && (int)(tile_ptr[hi] & ROW_MASK) <= r; step <<= 1) {
+            lo = hi + 1;
+            hi += step;
+        }
+        hi = hi > g.p ? g.p : hi;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
             if ((int)(tile_ptr[mid] & ROW_MASK) <= r)
@@ -292,7 +323,8 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_carry_meta(Geometry g, const int3
         unsigned expected = (unsigned)(e - t + 1);
         if (e - t + 1 > RUN_SERIAL_MAX) {
             meta.x |= 1u << 26; // long run: partials are only parked, k_calibrate sums them
-            atomicAdd(long_run_counter, 1u);
+            if (long_run_counter)
+                atomicAdd(long_run_counter, 1u);
         }
         if ((long long)row_ptr[r] != (long long)t * T) {
             expected += 1; // row r starts inside tile t-1, whose closing segment also arrives
@@ -311,7 +343,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_carry_meta(Geometry g, const int3
             }
         }
     }
-    carry_meta[t] = meta; // .w (x-window start) is set by k_tile_window afterwards
+    return meta; // .w (x-window start) is filled in by k_tile_tables
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -332,71 +364,103 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     return v;
 }
 
-__global__ void __launch_bounds__(FMT_BLOCK) k_tile_window(Geometry g, const int32_t *__restrict__ col,
-                                                       uint4 *__restrict__ carry_meta,
-                                                       uint32_t *__restrict__ covered, int XWIN_ELEMS,
+// One wavefront per tile t < p writes everything the SpMV kernels keep per tile besides the format arrays:
+// carry_meta[t] (lane 0 derives it, lane 1 derives tile t+1's first word at the same time: the two bisection chains
+// run side by side under the tile's column loads), the x-window of the tile, and the 32-byte header of the fused kernel
+// -- words 0..3 = carry_meta[t], 4 = carry_meta[t+1].x, 5..6 = tile_ptr[t], tile_ptr[t+1] (copies; the format arrays
+// themselves stay untouched), 7 = the tile's window statistics (bits 0..15 covered non-zeros, 16..31 lines), which
+// only k_stats_export reads.  (Three launches -- carry_meta, tile_window, tile_hdr -- until round 2.)
+__global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int32_t *__restrict__ row_ptr,
+                                                       const uint32_t *__restrict__ tile_ptr,
+                                                       const int32_t *__restrict__ col,
+                                                       uint4 *__restrict__ carry_meta, uint32_t *__restrict__ hdr,
+                                                       uint32_t *__restrict__ counters, int XWIN_ELEMS,
                                                        int line_shift)
 {
+    stamp_phase(counters, 3);
+    uint32_t *const long_run_counter = counters + 2;
     const int lane = threadIdx.x & (OMEGA - 1);
     const int t = blockIdx.x * FMT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (t >= g.p - 1)
+    if (t >= g.p)
         return;
+    const bool windowed = t < g.p - 1; // the CSR tail has no window
     const int32_t *c = col + (size_t)t * g.tile_elems + lane;
-    const int hi_limit = g.n > XWIN_ELEMS ? g.n - XWIN_ELEMS : 0;
-    auto window_of = [&](int centre) {
-        int lo = centre - XWIN_ELEMS / 2;
-        lo = lo < 0 ? 0 : (lo > hi_limit ? hi_limit : lo);
-        return lo & ~3;
-    };
-    // score every lane's candidate on the 64 samples (v_readlane broadcasts, no LDS shuffles)
-    const int sample = c[0];
-    const int my_lo = window_of(sample);
-    int score = 0;
+    const int sample = windowed ? c[0] : 0;
+
+    uint4 meta = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < 2 && t + lane < g.p)
+        meta = tile_carry_meta(g, row_ptr, tile_ptr, t + lane, lane == 0 ? long_run_counter : nullptr);
+    const unsigned next_x = (unsigned)__builtin_amdgcn_readlane((int)meta.x, 1);
+
+    unsigned window = 0, stats = 0;
+    if (windowed) {
+        const int hi_limit = g.n > XWIN_ELEMS ? g.n - XWIN_ELEMS : 0;
+        auto window_of = [&](int centre) {
+            int lo = centre - XWIN_ELEMS / 2;
+            lo = lo < 0 ? 0 : (lo > hi_limit ? hi_limit : lo);
+            return lo & ~3;
+        };
+        // score every lane's candidate on the 64 samples (v_readlane broadcasts, no LDS shuffles)
+        const int my_lo = window_of(sample);
+        int score = 0;
 #pragma unroll
-    for (int j = 0; j < OMEGA; j++)
-        score += (unsigned)(__builtin_amdgcn_readlane(sample, j) - my_lo) < (unsigned)XWIN_ELEMS;
-    // best candidate: highest score, lowest lane on ties (deterministic)
-    int best = score * OMEGA + (OMEGA - 1 - lane);
+        for (int j = 0; j < OMEGA; j++)
+            score += (unsigned)(__builtin_amdgcn_readlane(sample, j) - my_lo) < (unsigned)XWIN_ELEMS;
+        // best candidate: highest score, lowest lane on ties (deterministic)
+        int best = score * OMEGA + (OMEGA - 1 - lane);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const int o = __shfl_xor(best, d, OMEGA);
-        best = o > best ? o : best;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(best, d, OMEGA);
+            best = o > best ? o : best;
+        }
+        const int lo = __builtin_amdgcn_readlane(my_lo, OMEGA - 1 - (__builtin_amdgcn_readfirstlane(best) % OMEGA));
+        int inside = 0;
+        for (int i = 0; i < g.sigma; i++)
+            inside += (unsigned)(c[i * OMEGA] - lo) < (unsigned)XWIN_ELEMS;
+        inside = wave_sum_i32(inside);
+        // How many distinct 128-byte lines of x do the in-window lanes of ONE gather instruction (the 64 samples)
+        // touch?  That is what the window replaces: a gather spread over 30+ lines costs 60+ clk in the vector-memory
+        // path, one that sits on a handful of lines is cheap and the staging would cost more than it saves.
+        const bool in_win = (unsigned)(sample - lo) < (unsigned)XWIN_ELEMS;
+        const int line = sample >> line_shift;
+        bool first = in_win;
+#pragma unroll
+        for (int j = 0; j < OMEGA - 1; j++) {
+            const int other = __builtin_amdgcn_readlane(line, j);
+            const bool other_in = (__builtin_amdgcn_readlane((int)in_win, j) != 0);
+            first = first && !(j < lane && other_in && other == line);
+        }
+        const int lines = __popcll(__ballot(first));
+        if (inside * 100 >= g.tile_elems * XWIN_MIN_COVER_PCT) {
+            window = (unsigned)lo + 1u;
+            stats = (unsigned)inside | ((unsigned)lines << 16);
+        }
     }
-    const int lo = __builtin_amdgcn_readlane(my_lo, OMEGA - 1 - (__builtin_amdgcn_readfirstlane(best) % OMEGA));
-    int inside = 0;
-    for (int i = 0; i < g.sigma; i++)
-        inside += (unsigned)(c[i * OMEGA] - lo) < (unsigned)XWIN_ELEMS;
-    inside = wave_sum_i32(inside);
-    // How many distinct 128-byte lines of x do the in-window lanes of ONE gather instruction (the 64 samples) touch?
-    // That is what the window replaces: a gather spread over 30+ lines costs 60+ clk in the vector-memory path,
-    // one that sits on a handful of lines is cheap and the staging would cost more than it saves.
-    const bool in_win = (unsigned)(sample - lo) < (unsigned)XWIN_ELEMS;
-    const int line = sample >> line_shift;
-    bool first = in_win;
-#pragma unroll
-    for (int j = 0; j < OMEGA - 1; j++) {
-        const int other = __builtin_amdgcn_readlane(line, j);
-        const bool other_in = (__builtin_amdgcn_readlane((int)in_win, j) != 0);
-        first = first && !(j < lane && other_in && other == line);
-    }
-    const int lines = __popcll(__ballot(first));
     if (lane == 0) {
-        const bool on = inside * 100 >= g.tile_elems * XWIN_MIN_COVER_PCT;
-        reinterpret_cast<unsigned *>(&carry_meta[t])[3] = on ? (unsigned)lo + 1u : 0u;
-        // per-tile result, summed by k_window_stats: two global atomics per tile on the same two words
-        // serialised the whole kernel (646 us for 28 k tiles).  bits 0..15 covered non-zeros, 16..31 lines
-        covered[t] = on ? ((unsigned)inside | ((unsigned)lines << 16)) : 0u;
+        meta.w = window;
+        carry_meta[t] = meta;
+        reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t] = meta;
+        reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t + 1] = make_uint4(next_x, tile_ptr[t], tile_ptr[t + 1], stats);
     }
 }
 
-// counters[0] += tiles with a window, counters[1] += non-zeros inside those windows,
-// counters[3] += distinct x lines under the in-window lanes of the sampled gather
-__global__ void __launch_bounds__(256) k_window_stats(int tiles, const uint32_t *__restrict__ covered,
-                                                      uint32_t *__restrict__ counters)
+// LAST kernel of the conversion.  Sums the per-tile window statistics (counters[0] = tiles with a window, [1] =
+// non-zeros inside those windows, [3] = distinct x lines under the in-window lanes of the sampled gathers; per-tile
+// words because two global atomics per tile on the same two words serialised a whole kernel: 646 us for 28 k tiles),
+// and the workgroup that finishes last exports the six words the host needs -- tail start, number of offsets
+// (anonymouslib_cuda.h:165-167, format_cuda.h:331-343) and the four statistics -- straight into pinned,
+// device-visible host memory: everything it reads is final, and the host reads them after its one synchronisation
+// without three 4-to-16-byte device-to-host copies (7.6 us each).
+__global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_t *__restrict__ tile_ptr,
+                                                       const uint32_t *__restrict__ hdr,
+                                                       const int32_t *__restrict__ offset_ptr,
+                                                       uint32_t *__restrict__ counters,
+                                                       uint32_t *__restrict__ host_words)
 {
+    __shared__ unsigned part[16][3];
     unsigned on = 0, in = 0, lines = 0;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < tiles; t += gridDim.x * 256) {
-        const unsigned v = covered[t];
+    for (int t = blockIdx.x * 1024 + threadIdx.x; t < g.p - 1; t += gridDim.x * 1024) {
+        const unsigned v = hdr[8 * (size_t)t + 7];
         on += v != 0;
         in += v & 0xFFFFu;
         lines += v >> 16;
@@ -404,44 +468,39 @@ __global__ void __launch_bounds__(256) k_window_stats(int tiles, const uint32_t 
     on = (unsigned)wave_sum_i32((int)on);
     in = (unsigned)wave_sum_i32((int)in);
     lines = (unsigned)wave_sum_i32((int)lines);
-    if ((threadIdx.x & (OMEGA - 1)) == 0 && (on | in)) {
-        atomicAdd(counters + 0, on);
-        atomicAdd(counters + 1, in);
-        atomicAdd(counters + 3, lines);
+    if ((threadIdx.x & (OMEGA - 1)) == 0) {
+        part[threadIdx.x >> 6][0] = on;
+        part[threadIdx.x >> 6][1] = in;
+        part[threadIdx.x >> 6][2] = lines;
     }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Per-tile header of the fused kernel: everything wave-uniform a tile needs, in one 32-byte record
-// (one vector load instead of three): words 0..3 = carry_meta[t], 4 = carry_meta[t+1].x,
-// 5..6 = tile_ptr[t], tile_ptr[t+1] (copies; the format arrays themselves stay untouched).
-// ---------------------------------------------------------------------------------------------
-// Thread 0 also exports the six words the host needs from the conversion -- tail start, number of offsets
-// (anonymouslib_cuda.h:165-167, format_cuda.h:331-343) and the four conversion statistics -- straight into pinned,
-// device-visible host memory: this is the LAST kernel of the conversion, so everything it reads is final, and the host
-// reads them after its one synchronisation without three 4-to-16-byte device-to-host copies (7.6 us each).
-__global__ void __launch_bounds__(FMT_BLOCK) k_tile_hdr(Geometry g, const uint32_t *__restrict__ tile_ptr,
-                                                    const uint4 *__restrict__ carry_meta,
-                                                    uint32_t *__restrict__ hdr, const int32_t *__restrict__ offset_ptr,
-                                                    const uint32_t *__restrict__ counters,
-                                                    uint32_t *__restrict__ host_words)
-{
-    const int t = blockIdx.x * FMT_BLOCK + threadIdx.x;
-    if (t == 0 && host_words) {
-        host_words[0] = tile_ptr[g.p - 1];
-        host_words[1] = (uint32_t)offset_ptr[g.p];
-        host_words[2] = counters[0];
-        host_words[3] = counters[1];
-        host_words[4] = counters[2];
-        host_words[5] = counters[3];
-    }
-    if (t >= g.p)
+    __syncthreads();
+    if (threadIdx.x != 0)
         return;
-    const uint4 m = carry_meta[t];
-    uint4 lo = m;
-    uint4 hi = make_uint4(t + 1 < g.p ? carry_meta[t + 1].x : 0u, tile_ptr[t], tile_ptr[t + 1], 0u);
-    reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t] = lo;
-    reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t + 1] = hi;
+    on = in = lines = 0;
+    for (int w = 0; w < 16; w++)
+        on += part[w][0], in += part[w][1], lines += part[w][2];
+    if (gridDim.x > 1) { // (one workgroup up to 16 k tiles: no atomics, no fence)
+        if (on | in) {
+            atomicAdd(counters + 0, on);
+            atomicAdd(counters + 1, in);
+            atomicAdd(counters + 3, lines);
+        }
+        __threadfence();
+        if (atomicAdd(counters + 4, 1u) + 1u != gridDim.x)
+            return; // not the last workgroup
+        counters[4] = 0;
+        on = __hip_atomic_load(counters + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        in = __hip_atomic_load(counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lines = __hip_atomic_load(counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!host_words)
+        return;
+    uint4 *out = reinterpret_cast<uint4 *>(host_words);
+    const uint4 *stamps = reinterpret_cast<const uint4 *>(counters + STAMP_WORD);
+    out[0] = make_uint4(tile_ptr[g.p - 1], (uint32_t)offset_ptr[g.p], on, in);
+    out[1] = make_uint4(counters[2], lines, 0u, 0u);
+    out[2] = stamps[0]; // phase stamps 0, 1 (64-bit each)
+    out[3] = stamps[1]; // phase stamps 2, 3
 }
 
 // checkpoint loading: the index arrays come from a file and are used as addresses by every later kernel
@@ -481,19 +540,12 @@ __global__ void k_warmup(int *out)
 // ---------------------------------------------------------------------------------------------
 static inline int div_up(long long a, int b) { return (int)((a + b - 1) / b); }
 
-hipError_t launch_tile_ptr(const Geometry &g, const DeviceArrays &d, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_tile_ptr, dim3(div_up(g.p + 1, FMT_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
-                       d.tile_ptr);
-    return hipGetLastError();
-}
-
 hipError_t launch_row_scan(const Geometry &g, const DeviceArrays &d, hipStream_t s)
 {
     if (g.m <= 0)
         return hipSuccess;
     hipLaunchKernelGGL(k_row_scan, dim3(div_up(g.m, FMT_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
-                       d.tile_ptr, d.tile_desc);
+                       d.tile_ptr, d.tile_desc, d.counters);
     return hipGetLastError();
 }
 
@@ -502,8 +554,41 @@ hipError_t launch_tile_desc(const Geometry &g, const DeviceArrays &d, hipStream_
     if (g.p <= 1)
         return hipSuccess;
     hipLaunchKernelGGL(k_tile_desc, dim3(div_up(g.p - 1, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g,
-                       d.tile_ptr, d.tile_desc, d.offset_ptr);
+                       d.tile_ptr, d.tile_desc, d.offset_ptr, d.counters);
     return hipGetLastError();
+}
+
+// K6 for small tile counts: the exclusive scan of offset_ptr[0..entries) by ONE workgroup in ONE launch (thread i owns
+// `per` consecutive entries; wave shuffles + 16 LDS words carry the rest).  rocprim's device scan is two launches
+// (look-back state initialisation + scan) and takes over above SMALL_SCAN_MAX entries, where it is the faster one.
+constexpr int SMALL_SCAN_MAX = 16384;
+__global__ void __launch_bounds__(1024) k_offset_scan_small(int32_t *__restrict__ a, int entries)
+{
+    __shared__ int wave_total[16];
+    const int per = (entries + 1023) / 1024;
+    const int first = (int)threadIdx.x * per;
+    int sum = 0;
+    for (int i = first; i < first + per && i < entries; i++)
+        sum += a[i];
+    const int lane = threadIdx.x & (OMEGA - 1), w = threadIdx.x >> 6;
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < OMEGA; d <<= 1) {
+        const int v = __shfl_up(incl, d, OMEGA);
+        if (lane >= d)
+            incl += v;
+    }
+    if (lane == OMEGA - 1)
+        wave_total[w] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int k = 0; k < w; k++)
+        run += wave_total[k];
+    for (int i = first; i < first + per && i < entries; i++) {
+        const int v = a[i];
+        a[i] = run;
+        run += v;
+    }
 }
 
 size_t offset_scan_tmp_bytes(int entries)
@@ -516,6 +601,10 @@ size_t offset_scan_tmp_bytes(int entries)
 
 hipError_t launch_offset_scan(const Geometry &g, const DeviceArrays &d, void *tmp, size_t tmp_bytes, hipStream_t s)
 {
+    if (g.p + 1 <= SMALL_SCAN_MAX) {
+        hipLaunchKernelGGL(k_offset_scan_small, dim3(1), dim3(1024), 0, s, d.offset_ptr, g.p + 1);
+        return hipGetLastError();
+    }
     return rocprim::exclusive_scan(tmp, tmp_bytes, d.offset_ptr, d.offset_ptr, 0, (size_t)g.p + 1, rocprim::plus<int32_t>(), s);
 }
 
@@ -537,45 +626,28 @@ hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_
     const size_t lds = (size_t)g.sigma * (OMEGA + 1) * (vsz + 4);
     if (value_type == CSR5HIP_F64)
         hipLaunchKernelGGL(k_transpose<double>, dim3(g.p - 1), dim3(FMT_BLOCK), lds, s, g, d.tile_ptr,
-                           d.col, (double *)d.val, r2c ? 1 : 0);
+                           d.col, (double *)d.val, r2c ? 1 : 0, r2c ? d.counters : nullptr);
     else
         hipLaunchKernelGGL(k_transpose<float>, dim3(g.p - 1), dim3(FMT_BLOCK), lds, s, g, d.tile_ptr,
-                           d.col, (float *)d.val, r2c ? 1 : 0);
+                           d.col, (float *)d.val, r2c ? 1 : 0, r2c ? d.counters : nullptr);
     return hipGetLastError();
 }
 
-hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int value_size, uint32_t *host_words,
+                              hipStream_t s)
 {
     if (g.p <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(k_carry_meta, dim3(div_up(g.p, FMT_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
-                       d.tile_ptr, reinterpret_cast<uint4 *>(d.carry_meta), d.counters + 2);
-    return hipGetLastError();
-}
-
-hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int value_size, hipStream_t s)
-{
-    if (g.p <= 1)
-        return hipSuccess;
-    // the per-tile coverage words live in tile_hdr until k_tile_hdr (launched afterwards) overwrites them
-    hipLaunchKernelGGL(k_tile_window, dim3(div_up(g.p - 1, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g,
-                       d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.tile_hdr, xwin_elems(value_size),
-                       value_size == 8 ? 4 : 5);
+    hipLaunchKernelGGL(k_tile_tables, dim3(div_up(g.p, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
+                       d.tile_ptr, d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.tile_hdr, d.counters,
+                       xwin_elems(value_size), value_size == 8 ? 4 : 5);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
-    int blocks = div_up(g.p - 1, 256 * 8);
-    blocks = blocks > 64 ? 64 : blocks;
-    hipLaunchKernelGGL(k_window_stats, dim3(blocks), dim3(256), 0, s, g.p - 1, d.tile_hdr, d.counters);
-    return hipGetLastError();
-}
-
-hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, uint32_t *host_words, hipStream_t s)
-{
-    if (g.p <= 0)
-        return hipSuccess;
-    hipLaunchKernelGGL(k_tile_hdr, dim3(div_up(g.p, FMT_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.tile_ptr,
-                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr, d.offset_ptr, d.counters, host_words);
+    int blocks = div_up(g.p, 1024 * 16);
+    blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
+    hipLaunchKernelGGL(k_stats_export, dim3(blocks), dim3(1024), 0, s, g, d.tile_ptr, d.tile_hdr, d.offset_ptr,
+                       d.counters, host_words);
     return hipGetLastError();
 }
 

@@ -22,6 +22,8 @@ constexpr int FMT_WAVES_PER_BLOCK = 2;
 constexpr int FMT_BLOCK = OMEGA * FMT_WAVES_PER_BLOCK;
 constexpr int BIT_SS = 6;                     // bits of scansum_offset at omega = 64
 constexpr uint32_t ROW_MASK = 0x7FFFFFFFu;    // tile_ptr bit 31 = "tile has empty rows"
+constexpr int STAMP_WORD = 8;                 // counters[8..15]: wall-clock stamps of the conversion phases
+constexpr int COUNTER_WORDS = 16;
 constexpr int NUM_XCD = 8;
 constexpr int RUN_SERIAL_MAX = 64;            // carry runs up to this many tiles resolve in-kernel; longer ones in k_calibrate
 #ifndef CSR5_XWIN_BYTES
@@ -66,7 +68,8 @@ struct DeviceArrays {
     uint32_t *carry_cnt;    // [p], all zero between launches
     uint32_t *carry_meta;   // [p] x uint4 per tile: see k_carry_meta in csr5_format.hip
     uint32_t *tile_hdr;     // [8p] fused kernel: carry_meta[t], carry_meta[t+1].x and the tile_ptr pair in ONE 32-B record
-    uint32_t *counters;     // [4] conversion statistics: x-window tiles, covered non-zeros, long runs
+    uint32_t *counters;     // [16] conversion statistics: x-window tiles, covered non-zeros, long runs, gather lines; [4] = workgroups
+                            // done; [8..15] = four 64-bit wall-clock stamps, one per conversion phase (k_row_scan, k_tile_desc, ...)
     // column-slab child with an LDS hot table (csr5_slab.hip / k_spmv_hot): column words with bit 31 set index the table
     const int32_t *hot_cols;   // [hot_slabs * hot_capacity]
     const int32_t *hot_count;  // [hot_slabs]
@@ -75,7 +78,6 @@ struct DeviceArrays {
 };
 
 // ---- conversion (csr5_format.hip) ----
-hipError_t launch_tile_ptr(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_row_scan(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_tile_desc(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 size_t offset_scan_tmp_bytes(int entries);
@@ -83,9 +85,7 @@ hipError_t launch_offset_scan(const Geometry &g, const DeviceArrays &d, void *tm
 hipError_t launch_desc_offset(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c,
                             hipStream_t s);
-hipError_t launch_carry_meta(const Geometry &g, const DeviceArrays &d, hipStream_t s);
-hipError_t launch_tile_window(const Geometry &g, const DeviceArrays &d, int value_size, hipStream_t s);
-hipError_t launch_tile_hdr(const Geometry &g, const DeviceArrays &d, uint32_t *host_words, hipStream_t s);
+hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int value_size, uint32_t *host_words, hipStream_t s);
 hipError_t launch_warmup(hipStream_t s);
 // flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)
 hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,
