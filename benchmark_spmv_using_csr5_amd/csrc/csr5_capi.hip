@@ -128,6 +128,7 @@ struct csr5hip_handle_s {
     double t_slab = 0;
     csr5hip_handle_s *slab_child = nullptr;
     Buffer b_row_ptr2, b_col2, b_val2, b_P, b_mask, b_base;
+    Buffer b_slab_tmp; // temporaries of the slab build; kept between conversions only while small (SLAB_TMP_KEEP)
     // LDS hot table of the slab child (k_spmv_hot): chosen at conversion, see csr5_slab.hip
     int hot_request = 1;      // CSR5HIP_OPT_SLAB_HOT: 0 off, 1 auto, 2 force
     bool hot_enabled = false; // (child) column words are hot-encoded: spmv must use the persistent hot kernel
@@ -319,6 +320,11 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         if (value != 0 && value != 1)
             return CSR5HIP_INVALID_ARGUMENT;
         h->opt.mode = value;
+        if (h->slab_S > 0 && h->slab_child->hot_enabled && value != 1) {
+            // the hot table exists for the fused kernel only and its column words are encoded: rebuild without it
+            h->drop_graphs();
+            return build_slabs(h);
+        }
         break;
     case CSR5HIP_OPT_XCD_REMAP:
         h->opt.xcd_remap = value ? 1 : 0;
@@ -377,7 +383,7 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
     default:
         return CSR5HIP_INVALID_ARGUMENT;
     }
-    if (h->slab_child && (option == CSR5HIP_OPT_SPMV_MODE || option == CSR5HIP_OPT_LDS_Y || option == CSR5HIP_OPT_STREAM_NT))
+    if (h->slab_S > 0 && (option == CSR5HIP_OPT_SPMV_MODE || option == CSR5HIP_OPT_LDS_Y || option == CSR5HIP_OPT_STREAM_NT))
         csr5hip_set_option(h->slab_child, option, value);
     h->drop_graphs();
     return CSR5HIP_SUCCESS;
@@ -596,8 +602,22 @@ static void release_slabs(csr5hip_handle h)
         h->slab_child = nullptr;
     }
     for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_mask, &h->b_base, &h->b_hot_cols,
-                      &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off})
+                      &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_slab_tmp})
         b->release();
+    h->slab_S = 0;
+    h->slab_m2 = 0;
+    h->hot_cover_pct = 0;
+}
+// asCSR: the slab structure goes out of use but keeps its memory and its child handle, like the arena (capacity only
+// grows until csr5hip_free) -- a reconversion then allocates nothing.  Ten hipMalloc/hipFree pairs were two thirds of
+// the 1.9-ms conversion of a 3 M-nnz matrix.
+static void deactivate_slabs(csr5hip_handle h)
+{
+    if (h->slab_child) {
+        h->slab_child->drop_graphs();
+        h->slab_child->format = -1;
+        h->slab_child->hot_enabled = false;
+    }
     h->slab_S = 0;
     h->slab_m2 = 0;
     h->hot_cover_pct = 0;
@@ -627,34 +647,47 @@ static int slab_count_for(const csr5hip_handle_s *h)
 
 static int build_slabs(csr5hip_handle h)
 {
-    release_slabs(h);
+    deactivate_slabs(h);
     h->t_slab = 0;
     const int S = slab_count_for(h);
-    if (!S)
+    if (!S) {
+        release_slabs(h); // not wanted (any more): give the memory back
         return CSR5HIP_SUCCESS;
+    }
     const double t0 = now_ms();
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
     int bits = 0;
     while ((1 << bits) < S)
         bits++;
-    struct Temps {
-        void *hist = nullptr, *scan_tmp = nullptr, *key = nullptr, *count = nullptr, *sel_tmp = nullptr;
-        ~Temps()
-        {
-            for (void *p : {hist, scan_tmp, key, count, sel_tmp})
-                if (p)
-                    (void)hipFree(p);
-        }
-    } t;
+    // all temporaries of the build in one allocation
+    constexpr size_t SLAB_TMP_KEEP = (size_t)64 << 20;
     size_t scan_bytes = 0, sel_bytes = 0;
     HIP_TRY(slab_scan_tmp_bytes((size_t)S * g.p, &scan_bytes));
     HIP_TRY(slab_select_tmp_bytes(g.nnz, &sel_bytes));
-    HIP_TRY(hipMalloc(&t.hist, (size_t)S * g.p * 4));
-    HIP_TRY(hipMalloc(&t.scan_tmp, scan_bytes ? scan_bytes : 4));
-    HIP_TRY(hipMalloc(&t.key, (size_t)g.nnz * 8));
-    HIP_TRY(hipMalloc(&t.count, 4));
-    HIP_TRY(hipMalloc(&t.sel_tmp, sel_bytes ? sel_bytes : 4));
+    const size_t nb = (size_t)(g.n > 0 ? g.n : 1) * 4, hb = (size_t)S * slab_hot_buckets() * 4;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    const size_t o_hist = take((size_t)S * g.p * 4), o_scan = take(scan_bytes), o_key = take((size_t)g.nnz * 8),
+                 o_count = take(16), o_sel = take(sel_bytes), o_cnt = take(nb), o_hotmap = take(nb), o_chist = take(hb),
+                 o_thr = take((size_t)S * 4);
+    HIP_TRY(h->b_slab_tmp.reserve(off));
+    struct TmpGuard { // big temporaries (8 B per non-zero) do not outlive the build
+        Buffer &b;
+        ~TmpGuard()
+        {
+            if (b.cap > SLAB_TMP_KEEP)
+                b.release();
+        }
+    } tmp_guard{h->b_slab_tmp};
+    char *tb = (char *)h->b_slab_tmp.ptr;
+    struct {
+        void *hist, *scan_tmp, *key, *count, *sel_tmp;
+    } t{tb + o_hist, tb + o_scan, tb + o_key, tb + o_count, tb + o_sel};
     HIP_TRY(h->b_col2.reserve((size_t)g.nnz * 4));
     HIP_TRY(h->b_val2.reserve((size_t)g.nnz * h->vsize()));
     HIP_TRY(slab_partition(g, h->d, h->value_type, S, bits, h->slab_shift, (uint32_t *)t.hist, t.scan_tmp, scan_bytes,
@@ -708,21 +741,9 @@ static int build_slabs(csr5hip_handle h)
         // a slot is staged by each of the ~32 workgroups of the slab's XCD in every SpMV: it must be used more often
         int min_count = 48 / stride;
         min_count = min_count < 2 ? 2 : min_count;
-        struct HotTemps {
-            void *cnt = nullptr, *hotmap = nullptr, *chist = nullptr, *thr = nullptr, *covered = nullptr;
-            ~HotTemps()
-            {
-                for (void *p : {cnt, hotmap, chist, thr, covered})
-                    if (p)
-                        (void)hipFree(p);
-            }
-        } ht;
-        const size_t nb = (size_t)(g.n > 0 ? g.n : 1) * 4, hb = (size_t)S * slab_hot_buckets() * 4;
-        HIP_TRY(hipMalloc(&ht.cnt, nb));
-        HIP_TRY(hipMalloc(&ht.hotmap, nb));
-        HIP_TRY(hipMalloc(&ht.chist, hb));
-        HIP_TRY(hipMalloc(&ht.thr, (size_t)S * 4));
-        HIP_TRY(hipMalloc(&ht.covered, 8));
+        struct {
+            void *cnt, *hotmap, *chist, *thr, *covered;
+        } ht{tb + o_cnt, tb + o_hotmap, tb + o_chist, tb + o_thr, tb + o_count + 8};
         HIP_TRY(h->b_hot_cols.reserve((size_t)S * hot_capacity * 4));
         HIP_TRY(h->b_hot_count.reserve((size_t)S * 4));
         HIP_TRY(h->b_hot_tile0.reserve(((size_t)S + 1) * 4));
@@ -750,10 +771,10 @@ static int build_slabs(csr5hip_handle h)
             HIP_TRY(hipStreamSynchronize(s));
         }
     }
-    // (the temporaries are released when `t` goes out of scope)
 
     // the stacked matrix: an ordinary CSR matrix with m2 rows, converted and multiplied by the ordinary kernels
-    csr5hip_handle c = new csr5hip_handle_s();
+    csr5hip_handle c = h->slab_child ? h->slab_child : new csr5hip_handle_s(); // (kept across asCSR/asCSR5 cycles)
+    h->slab_child = c;
     c->is_child = true;
     c->g.m = (int)m2;
     c->g.n = g.n;
@@ -776,11 +797,9 @@ static int build_slabs(csr5hip_handle h)
     if (rc == CSR5HIP_SUCCESS)
         rc = csr5hip_as_csr5(c);
     if (rc != CSR5HIP_SUCCESS) {
-        csr5hip_free(c);
         release_slabs(h);
         return rc;
     }
-    h->slab_child = c;
     h->slab_S = S;
     h->slab_m2 = (int)m2;
     h->t_slab = now_ms() - t0;
@@ -1029,7 +1048,7 @@ int csr5hip_as_csr(csr5hip_handle h)
     if (h->format != CSR5HIP_FORMAT_CSR5)
         return CSR5HIP_UNKOWN_FORMAT;
     h->drop_graphs();
-    release_slabs(h);
+    deactivate_slabs(h);
     HIP_TRY(launch_transpose(h->g, h->d, h->value_type, false, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     // the aux buffers stay cached in the handle (capacity only grows) until csr5hip_free
@@ -1248,10 +1267,10 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->column_slabs = h->slab_S;
     info->slab_shift = h->slab_shift;
     info->slab_segments = h->slab_m2;
-    info->slab_sigma = h->slab_child ? h->slab_child->g.sigma : 0;
-    info->slab_tiles = h->slab_child ? h->slab_child->g.p : 0;
+    info->slab_sigma = h->slab_S > 0 ? h->slab_child->g.sigma : 0;
+    info->slab_tiles = h->slab_S > 0 ? h->slab_child->g.p : 0;
     info->t_slab_ms = h->t_slab;
-    info->slab_hot = h->slab_child && h->slab_child->hot_enabled ? 1 : 0;
+    info->slab_hot = h->slab_S > 0 && h->slab_child->hot_enabled ? 1 : 0;
     info->slab_hot_cover_pct = h->hot_cover_pct;
     return CSR5HIP_SUCCESS;
 }

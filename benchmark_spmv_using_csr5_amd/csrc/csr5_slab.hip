@@ -171,17 +171,28 @@ struct SegmentStart {
     __device__ bool operator()(const int &j) const { return j == 0 || key[j] != key[j - 1]; }
 };
 
+// (one atomic per WORKGROUP of a bounded grid: one per wavefront of 65 536 workgroups was 262 k increments of a single
+// word, 2.9 of the kernel's 3.0 ms on R-MAT 24)
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_slab_count_segments(int nnz, const unsigned long long *__restrict__ key, unsigned int *__restrict__ count)
 {
+    __shared__ unsigned part[SLAB_BLOCK / OMEGA];
     unsigned local = 0;
     for (size_t j = (size_t)blockIdx.x * SLAB_BLOCK + threadIdx.x; j < (size_t)nnz; j += (size_t)gridDim.x * SLAB_BLOCK)
         local += j == 0 || key[j] != key[j - 1];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         local += __shfl_xor(local, d, OMEGA);
-    if ((threadIdx.x & (OMEGA - 1)) == 0 && local)
-        atomicAdd(count, local);
+    if ((threadIdx.x & (OMEGA - 1)) == 0)
+        part[threadIdx.x / OMEGA] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+        for (int w = 0; w < SLAB_BLOCK / OMEGA; w++)
+            total += part[w];
+        if (total)
+            atomicAdd(count, total);
+    }
 }
 
 // one thread per segment s: mask bit of (row, slab); the first segment of a slab inside a 64-row block records its
@@ -329,31 +340,75 @@ k_col_count(int nnz, int stride, const int32_t *__restrict__ col, uint32_t *__re
     }
 }
 
+// Histogram of the use counts per slab.  Most columns have SMALL counts (on a matrix without popular columns all of
+// them: one million increments on eighty words took 0.56 ms), so the buckets below HOT_LOW are accumulated per workgroup
+// in LDS and flushed once; only the rare large counts go to memory directly.
+constexpr int HOT_LOW = 64;
+constexpr int HOT_HIST_COLS = 4096; // columns per workgroup
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_hot_hist(int n, const uint32_t *__restrict__ cnt, int bits, int shift, uint32_t *__restrict__ chist)
+k_hot_hist(int n, const uint32_t *__restrict__ cnt, int S, int bits, int shift, uint32_t *__restrict__ chist)
 {
-    const int c = blockIdx.x * SLAB_BLOCK + threadIdx.x;
-    if (c >= n)
-        return;
-    const uint32_t v = cnt[c];
-    if (v)
-        atomicAdd(&chist[(size_t)slab_of((uint32_t)c, shift, bits) * HOT_BUCKETS + (v < HOT_BUCKETS - 1 ? v : HOT_BUCKETS - 1)], 1u);
+    __shared__ uint32_t low[SLAB_MAX * HOT_LOW];
+    for (int i = threadIdx.x; i < S * HOT_LOW; i += SLAB_BLOCK)
+        low[i] = 0;
+    __syncthreads();
+    const int first = blockIdx.x * HOT_HIST_COLS;
+    for (int c = first + threadIdx.x; c < first + HOT_HIST_COLS && c < n; c += SLAB_BLOCK) {
+        const uint32_t v = cnt[c];
+        if (!v)
+            continue;
+        const uint32_t k = slab_of((uint32_t)c, shift, bits);
+        if (v < HOT_LOW)
+            atomicAdd(&low[k * HOT_LOW + v], 1u);
+        else
+            atomicAdd(&chist[(size_t)k * HOT_BUCKETS + (v < HOT_BUCKETS - 1 ? v : HOT_BUCKETS - 1)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < S * HOT_LOW; i += SLAB_BLOCK)
+        if (low[i])
+            atomicAdd(&chist[(size_t)(i / HOT_LOW) * HOT_BUCKETS + i % HOT_LOW], low[i]);
 }
 
-// one workgroup per slab: thr[k] = smallest bucket b >= min_count such that the columns with count >= b fit
-__global__ void __launch_bounds__(64)
+// one wavefront per slab: thr[k] = smallest bucket b >= min_count such that the columns with count >= b fit, i.e.
+// suffix(b) = sum of h[b..] <= capacity - 1 (slot 0 is reserved).  suffix() only grows as b falls, so the answer is
+// the minimum over the lanes of "lowest fitting bucket of my 32" (a serial walk of 2 048 dependent loads took 0.12 ms).
+__global__ void __launch_bounds__(OMEGA)
 k_hot_threshold(int capacity, int min_count, const uint32_t *__restrict__ chist, uint32_t *__restrict__ thr)
 {
-    if (threadIdx.x != 0)
-        return;
-    const uint32_t *h = chist + (size_t)blockIdx.x * HOT_BUCKETS;
-    uint32_t total = 0;
-    int b = HOT_BUCKETS;
-    while (b - 1 >= min_count && total + h[b - 1] <= (uint32_t)(capacity - 1)) { // slot 0 is reserved
-        b--;
-        total += h[b];
+    constexpr int PER = HOT_BUCKETS / OMEGA;
+    const int lane = threadIdx.x;
+    const uint32_t *h = chist + (size_t)blockIdx.x * HOT_BUCKETS + lane * PER;
+    uint32_t v[PER];
+    unsigned long long own = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        v[i] = h[i];
+        own += v[i];
     }
-    thr[blockIdx.x] = (uint32_t)b;
+    // exclusive suffix over the lanes: sum of the lanes above
+    unsigned long long incl = own;
+#pragma unroll
+    for (int d = 1; d < OMEGA; d <<= 1) {
+        const unsigned long long o = __shfl_down(incl, d, OMEGA);
+        if (lane + d < OMEGA)
+            incl += o;
+    }
+    unsigned long long total = incl - own;
+    int best = HOT_BUCKETS; // suffix(HOT_BUCKETS) = 0 always fits
+#pragma unroll
+    for (int i = PER - 1; i >= 0; i--) {
+        total += v[i];
+        const int b = lane * PER + i;
+        if (b >= min_count && total <= (unsigned long long)(capacity - 1))
+            best = b;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(best, d, OMEGA);
+        best = o < best ? o : best;
+    }
+    if (lane == 0)
+        thr[blockIdx.x] = (uint32_t)best;
 }
 
 // pass 0: every column with count >= thr gets a slot; pass 1: columns of the next lower count fill what is left
@@ -363,23 +418,28 @@ k_hot_assign(int n, const uint32_t *__restrict__ cnt, int bits, int shift, const
              int32_t *__restrict__ hotmap, unsigned long long *__restrict__ covered)
 {
     const int c = blockIdx.x * SLAB_BLOCK + threadIdx.x;
-    if (c >= n)
-        return;
-    const uint32_t v = cnt[c];
-    if (!v)
-        return;
-    const uint32_t k = slab_of((uint32_t)c, shift, bits);
-    const uint32_t bucket = v < HOT_BUCKETS - 1 ? v : HOT_BUCKETS - 1;
-    const uint32_t b = thr[k];
-    const bool take = pass == 0 ? bucket >= b : (bucket + 1 == b && (int)bucket >= min_count);
-    if (!take)
-        return;
-    const int slot = atomicAdd(&hot_count[k], 1);
-    if (slot < capacity) {
-        hot_cols[(size_t)k * capacity + slot] = c;
-        hotmap[c] = slot;
-        atomicAdd(covered, (unsigned long long)v);
+    const uint32_t v = c < n ? cnt[c] : 0u;
+    unsigned long long got = 0;
+    if (v) {
+        const uint32_t k = slab_of((uint32_t)c, shift, bits);
+        const uint32_t bucket = v < HOT_BUCKETS - 1 ? v : HOT_BUCKETS - 1;
+        const uint32_t b = thr[k];
+        const bool take = pass == 0 ? bucket >= b : (bucket + 1 == b && (int)bucket >= min_count);
+        if (take) {
+            const int slot = atomicAdd(&hot_count[k], 1);
+            if (slot < capacity) {
+                hot_cols[(size_t)k * capacity + slot] = c;
+                hotmap[c] = slot;
+                got = v;
+            }
+        }
     }
+    // sampled non-zeros that found a slot: one increment per wavefront (196 k increments of one word on R-MAT 24)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        got += __shfl_xor(got, d, OMEGA);
+    if ((threadIdx.x & (OMEGA - 1)) == 0 && got)
+        atomicAdd(covered, got);
 }
 
 // clamp the slot counts; first tile OWNED by every slab (a tile belongs to the slab of its first element)
@@ -475,7 +535,7 @@ hipError_t slab_count_segments(int nnz, const unsigned long long *key2, unsigned
     if (e != hipSuccess)
         return e;
     long long blocks = ((long long)nnz + SLAB_BLOCK * 16 - 1) / (SLAB_BLOCK * 16);
-    blocks = blocks < 1 ? 1 : (blocks > 65536 ? 65536 : blocks);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
     hipLaunchKernelGGL(k_slab_count_segments, dim3((unsigned)blocks), dim3(SLAB_BLOCK), 0, s, nnz, key2, d_count);
     return hipGetLastError();
 }
@@ -556,8 +616,9 @@ hipError_t slab_hot_select(int n, int nnz, int p_hist, int p, int T, int S, int 
         return e;
     hipLaunchKernelGGL(k_col_count, dim3((unsigned)blocks), dim3(SLAB_BLOCK), 0, s, nnz, sample_stride, col2, cnt);
     const dim3 cols_grid((n + SLAB_BLOCK - 1) / SLAB_BLOCK);
-    hipLaunchKernelGGL(k_hot_hist, cols_grid, dim3(SLAB_BLOCK), 0, s, n, cnt, bits, shift, chist);
-    hipLaunchKernelGGL(k_hot_threshold, dim3(S), dim3(64), 0, s, capacity, min_count, chist, thr);
+    hipLaunchKernelGGL(k_hot_hist, dim3((n + HOT_HIST_COLS - 1) / HOT_HIST_COLS), dim3(SLAB_BLOCK), 0, s, n, cnt, S, bits, shift,
+                       chist);
+    hipLaunchKernelGGL(k_hot_threshold, dim3(S), dim3(OMEGA), 0, s, capacity, min_count, chist, thr);
     for (int pass = 0; pass < 2; pass++)
         hipLaunchKernelGGL(k_hot_assign, cols_grid, dim3(SLAB_BLOCK), 0, s, n, cnt, bits, shift, thr, capacity, min_count,
                            pass, hot_count, hot_cols, hotmap, covered);

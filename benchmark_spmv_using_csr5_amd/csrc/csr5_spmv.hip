@@ -1021,6 +1021,8 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
                 return opt.lds_y ? launch_one<VT, S, FUSED, false, true, true>(g, d, x, y, opt, s) \
                                  : launch_one<VT, S, FUSED, false, false, true>(g, d, x, y, opt, s); \
         }                                                                                          \
+        if (opt.hot) /* hot-encoded column words are only understood by the fused persistent kernel */ \
+            return hipErrorInvalidValue;                                                           \
         return opt.lds_y ? launch_one<VT, S, FUSED, false, true>(g, d, x, y, opt, s)               \
                          : launch_one<VT, S, FUSED, false, false>(g, d, x, y, opt, s);
 #if defined(CSR5_ABLATE) || defined(CSR5_FEW_SIGMAS) // experiment builds: few instantiations only
@@ -1033,7 +1035,7 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
         CSR5_CASE(29) CSR5_CASE(30) CSR5_CASE(31) CSR5_CASE(32)
 #endif
 #undef CSR5_CASE
-    default: return launch_one<VT, 0, FUSED, false, false>(g, d, x, y, opt, s);
+    default: return opt.hot ? hipErrorInvalidValue : launch_one<VT, 0, FUSED, false, false>(g, d, x, y, opt, s);
     }
 }
 

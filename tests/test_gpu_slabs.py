@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
+from benchmark_spmv_using_csr5_amd import _capi  # noqa: E402
 from benchmark_spmv_using_csr5_amd import handle as H  # noqa: E402
 from benchmark_spmv_using_csr5_amd import matrices as M  # noqa: E402
 from tests import zoo  # noqa: E402
@@ -233,4 +234,43 @@ def test_slab_hot_rmat_device():
     torch.cuda.synchronize()
     assert torch.equal(y[nonempty], ref[nonempty])
     assert A.destroy() == 0
+    A.close()
+
+
+def test_slab_cycles_and_mode_switch(oracle):
+    """The slab structure keeps its memory and its child handle over asCSR / asCSR5 cycles (nothing is reallocated):
+    every cycle must give the same y, also when the slab count, the hot table or sigma change in between; switching a
+    converted matrix with a hot table to the two-pass mode rebuilds the structure without the table (its column words
+    are encoded for the fused persistent kernel only)."""
+    mat = _hub_columns_matrix(30000, 200000, 9, 400, 7)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=3, mode="int")
+    exp = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    nonempty = np.diff(mat.row_ptr) > 0
+    rp, ci, va = _device_csr(mat, val, np.float64)
+    ci0, va0 = ci.clone(), va.clone()
+    xd = torch.from_numpy(x).to(DEV)
+    yd = torch.zeros(mat.m, dtype=torch.float64, device=DEV)
+    A = H.anonymouslibHandle(mat.m, mat.n)
+    assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0
+    plan = [(16, 8, 2), (16, 8, 2), (6, 16, 0), (16, 0, 1), (12, 32, 2), (16, 8, 1)]
+    for sigma, slabs, hot in plan:
+        assert A.setSigma(sigma) == 0 and A.setColumnSlabs(slabs) == 0 and A.setSlabHot(hot) == 0
+        assert A.asCSR5() == 0, _capi.last_error()
+        i = A.info()
+        assert i.column_slabs == slabs and i.slab_hot == (1 if hot == 2 and slabs else i.slab_hot)
+        yd.fill_(0.0)
+        assert A.spmv(1.0, yd) == 0
+        torch.cuda.synchronize()
+        y = yd.cpu().numpy()
+        assert np.array_equal(y[nonempty], exp[nonempty]), (sigma, slabs, hot)
+        if hot == 2 and slabs:
+            assert A.setSpmvMode(H.SPMV_TWO_PASS) == 0, _capi.last_error()
+            assert A.info().slab_hot == 0 and A.info().column_slabs == slabs
+            yd.fill_(0.0)
+            assert A.spmv(1.0, yd) == 0
+            torch.cuda.synchronize()
+            assert np.array_equal(yd.cpu().numpy()[nonempty], exp[nonempty]), ("two-pass", sigma, slabs)
+            assert A.setSpmvMode(H.SPMV_FUSED) == 0
+        assert A.asCSR() == 0
+        assert torch.equal(ci, ci0) and torch.equal(va, va0), "asCSR restores the caller's arrays"
     A.close()
