@@ -5,7 +5,7 @@
 
 A "step" is one SpMV pass (one ``spmv()`` call: y = A*x) over the rank's matrix shard, with every input already
 resident in HBM.  The default workload is BASELINE.json configs[3], the configuration the metric spans: synthetic
-R-MAT scale 24 (16.7 M rows, 268 M non-zeros, fp64), STRONG scaling: ONE global matrix cut into N nnz-balanced row
+R-MAT scale 24 (16.7 M rows, 268 M non-zeros, fp64), STRONG scaling: ONE global matrix cut into N cost-balanced (nnz + 2 * rows) row
 blocks, x replicated by ONE RCCL broadcast before the loop, no per-step collective.  At N = 1
 the whole matrix sits on one GPU (3.56 GB of algorithmic bytes per SpMV), so the N = 1 value is the first point of
 the 1 -> 8 curve.  value = 2 * nnz_total * K / (max-over-ranks wall time of the K steps).
@@ -91,7 +91,7 @@ def parse_args():
     ap.add_argument("--slab-shift", type=int, default=None)
     ap.add_argument("--slab-hot", default="auto", choices=["auto", "off", "force"], help="LDS hot table of the slab kernel")
     ap.add_argument("--scaling", default=None, choices=[None, "weak", "strong"],
-                    help="N > 1: strong (default for R-MAT) = ONE global matrix cut into nnz-balanced row blocks; "
+                    help="N > 1: strong (default for R-MAT) = ONE global matrix cut into cost-balanced (nnz + 2 * rows) row blocks; "
                          "weak = one fixed-size row block per GPU")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--scale", type=float, default=1.0, help="size factor of the synthetic stand-in (experiments)")
@@ -122,11 +122,11 @@ def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device, s
     kw = {} if scale == 1.0 else {"scale": scale}
     if workload in ("webbase", "scircuit") and band is not None:
         kw["band"] = band
-    if strong and world > 1:  # one global matrix, nnz-balanced row blocks (sharding.py)
+    if strong and world > 1:  # one global matrix, cost-balanced row blocks (sharding.py)
         from benchmark_spmv_using_csr5_amd import sharding as S
         full = gen(seed=seed, dtype=dtype, **kw)
         blk = S.extract_row_block(full.row_ptr, full.col, full.val, full.n,
-                                  S.partition_rows_by_nnz(full.row_ptr, world), rank)
+                                  S.partition_rows_by_cost(full.row_ptr, world), rank)
         return M.CsrMatrix(blk.m, blk.n, blk.row_ptr, blk.col, blk.val, full.name), full.name
     mat = gen(seed=seed + 101 * rank, dtype=dtype, **kw)
     if world > 1:  # weak: spread the block's columns over the global column space of all blocks
@@ -469,7 +469,7 @@ def main():
                                         steps, warmup)
             roof["cold"] = cold_dict(prob, cold_ms, k, cs)
         part = ("whole matrix on one GPU" if world == 1 else
-                f"{scaling} scaling, {'nnz-balanced row blocks of ONE matrix' if scaling == 'strong' else 'one fixed-size row block per GPU'}, "
+                f"{scaling} scaling, {'row blocks of ONE matrix balanced by nnz + 2 * rows' if scaling == 'strong' else 'one fixed-size row block per GPU'}, "
                 "x replicated by one RCCL broadcast, no per-step collective")
         cfg = {"workload": f"{label}: CSR->CSR5 (omega=64, sigma={info.sigma}) + CSR5 SpMV, {part}",
                **config_dict(prob, args, ingest_ms)}

@@ -36,6 +36,7 @@ OPT_COLUMN_SLABS = 6
 OPT_SLAB_SHIFT = 7
 OPT_ZERO_EMPTY_ROWS = 8
 OPT_SLAB_HOT = 9
+MULTI_OPT_ROW_WEIGHT = 100  # csr5hip_multi_set_option only (before input_csr)
 
 
 class Csr5Info(C.Structure):

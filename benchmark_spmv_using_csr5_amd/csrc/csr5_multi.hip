@@ -79,12 +79,13 @@ int fail(hipError_t e, const char *what)
             return rc_;                                                                            \
     } while (0)
 
-__device__ __forceinline__ int upper_bound_rows(const int32_t *a, long long key, int size)
+// number of r in [0, size) with row_ptr[r] + weight * r <= key (the cost prefix is sorted: both terms are monotone)
+__device__ __forceinline__ int upper_bound_cost(const int32_t *a, long long weight, long long key, int size)
 {
     int lo = 0, hi = size;
     while (lo < hi) {
         const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-        if ((long long)a[mid] <= key)
+        if ((long long)a[mid] + weight * mid <= key)
             lo = mid + 1;
         else
             hi = mid;
@@ -92,14 +93,17 @@ __device__ __forceinline__ int upper_bound_rows(const int32_t *a, long long key,
     return lo;
 }
 
-// cut[g] = first row of block g: the row that contains non-zero number g*nnz/G (cut[0] = 0, cut[G] = m), monotone
-__global__ void k_row_cuts(int m, int nnz, int G, const int32_t *__restrict__ row_ptr, int32_t *__restrict__ cut)
+// cut[g] = first row of block g: the last row whose cost prefix (non-zeros + weight * rows before it) is <= g/G of the
+// total (cut[0] = 0, cut[G] = m), monotone.  weight = 0: the row that contains non-zero number g*nnz/G.
+__global__ void k_row_cuts(int m, int nnz, int G, int weight, const int32_t *__restrict__ row_ptr,
+                           int32_t *__restrict__ cut)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
+    const long long total = (long long)nnz + (long long)weight * m;
     cut[0] = 0;
     for (int g = 1; g < G; g++) {
-        int r = upper_bound_rows(row_ptr, (long long)g * nnz / G, m + 1) - 1;
+        int r = upper_bound_cost(row_ptr, weight, (long long)g * total / G, m + 1) - 1;
         r = r < cut[g - 1] ? cut[g - 1] : (r > m ? m : r);
         cut[g] = r;
     }
@@ -117,6 +121,7 @@ __global__ void k_rebase(int count, int32_t base, int32_t *__restrict__ row_ptr)
 
 struct csr5hip_multi_s {
     int G = 0, m = 0, n = 0, nnz = 0, value_type = CSR5HIP_F64;
+    int row_weight = CSR5HIP_MULTI_DEFAULT_ROW_WEIGHT;
     std::vector<int> dev, cut, shard_nnz;
     std::vector<csr5hip_handle> h;
     std::vector<hipStream_t> stream;
@@ -204,7 +209,7 @@ int csr5hip_multi_input_csr(csr5hip_multi mh, int nnz, const int32_t *d_row_ptr,
     MHIP(hipSetDevice(mh->dev[0]));
     int32_t *d_cut = nullptr;
     MHIP(hipMalloc(&d_cut, ((size_t)G + 1) * 4));
-    hipLaunchKernelGGL(k_row_cuts, dim3(1), dim3(64), 0, mh->stream[0], mh->m, nnz, G, d_row_ptr, d_cut);
+    hipLaunchKernelGGL(k_row_cuts, dim3(1), dim3(64), 0, mh->stream[0], mh->m, nnz, G, mh->row_weight, d_row_ptr, d_cut);
     std::vector<int32_t> cut(G + 1), ptr_at(G + 1);
     hipError_t e = hipMemcpyAsync(cut.data(), d_cut, ((size_t)G + 1) * 4, hipMemcpyDeviceToHost, mh->stream[0]);
     if (e == hipSuccess)
@@ -271,6 +276,12 @@ int csr5hip_multi_set_option(csr5hip_multi mh, int option, int value)
 {
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
+    if (option == CSR5HIP_MULTI_OPT_ROW_WEIGHT) { // takes effect at the next input_csr
+        if (value < 0 || value > 64)
+            return CSR5HIP_INVALID_ARGUMENT;
+        mh->row_weight = value;
+        return CSR5HIP_SUCCESS;
+    }
     for (int g = 0; g < mh->G; g++)
         if (mh->h[g]) {
             MHIP(hipSetDevice(mh->dev[g]));

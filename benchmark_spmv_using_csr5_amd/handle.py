@@ -225,7 +225,7 @@ class anonymouslibHandle:
 
 
 class MultiGpuHandle:
-    """One matrix on the G GPUs of a node through the C ABI (``csr5hip_multi_*``, include/csr5hip.h): nnz-balanced row
+    """One matrix on the G GPUs of a node through the C ABI (``csr5hip_multi_*``, include/csr5hip.h): cost-balanced (nnz + 2 * rows) row
     blocks, one ordinary handle + stream per device, x replicated by ONE RCCL broadcast at ``setX``, y sharded.
     ``devices`` may repeat a device id (several shards on one GPU) -- how a 1-GPU box exercises the path."""
 
@@ -252,6 +252,10 @@ class MultiGpuHandle:
 
     def setOption(self, option: int, value: int) -> int:
         return self._lib.csr5hip_multi_set_option(self._h, int(option), int(value))
+
+    def setRowWeight(self, weight: int) -> int:
+        """cost of a row in non-zeros when the row blocks are cut (default 2; 0 = plain nnz balance); before inputCSR"""
+        return self.setOption(_capi.MULTI_OPT_ROW_WEIGHT, int(weight))
 
     def asCSR5(self) -> int:
         return self._lib.csr5hip_multi_as_csr5(self._h)

@@ -270,14 +270,14 @@ def rmat_device(scale: int, edge_factor: int, seed: int, rank: int, world: int, 
                 abcd=(0.57, 0.19, 0.19, 0.05), strong: bool = False) -> DeviceCsr:
     """weak (default): one row block per rank, every rank owns a 2^scale-row R-MAT block whose columns
     are spread over the world * 2^scale global columns.
-    strong: ONE global 2^scale R-MAT (same seed on every rank), cut into `world` nnz-balanced row
-    blocks (sharding.partition_rows_by_nnz); the rank keeps its block with global columns."""
+    strong: ONE global 2^scale R-MAT (same seed on every rank), cut into `world` cost-balanced row
+    blocks (sharding.partition_rows_by_cost); the rank keeps its block with global columns."""
     import torch
 
     if strong and world > 1:
-        from .sharding import partition_rows_by_nnz
+        from .sharding import partition_rows_by_cost
         full = rmat_device(scale, edge_factor, seed, 0, 1, device, abcd=abcd)
-        cuts = partition_rows_by_nnz(full.row_ptr.cpu().numpy(), world)
+        cuts = partition_rows_by_cost(full.row_ptr.cpu().numpy(), world)
         lo, hi = int(cuts[rank]), int(cuts[rank + 1])
         a, b = int(full.row_ptr[lo]), int(full.row_ptr[hi])
         row_ptr = (full.row_ptr[lo: hi + 1] - a).to(torch.int32).contiguous()
@@ -314,11 +314,12 @@ def rmat_device(scale: int, edge_factor: int, seed: int, rank: int, world: int, 
 
 
 def rmat_device_shard(scale: int, edge_factor: int, seed: int, rank: int, world: int, device,
-                      abcd=(0.57, 0.19, 0.19, 0.05), chunk_log2: int = 24) -> DeviceCsr:
-    """Row block `rank` of ONE global 2^scale R-MAT cut into `world` nnz-balanced row blocks (strong scaling,
+                      abcd=(0.57, 0.19, 0.19, 0.05), chunk_log2: int = 24, row_weight: int = None) -> DeviceCsr:
+    """Row block `rank` of ONE global 2^scale R-MAT cut into `world` cost-balanced row blocks (strong scaling,
     BASELINE config 3), generated PER SHARD: the edge list is produced in fixed seeded chunks (the same for every
     world size, so N = 1 and N = 8 see the same matrix), pass 1 only histograms the rows to find the cuts
-    (sharding.partition_rows_by_nnz semantics), pass 2 regenerates the chunks and keeps the rows of this rank.
+    (sharding.partition_rows_by_cost semantics: non-zeros + row_weight * rows per block; row_weight = 0 is the plain
+    nnz balance), pass 2 regenerates the chunks and keeps the rows of this rank.
     The full matrix is never materialised on a rank that owns 1/world of it."""
     import torch
 
@@ -340,6 +341,9 @@ def rmat_device_shard(scale: int, edge_factor: int, seed: int, rank: int, world:
         return rows, cols
 
     lo, hi = 0, n
+    if row_weight is None:
+        from .sharding import ROW_WEIGHT
+        row_weight = ROW_WEIGHT
     if world > 1:
         hist = torch.zeros(n, dtype=torch.int64, device=device)
         for ci in range(nchunks):
@@ -348,9 +352,11 @@ def rmat_device_shard(scale: int, edge_factor: int, seed: int, rank: int, world:
         ptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
         ptr[1:] = torch.cumsum(hist, 0)
         del hist
+        ptr += row_weight * torch.arange(n + 1, dtype=torch.int64, device=device)  # cost up to row r
+        total = ne + row_weight * n
         cuts = [0]
         for gidx in range(1, world):
-            target = (gidx * ne) // world
+            target = (gidx * total) // world
             r = int(torch.searchsorted(ptr, torch.tensor([target], device=device), right=True)[0]) - 1
             cuts.append(min(max(r, cuts[-1]), n))
         cuts.append(n)
@@ -375,5 +381,6 @@ def rmat_device_shard(scale: int, edge_factor: int, seed: int, rank: int, world:
     del rows
     row_ptr = torch.zeros(mloc + 1, dtype=torch.int64, device=device)
     row_ptr[1:] = torch.cumsum(counts, 0)
-    name = f"rmat{scale}(synthetic)" if world == 1 else f"rmat{scale}(synthetic) rows {lo}:{hi} of {world} nnz-balanced blocks"
+    name = (f"rmat{scale}(synthetic)" if world == 1 else
+            f"rmat{scale}(synthetic) rows {lo}:{hi} of {world} blocks balanced by nnz + {row_weight} * rows")
     return DeviceCsr(mloc, n, int(cols.numel()), row_ptr.to(torch.int32), cols, name)

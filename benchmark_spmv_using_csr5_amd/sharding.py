@@ -15,21 +15,36 @@ from dataclasses import dataclass
 import numpy as np
 
 
-def partition_rows_by_nnz(row_ptr: np.ndarray, parts: int) -> np.ndarray:
-    """Row split points r_0=0 <= r_1 <= ... <= r_parts=m with ~nnz/parts non-zeros per block.
+# What a row costs in units of one non-zero when row blocks are balanced.  Measured on the eight row blocks of R-MAT
+# scale 24 (scripts/experiments/shard_alone.py): blocks of equal nnz take 200 us where rows hold 477 non-zeros and 285 us
+# where they hold 4.6 -- the y element, the row pointer and the row's share of the slab combine are paid per ROW:
+# (285 - 200) us / 7.2 M rows = 11.7 ps per row against 6.0 ps per non-zero.
+ROW_WEIGHT = 2
 
-    r_g = (number of rows whose pointer is <= g*nnz/parts) - 1 clipped to [r_{g-1}, m], i.e. the row
-    that contains non-zero number g*nnz/parts starts the next block."""
+
+def partition_rows_by_cost(row_ptr: np.ndarray, parts: int, row_weight: int = ROW_WEIGHT) -> np.ndarray:
+    """Row split points r_0=0 <= r_1 <= ... <= r_parts=m with ~1/parts of the cost per block, where the cost of rows
+    [0, r) is row_ptr[r] + row_weight * r (non-zeros plus row_weight per row; row_weight = 0 is SURVEY 8(e)'s plain
+    nnz balance).
+
+    r_g = (number of r whose cost prefix is <= g*total/parts) - 1 clipped to [r_{g-1}, m]: the reference's own
+    `tile_ptr` primitive (upper bound on a sorted array, utils_cuda.h:25-53) on the cost prefix."""
     row_ptr = np.asarray(row_ptr, dtype=np.int64)
     m = row_ptr.size - 1
-    nnz = int(row_ptr[m])
+    key = row_ptr + int(row_weight) * np.arange(m + 1, dtype=np.int64)
+    total = int(key[m])
     cuts = np.zeros(parts + 1, dtype=np.int64)
     cuts[parts] = m
     for g in range(1, parts):
-        target = (g * nnz) // parts
-        r = int(np.searchsorted(row_ptr, target, side="right")) - 1
+        target = (g * total) // parts
+        r = int(np.searchsorted(key, target, side="right")) - 1
         cuts[g] = min(max(r, cuts[g - 1]), m)
     return cuts
+
+
+def partition_rows_by_nnz(row_ptr: np.ndarray, parts: int) -> np.ndarray:
+    """~nnz/parts non-zeros per block: the row that contains non-zero number g*nnz/parts starts block g."""
+    return partition_rows_by_cost(row_ptr, parts, 0)
 
 
 @dataclass
@@ -90,7 +105,7 @@ class ShardedSpmv:
     `anonymouslibHandle` (see `hip_local_spmv`); the CPU tests pass a host CSR loop."""
 
     def __init__(self, row_ptr, col, val, n: int, rank: int, world: int):
-        self.cuts = partition_rows_by_nnz(row_ptr, world)
+        self.cuts = partition_rows_by_cost(row_ptr, world)
         self.block = extract_row_block(row_ptr, col, val, n, self.cuts, rank)
         self.rank, self.world = rank, world
 
@@ -207,7 +222,7 @@ class CoupledSpmv:
         m = int(np.asarray(row_ptr).size - 1)
         if m != n:
             raise ValueError("coupled iterations need a square matrix (y becomes the next x)")
-        self.cuts = partition_rows_by_nnz(row_ptr, world)
+        self.cuts = partition_rows_by_cost(row_ptr, world)
         self.layout = PaddedLayout(self.cuts)
         blk = extract_row_block(row_ptr, col, val, n, self.cuts, rank)
         self.block = RowBlock(rank, blk.row_lo, blk.row_hi, self.layout.padded_len, blk.row_ptr,

@@ -247,8 +247,10 @@ int csr5hip_load(const char *path, csr5hip_handle *h, csr5hip_csr *arrays);
 /* ---------------------------------------------------------------------------------------------------
  * One matrix on the G GPUs of a node (SURVEY.md section 8, row e).  The reference is single-device
  * (CSR5_cuda/main.cu:25-26 `cudaSetDevice(0)`): this is the MI355X addition.  The matrix is cut into G contiguous
- * row blocks balanced by NON-ZEROS (split points = upper_bound(row_ptr, g*nnz/G) - 1, the reference's tile_ptr
- * primitive, utils_cuda.h:25-53); every block becomes an ordinary handle on its own device and stream; x is
+ * row blocks balanced by COST = non-zeros + row_weight * rows (split points = upper_bound(cost prefix, g*total/G) - 1,
+ * the reference's tile_ptr primitive, utils_cuda.h:25-53; row_weight defaults to 2 -- what a row's y element, pointer
+ * and share of the slab combine cost next to a non-zero, measured -- and CSR5HIP_MULTI_OPT_ROW_WEIGHT = 0 gives the
+ * plain nnz balance); every block becomes an ordinary handle on its own device and stream; x is
  * replicated ONCE at set_x time by a single RCCL broadcast over xGMI (librccl is opened lazily; device-to-device
  * copies when it is absent or a device is listed twice); y stays sharded; no per-SpMV collective.
  * Single host thread, all calls asynchronous per device.  devices[] may list a device several times (several
@@ -271,6 +273,9 @@ int csr5hip_multi_free(csr5hip_multi mh);
  * the per-device shards (and rebased); the caller's arrays are not modified by asCSR5 and may be freed afterwards. */
 int csr5hip_multi_input_csr(csr5hip_multi mh, int nnz, const int32_t *d_row_ptr, const int32_t *d_col_idx, const void *d_val);
 int csr5hip_multi_set_sigma(csr5hip_multi mh, int sigma);
+/* csr5hip_set_option on every shard; CSR5HIP_MULTI_OPT_ROW_WEIGHT (0..64, before input_csr) is the handle's own key */
+#define CSR5HIP_MULTI_OPT_ROW_WEIGHT 100
+#define CSR5HIP_MULTI_DEFAULT_ROW_WEIGHT 2
 int csr5hip_multi_set_option(csr5hip_multi mh, int option, int value);
 int csr5hip_multi_as_csr5(csr5hip_multi mh);
 /* setX: d_x on devices[0], n values, borrowed by the shards that live there; ONE broadcast to the other devices */

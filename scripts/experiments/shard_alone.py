@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""One row block of the strong-scaling R-MAT (rank r of W) ALONE on one GPU: what each GPU of an N-GPU run does per
+SpMV, measured without the other ranks (a 1-GPU box cannot run them side by side).  Ideal = t(1 of 1) / W.
+
+    python scripts/experiments/shard_alone.py --scale 24 --world 8 --ranks 0,3,7
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=int, default=24)
+    ap.add_argument("--world", type=int, default=8)
+    ap.add_argument("--ranks", default="0")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--slabs", default="auto")
+    ap.add_argument("--hot", default="auto")
+    ap.add_argument("--row-weight", type=int, default=None)
+    args = ap.parse_args()
+    import torch
+    from benchmark_spmv_using_csr5_amd import handle as H
+    from benchmark_spmv_using_csr5_amd import matrices as M
+
+    dev = torch.device("cuda:0")
+    for rank in [int(r) for r in args.ranks.split(",")]:
+        mat = M.rmat_device_shard(args.scale, 16, 1, rank, args.world, dev, row_weight=args.row_weight)
+        g = torch.Generator(device=dev).manual_seed(7)
+        va = torch.randint(0, 10, (mat.nnz,), generator=g, device=dev).to(torch.float64)
+        x = torch.randint(0, 10, (mat.n,), generator=g, device=dev).to(torch.float64)
+        y = torch.zeros(mat.m, dtype=torch.float64, device=dev)
+        A = H.anonymouslibHandle(mat.m, mat.n)
+        assert A.inputCSR(mat.nnz, mat.row_ptr, mat.col.clone(), va) == 0 and A.setX(x) == 0
+        A.setSigma(-1)
+        A.setColumnSlabs(1 if args.slabs == "auto" else int(args.slabs))
+        A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.hot])
+        assert A.asCSR5() == 0
+        i = A.info()
+        assert A.spmv_repeat(1.0, y, 10) == 0
+        torch.cuda.synchronize()
+        A.timer_start()
+        assert A.spmv_repeat(1.0, y, args.steps) == 0
+        us = A.timer_stop() * 1e3 / args.steps
+        b_alg = M.algorithmic_bytes(mat.m, mat.n, mat.nnz, 8)
+        print(json.dumps({"rank": rank, "world": args.world, "m": mat.m, "nnz": mat.nnz, "sigma": i.sigma,
+                          "slabs": i.column_slabs, "hot": i.slab_hot, "hot_cover_pct": i.slab_hot_cover_pct,
+                          "us": round(us, 1), "frac": round(b_alg / (us * 1e-6) / 8e12, 3),
+                          "gflops_if_all_ranks_alike": round(2 * mat.nnz * args.world / (us * 1e-6) / 1e9, 1)}))
+        A.destroy()
+        A.close()
+        del mat, va, x, y
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

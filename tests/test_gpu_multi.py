@@ -22,12 +22,14 @@ def _devices(G):
     return [g % n for g in range(G)] if n >= 2 else [0] * G
 
 
-def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None):
+def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None, row_weight=None):
     rp = torch.from_numpy(mat.row_ptr.astype(np.int32)).to(DEV)
     ci = torch.from_numpy(mat.col.astype(np.int32)).to(DEV)
     va = torch.from_numpy(val.astype(dtype)).to(DEV)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
     A = H.MultiGpuHandle(_devices(G), mat.m, mat.n, dtype=np.dtype(dtype).name)
+    if row_weight is not None:
+        assert A.setOption(100, row_weight) == 0  # CSR5HIP_MULTI_OPT_ROW_WEIGHT, before inputCSR
     assert A.inputCSR(mat.nnz, rp, ci, va) == 0
     assert A.setSigma(sigma) == 0
     if slabs is not None:
@@ -54,8 +56,10 @@ def test_multi_zoo_exact(oracle, G):
     for mat in zoo.small_zoo():
         val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=5, mode="int")
         ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
-        y, cuts, nnzs, bkind, tails = _run_multi(mat, val, x, G)
-        assert cuts == list(S.partition_rows_by_nnz(mat.row_ptr, G)), "device-side cuts == sharding.partition_rows_by_nnz"
+        weight = (None, 0, 5)[(G + mat.m) % 3]
+        y, cuts, nnzs, bkind, tails = _run_multi(mat, val, x, G, row_weight=weight)
+        want = S.partition_rows_by_cost(mat.row_ptr, G, S.ROW_WEIGHT if weight is None else weight)
+        assert cuts == list(want), "device-side cuts == sharding.partition_rows_by_cost"
         assert sum(nnzs) == mat.nnz
         lens = np.diff(mat.row_ptr)
         nonempty = lens > 0
@@ -72,7 +76,7 @@ def test_multi_zoo_exact(oracle, G):
 
 
 def test_multi_rmat20_eight_row_blocks_on_one_device(oracle):
-    """The 8 nnz-balanced row blocks of one R-MAT 20 (what 8 GPUs would hold), each through its own handle; the
+    """The 8 cost-balanced row blocks of one R-MAT 20 (what 8 GPUs would hold), each through its own handle; the
     concatenated y must equal the full-matrix product exactly, with and without column slabs in the shards."""
     mat = M.rmat(20, 16, seed=4)
     val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=8, mode="int")
@@ -81,7 +85,9 @@ def test_multi_rmat20_eight_row_blocks_on_one_device(oracle):
     for slabs in (0, 1):
         y, cuts, nnzs, _, _ = _run_multi(mat, val, x, 8, slabs=slabs)
         assert np.array_equal(y[nonempty], ref[nonempty]), slabs
-        assert max(nnzs) <= 1.25 * mat.nnz / 8, "row blocks are balanced by non-zeros (power-law rows)"
+        cost = np.asarray(nnzs) + S.ROW_WEIGHT * np.diff(cuts)
+        assert cost.max() <= 1.1 * cost.sum() / 8, "row blocks are balanced by non-zeros + ROW_WEIGHT * rows (power-law rows)"
+        assert max(nnzs) <= 1.25 * mat.nnz / 8
 
 
 def test_multi_real_data_fp32_and_graph_replay(oracle):

@@ -147,6 +147,14 @@ def test_nnz_balanced_row_partition():
         blocks = [S.extract_row_block(mat.row_ptr, mat.col, mat.val, mat.n, cuts, r) for r in range(parts)]
         assert np.array_equal(np.concatenate([b.col for b in blocks]), mat.col)
         assert all(b.row_ptr[0] == 0 and b.row_ptr[-1] == b.nnz for b in blocks)
+        # cost balance (the default of every sharded path): non-zeros + ROW_WEIGHT per row, same guarantees
+        for w in (S.ROW_WEIGHT, 5):
+            cc = S.partition_rows_by_cost(mat.row_ptr, parts, w)
+            assert cc[0] == 0 and cc[-1] == mat.m and np.all(np.diff(cc) >= 0)
+            cost = np.diff(mat.row_ptr[cc].astype(np.int64)) + w * np.diff(cc)
+            assert cost.sum() == mat.nnz + w * mat.m
+            assert cost.max() <= (mat.nnz + w * mat.m) / parts + longest + w
+        assert np.array_equal(S.partition_rows_by_cost(mat.row_ptr, parts, 0), cuts)
 
 
 def _gloo_worker(rank, world, port, q):
@@ -320,17 +328,18 @@ def test_new_option_keys_and_multi_handle_argument_checks():
 
 def test_rmat_shards_are_row_blocks_of_one_matrix():
     """Strong scaling input (BASELINE config 3): the per-shard generator gives every world size the SAME global matrix;
-    the shards are its nnz-balanced row blocks (sharding.partition_rows_by_nnz), generated without materialising it."""
+    the shards are its cost-balanced row blocks (sharding.partition_rows_by_cost; row_weight = 0: by nnz), generated
+    without materialising it."""
     torch = pytest.importorskip("torch")
     full = M.rmat_device_shard(11, 8, seed=3, rank=0, world=1, device="cpu", chunk_log2=12)
     rp = full.row_ptr.numpy().astype(np.int64)
     col = full.col.numpy()
     assert full.m == 1 << 11 and full.nnz == (1 << 11) * 8 and rp[-1] == full.nnz
-    for world in (2, 3, 8):
-        cuts = S.partition_rows_by_nnz(rp, world)
+    for world, weight in ((2, None), (3, 0), (8, None), (8, 7)):
+        cuts = S.partition_rows_by_cost(rp, world, S.ROW_WEIGHT if weight is None else weight)
         lo_rows = 0
         for rank in range(world):
-            sh = M.rmat_device_shard(11, 8, seed=3, rank=rank, world=world, device="cpu", chunk_log2=12)
+            sh = M.rmat_device_shard(11, 8, seed=3, rank=rank, world=world, device="cpu", chunk_log2=12, row_weight=weight)
             lo, hi = int(cuts[rank]), int(cuts[rank + 1])
             assert sh.m == hi - lo and sh.n == full.n
             assert np.array_equal(sh.row_ptr.numpy().astype(np.int64), rp[lo:hi + 1] - rp[lo])
