@@ -526,24 +526,36 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             // compiler drain the vector memory counter in front of every table read).
             const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(x), (short)0, g.n * (int)sizeof(VT), 0x00020000);
             using word_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
-            word_t xg[SIGMA];
-#pragma unroll
-            for (int i = 0; i < SIGMA; i++) {
-                const unsigned off = c[i] < 0 ? 0xFFFFFFFFu : (unsigned)c[i] * (unsigned)sizeof(VT);
+            word_t xg[SIGMA], sg = 0;
+            auto cold_word = [&](int32_t cw) -> word_t {
+                const unsigned off = cw < 0 ? 0xFFFFFFFFu : (unsigned)cw * (unsigned)sizeof(VT);
                 if constexpr (sizeof(VT) == 8)
-                    xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
+                    return __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
                 else
-                    xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b32(xbuf, off, 0, 0));
-            }
+                    return __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b32(xbuf, off, 0, 0));
+            };
+            auto table_word = [&](int32_t cw) -> word_t {
+                return __builtin_bit_cast(word_t, hot[cw < 0 ? (unsigned)cw & 0x7FFFFFFFu : 0u]);
+            };
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++)
+                xg[i] = cold_word(c[i]);
+            // the short-spill gather of tile t+1's first elements rides in the same batch, the same way (lanes
+            // beyond the spill length read column 0: one line)
+            const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
+            const int32_t scw = lane < L ? spill_c : 0;
+            if constexpr (FUSED)
+                sg = cold_word(scw);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < SIGMA; i++) {
-                const unsigned slot = c[i] < 0 ? (unsigned)c[i] & 0x7FFFFFFFu : 0u;
-                const word_t xl = __builtin_bit_cast(word_t, hot[slot]);
-                xv[i] = __builtin_bit_cast(VT, (word_t)(xg[i] | xl));
+            for (int i = 0; i < SIGMA; i++)
+                xv[i] = __builtin_bit_cast(VT, (word_t)(xg[i] | table_word(c[i])));
+            if constexpr (FUSED) {
+                const VT sx = __builtin_bit_cast(VT, (word_t)(sg | table_word(scw)));
+                lead_next = lane < L ? spill_v * sx : (VT)0;
             }
         }
-        if constexpr (FUSED) {
+        if constexpr (FUSED && !HOT) {
             // the closing row of this tile spills mt.z <= 64 elements into tile t+1 and ends there:
             // gather x for exactly those lanes; the other lanes re-read x[0] (one cache line), so the
             // gather is unconditional and rides in the same round trip as the tile's own gathers
@@ -622,7 +634,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         return;
     }
 
-    const bool empty_rows = rs_raw >> 31;
+    const bool empty_rows = HOT ? false : (bool)(rs_raw >> 31); // (a slab child has no empty rows)
     const int row_start = (int)(rs_raw & ROW_MASK);
     VT *y_local = y + row_start + 1;
     const int32_t *off_local = empty_rows ? offset + offset_ptr[t] : nullptr;
@@ -737,8 +749,19 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             const int nseg = __builtin_amdgcn_readlane(stored_hi, 63 - __builtin_clzll(smask));
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (int j = lane; j < nseg; j += OMEGA)
-                y_local[empty_rows ? off_local[j] : j] = seg[j];
+            // Two loops, not one with a select: the offset load would sit in the loop of every tile, and a store
+            // whose address depends on a load makes the compiler drain the vector-memory counter -- i.e. the previous
+            // iteration's STORE -- before it issues the next one (one store round trip per 64 segments).
+            if constexpr (!HOT) { // (a slab child has no empty rows)
+                if (empty_rows) {
+                    for (int j = lane; j < nseg; j += OMEGA)
+                        y_local[off_local[j]] = seg[j];
+                }
+            }
+            if (HOT || !empty_rows) {
+                for (int j = lane; j < nseg; j += OMEGA)
+                    y_local[j] = seg[j];
+            }
         }
     }
     if constexpr (FUSED) {

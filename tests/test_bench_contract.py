@@ -67,5 +67,7 @@ def test_bench_multi_gpu_form_launches_its_own_ranks():
     d = _run("--gpus", "2", "--workload", "rmat18", "--steps", "10", "--warmup", "2",
              env={"CSR5_BENCH_SHARE_GPU": "1"} if torch.cuda.device_count() < 2 else None)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "cpu_baseline" not in d
-    assert d["config"]["nnz_per_gpu"] < (1 << 18) * 16, "rank 0 holds one nnz-balanced row block, not the whole matrix"
-    assert abs(d["config"]["nnz_per_gpu"] - (1 << 18) * 8) < 0.05 * (1 << 18) * 8
+    assert d["config"]["nnz_per_gpu"] < (1 << 18) * 16, "rank 0 holds one row block, not the whole matrix"
+    # blocks are balanced by cost = nnz + 2 per row (sharding.ROW_WEIGHT): half of (16 + 2) * 2^18 each
+    cost = d["config"]["nnz_per_gpu"] + 2 * d["config"]["m_per_gpu"]
+    assert abs(cost - (1 << 18) * 9) < 0.05 * (1 << 18) * 9
