@@ -15,6 +15,11 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def ck(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} -> {rc}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="scircuit", choices=["scircuit", "webbase", "nd24k", "rmat20", "rmat22", "rmat24"])
@@ -38,27 +43,24 @@ def main():
     va = torch.randint(0, 10, (mat.nnz,), device=dev).to(dt)
     x = torch.randint(0, 10, (mat.n,), device=dev).to(dt)
     A = H.anonymouslibHandle(mat.m, mat.n, dtype="float32" if f32 else "float64")
-    assert A.inputCSR(mat.nnz, rp, ci, va) == 0
-    assert A.setX(x) == 0
+    ck(A.inputCSR(mat.nnz, rp, ci, va), "inputCSR")
+    ck(A.setX(x), "setX")
     A.setSigma(args.sigma)
     A.setColumnSlabs(1 if args.slabs == "auto" else int(args.slabs))
     A.warmup()
     for _ in range(5):
-        rc = A.asCSR5()
-        assert rc == 0, rc
-        rc = A.asCSR()
-        assert rc == 0, rc
+        ck(A.asCSR5(), "asCSR5")
+        ck(A.asCSR(), "asCSR")
     torch.cuda.synchronize()
     times = []
     for _ in range(args.rounds):
         t0 = time.perf_counter()
         rc = A.asCSR5()
         t1 = time.perf_counter()
-        assert rc == 0, rc
+        ck(rc, "asCSR5")
         times.append((t1 - t0) * 1e6)
         info = A.info()
-        rc = A.asCSR()
-        assert rc == 0, rc
+        ck(A.asCSR(), "asCSR")
     out = {"workload": args.workload, "m": mat.m, "nnz": mat.nnz, "sigma": info.sigma, "tiles": info.p,
            "column_slabs": info.column_slabs, "rounds": args.rounds,
            "as_csr5_us": {"median": round(statistics.median(times), 1), "min": round(min(times), 1),

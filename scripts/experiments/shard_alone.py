@@ -12,6 +12,11 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
+def ck(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} -> {rc}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scale", type=int, default=24)
@@ -34,16 +39,17 @@ def main():
         x = torch.randint(0, 10, (mat.n,), generator=g, device=dev).to(torch.float64)
         y = torch.zeros(mat.m, dtype=torch.float64, device=dev)
         A = H.anonymouslibHandle(mat.m, mat.n)
-        assert A.inputCSR(mat.nnz, mat.row_ptr, mat.col.clone(), va) == 0 and A.setX(x) == 0
+        ck(A.inputCSR(mat.nnz, mat.row_ptr, mat.col.clone(), va), "inputCSR")
+        ck(A.setX(x), "setX")
         A.setSigma(-1)
         A.setColumnSlabs(1 if args.slabs == "auto" else int(args.slabs))
         A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.hot])
-        assert A.asCSR5() == 0
+        ck(A.asCSR5(), "asCSR5")
         i = A.info()
-        assert A.spmv_repeat(1.0, y, 10) == 0
+        ck(A.spmv_repeat(1.0, y, 10), "spmv_repeat")
         torch.cuda.synchronize()
         A.timer_start()
-        assert A.spmv_repeat(1.0, y, args.steps) == 0
+        ck(A.spmv_repeat(1.0, y, args.steps), "spmv_repeat")
         us = A.timer_stop() * 1e3 / args.steps
         b_alg = M.algorithmic_bytes(mat.m, mat.n, mat.nnz, 8)
         print(json.dumps({"rank": rank, "world": args.world, "m": mat.m, "nnz": mat.nnz, "sigma": i.sigma,
