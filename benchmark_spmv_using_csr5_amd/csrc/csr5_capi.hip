@@ -692,7 +692,7 @@ static int build_slabs(csr5hip_handle h)
     HIP_TRY(h->b_val2.reserve((size_t)g.nnz * h->vsize()));
     HIP_TRY(slab_partition(g, h->d, h->value_type, S, bits, h->slab_shift, (uint32_t *)t.hist, t.scan_tmp, scan_bytes,
                            (int32_t *)h->b_col2.ptr, h->b_val2.ptr, (unsigned long long *)t.key, s));
-    HIP_TRY(slab_count_segments(g.nnz, (const unsigned long long *)t.key, (unsigned int *)t.count, s));
+    HIP_TRY(slab_count_segments(g.nnz, (const unsigned long long *)t.key, t.sel_tmp, (unsigned int *)t.count, s));
     unsigned int m2 = 0;
     HIP_TRY(hipMemcpyAsync(&m2, t.count, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -703,8 +703,7 @@ static int build_slabs(csr5hip_handle h)
         return CSR5HIP_SUCCESS;
     }
     HIP_TRY(h->b_row_ptr2.reserve(((size_t)m2 + 1) * 4));
-    HIP_TRY(slab_segments(g.nnz, (const unsigned long long *)t.key, t.sel_tmp, sel_bytes, (int32_t *)h->b_row_ptr2.ptr,
-                          (unsigned int *)t.count, s));
+    HIP_TRY(slab_segments(g.nnz, (const unsigned long long *)t.key, t.sel_tmp, (int32_t *)h->b_row_ptr2.ptr, s));
     const size_t mask_words = ((size_t)g.m * S + 31) / 32 + 1;
     const size_t base_words = ((size_t)g.m + OMEGA - 1) / OMEGA * S;
     HIP_TRY(h->b_mask.reserve(mask_words * 4));

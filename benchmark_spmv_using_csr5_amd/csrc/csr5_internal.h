@@ -97,9 +97,8 @@ hipError_t slab_select_tmp_bytes(int nnz, size_t *bytes);
 hipError_t slab_partition(const Geometry &g, const DeviceArrays &d, int value_type, int S, int bits, int shift,
                           uint32_t *hist, void *scan_tmp, size_t scan_tmp_bytes, int32_t *col2, void *val2,
                           unsigned long long *key2, hipStream_t s);
-hipError_t slab_count_segments(int nnz, const unsigned long long *key2, unsigned int *d_count, hipStream_t s);
-hipError_t slab_segments(int nnz, const unsigned long long *key2, void *tmp, size_t tmp_bytes, int32_t *row_ptr2,
-                         unsigned int *d_count, hipStream_t s);
+hipError_t slab_count_segments(int nnz, const unsigned long long *key2, void *tmp, unsigned int *d_count, hipStream_t s);
+hipError_t slab_segments(int nnz, const unsigned long long *key2, const void *tmp, int32_t *row_ptr2, hipStream_t s);
 hipError_t slab_tables(int m2, int nnz, int S, int32_t *row_ptr2, const unsigned long long *key2, uint32_t *mask,
                        uint32_t *base, hipStream_t s);
 hipError_t slab_hot_select(int n, int nnz, int p_hist, int p, int T, int S, int bits, int shift, int capacity,

@@ -25,8 +25,6 @@
 #include "csr5_internal.h"
 
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/device/device_select.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace csr5 {
 
@@ -166,19 +164,31 @@ k_slab_scatter(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *
     }
 }
 
-struct SegmentStart {
-    const unsigned long long *key;
-    __device__ bool operator()(const int &j) const { return j == 0 || key[j] != key[j - 1]; }
-};
+// Segment starts (positions j with key[j] != key[j-1]) -> row_ptr' in three small steps on a fixed partition of the keys
+// into <= SEG_BLOCKS chunks: per-chunk counts (no atomics), one-workgroup scan of the counts (also the total m'), then
+// every chunk re-reads its keys and writes its starts behind its offset (ballot ranks, no atomics).  rocprim::select on
+// a counting iterator did this in 4.8 ms on R-MAT 24 after a 3.0-ms counting pass; the two passes here read the keys
+// twice at stream speed.
+constexpr int SEG_BLOCKS = 2048;
+__host__ __device__ inline long long seg_chunk(int nnz, int blocks)
+{
+    long long c = ((long long)nnz + blocks - 1) / blocks;
+    return (c + SLAB_BLOCK - 1) / SLAB_BLOCK * SLAB_BLOCK;
+}
+static int seg_blocks(int nnz)
+{
+    long long b = ((long long)nnz + 4095) / 4096;
+    return (int)(b < 1 ? 1 : (b > SEG_BLOCKS ? SEG_BLOCKS : b));
+}
 
-// (one atomic per WORKGROUP of a bounded grid: one per wavefront of 65 536 workgroups was 262 k increments of a single
-// word, 2.9 of the kernel's 3.0 ms on R-MAT 24)
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_slab_count_segments(int nnz, const unsigned long long *__restrict__ key, unsigned int *__restrict__ count)
+k_slab_count_segments(int nnz, const unsigned long long *__restrict__ key, unsigned int *__restrict__ block_count)
 {
     __shared__ unsigned part[SLAB_BLOCK / OMEGA];
+    const long long chunk = seg_chunk(nnz, gridDim.x);
+    const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < nnz ? lo + chunk : nnz;
     unsigned local = 0;
-    for (size_t j = (size_t)blockIdx.x * SLAB_BLOCK + threadIdx.x; j < (size_t)nnz; j += (size_t)gridDim.x * SLAB_BLOCK)
+    for (long long j = lo + threadIdx.x; j < hi; j += SLAB_BLOCK)
         local += j == 0 || key[j] != key[j - 1];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
@@ -190,8 +200,72 @@ k_slab_count_segments(int nnz, const unsigned long long *__restrict__ key, unsig
         unsigned total = 0;
         for (int w = 0; w < SLAB_BLOCK / OMEGA; w++)
             total += part[w];
-        if (total)
-            atomicAdd(count, total);
+        block_count[blockIdx.x] = total;
+    }
+}
+
+// exclusive scan of the <= SEG_BLOCKS chunk counts in place (one workgroup); block_count[blocks] and *total = m'
+__global__ void __launch_bounds__(1024) k_slab_scan_counts(int blocks, unsigned int *__restrict__ block_count,
+                                                           unsigned int *__restrict__ total)
+{
+    __shared__ unsigned wave_total[16];
+    const int per = (blocks + 1023) / 1024; // 1 or 2
+    const int first = (int)threadIdx.x * per;
+    unsigned v[2] = {0u, 0u};
+    for (int i = 0; i < per; i++)
+        if (first + i < blocks)
+            v[i] = block_count[first + i];
+    const unsigned sum = v[0] + v[1];
+    const int lane = threadIdx.x & (OMEGA - 1), w = threadIdx.x >> 6;
+    unsigned incl = sum;
+#pragma unroll
+    for (int d = 1; d < OMEGA; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d, OMEGA);
+        if (lane >= d)
+            incl += o;
+    }
+    if (lane == OMEGA - 1)
+        wave_total[w] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (int k = 0; k < w; k++)
+        run += wave_total[k];
+    for (int i = 0; i < per; i++)
+        if (first + i < blocks) {
+            block_count[first + i] = run;
+            run += v[i];
+        }
+    if (threadIdx.x == 1023) {
+        block_count[blocks] = run;
+        *total = run;
+    }
+}
+
+__global__ void __launch_bounds__(SLAB_BLOCK)
+k_slab_emit_segments(int nnz, const unsigned long long *__restrict__ key, const unsigned int *__restrict__ block_offset,
+                     int32_t *__restrict__ row_ptr2)
+{
+    __shared__ unsigned wave_count[SLAB_BLOCK / OMEGA];
+    const long long chunk = seg_chunk(nnz, gridDim.x);
+    const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < nnz ? lo + chunk : nnz;
+    const int lane = threadIdx.x & (OMEGA - 1), w = threadIdx.x / OMEGA;
+    unsigned out = block_offset[blockIdx.x];
+    for (long long j0 = lo; j0 < hi; j0 += SLAB_BLOCK) { // (chunk is a multiple of the workgroup size: uniform trip count)
+        const long long j = j0 + threadIdx.x;
+        const bool start = j < hi && (j == 0 || key[j] != key[j - 1]);
+        const unsigned long long b = __ballot(start);
+        if (lane == 0)
+            wave_count[w] = (unsigned)__popcll(b);
+        __syncthreads();
+        unsigned before = 0, all = 0;
+        for (int k = 0; k < SLAB_BLOCK / OMEGA; k++) {
+            before += k < w ? wave_count[k] : 0u;
+            all += wave_count[k];
+        }
+        if (start)
+            row_ptr2[out + before + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = (int32_t)j;
+        out += all;
+        __syncthreads();
     }
 }
 
@@ -529,30 +603,27 @@ hipError_t slab_scan_tmp_bytes(size_t items, size_t *bytes)
     return rocprim::exclusive_scan(nullptr, *bytes, null_u, null_u, 0u, items, rocprim::plus<uint32_t>(), nullptr);
 }
 
-hipError_t slab_count_segments(int nnz, const unsigned long long *key2, unsigned int *d_count, hipStream_t s)
+hipError_t slab_select_tmp_bytes(int nnz, size_t *bytes)
 {
-    hipError_t e = hipMemsetAsync(d_count, 0, 4, s);
-    if (e != hipSuccess)
-        return e;
-    long long blocks = ((long long)nnz + SLAB_BLOCK * 16 - 1) / (SLAB_BLOCK * 16);
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    hipLaunchKernelGGL(k_slab_count_segments, dim3((unsigned)blocks), dim3(SLAB_BLOCK), 0, s, nnz, key2, d_count);
+    *bytes = ((size_t)seg_blocks(nnz) + 1) * 4; // chunk counts, then (in place) chunk offsets and the total
+    return hipSuccess;
+}
+
+// d_count <- m' (number of segments); `tmp` (slab_select_tmp_bytes) keeps the chunk offsets for slab_segments
+hipError_t slab_count_segments(int nnz, const unsigned long long *key2, void *tmp, unsigned int *d_count, hipStream_t s)
+{
+    const int blocks = seg_blocks(nnz);
+    hipLaunchKernelGGL(k_slab_count_segments, dim3(blocks), dim3(SLAB_BLOCK), 0, s, nnz, key2, (unsigned int *)tmp);
+    hipLaunchKernelGGL(k_slab_scan_counts, dim3(1), dim3(1024), 0, s, blocks, (unsigned int *)tmp, d_count);
     return hipGetLastError();
 }
 
-hipError_t slab_select_tmp_bytes(int nnz, size_t *bytes)
+// row_ptr'[0 .. m') <- segment starts (after slab_count_segments on the same keys and tmp)
+hipError_t slab_segments(int nnz, const unsigned long long *key2, const void *tmp, int32_t *row_ptr2, hipStream_t s)
 {
-    int32_t *null_i = nullptr;
-    unsigned int *null_c = nullptr;
-    return rocprim::select(nullptr, *bytes, rocprim::counting_iterator<int>(0), null_i, null_c, (size_t)nnz,
-                           SegmentStart{nullptr}, nullptr);
-}
-
-hipError_t slab_segments(int nnz, const unsigned long long *key2, void *tmp, size_t tmp_bytes, int32_t *row_ptr2,
-                         unsigned int *d_count, hipStream_t s)
-{
-    return rocprim::select(tmp, tmp_bytes, rocprim::counting_iterator<int>(0), row_ptr2, d_count, (size_t)nnz,
-                           SegmentStart{key2}, s);
+    hipLaunchKernelGGL(k_slab_emit_segments, dim3(seg_blocks(nnz)), dim3(SLAB_BLOCK), 0, s, nnz, key2,
+                       (const unsigned int *)tmp, row_ptr2);
+    return hipGetLastError();
 }
 
 hipError_t slab_tables(int m2, int nnz, int S, int32_t *row_ptr2, const unsigned long long *key2, uint32_t *mask,
