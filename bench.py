@@ -345,6 +345,9 @@ def sub_config(name, args, dev):
         "config": config_dict(prob, a),
         "roofline": roofline_dict(prob, ev_step, wall_step, {"cold": cold_dict(prob, cold_ms, k, cold_steps)}),
     }
+    i = prob.info
+    key = f"{label}|{dtype_name}|sigma={i.sigma}|{a.mode}|slabs={i.column_slabs}/{i.slab_shift}/hot={i.slab_hot}"
+    out["roofline"]["traffic"], out["roofline"]["traffic_source"] = profiled_traffic(key)  # (of the warm protocol)
     prob.close()
     return out
 
