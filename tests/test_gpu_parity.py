@@ -456,7 +456,8 @@ def test_autotune_sigma(oracle):
 
 def test_seeded_fuzz_against_oracle(oracle):
     """Seeded fuzz: random shapes, row-length laws (incl. bursts of empty rows and hub rows), sigma, SpMV
-    mode, LDS options and dtype; integer data, so format and y must be bit-identical to the oracle."""
+    mode, LDS options, column slabs / hot table and dtype; integer data, so format and y must be bit-identical to the
+    oracle."""
     # CSR5_FUZZ_CASES / CSR5_FUZZ_SEED: longer one-off campaigns (scripts/experiments/fuzz_long.sh); defaults = the CI run
     import os
     rng = np.random.default_rng(int(os.environ.get("CSR5_FUZZ_SEED", "20260928")))
@@ -491,12 +492,16 @@ def test_seeded_fuzz_against_oracle(oracle):
         xwin = int(rng.choice([0, 2])) if mode == H.SPMV_FUSED else None
         ldsy = int(rng.choice([0, 2]))
         nt = int(rng.choice([0, 2])) if mode == H.SPMV_FUSED and not xwin else None
+        # column slabs (forced; 0 = off) in two cases of five, the LDS hot table (forced) on half of those that can carry it
+        slabs = int(rng.choice([2, 4, 8, 16, 32, 64])) if case % 5 in (1, 3) else 0
+        hot = int(rng.choice([0, 2])) if slabs % 8 == 0 and slabs and mode == H.SPMV_FUSED else 0
         fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
-        arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, dtype=dtype, xwin=xwin, ldsy=ldsy, nt=nt, repeat=2)
+        arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, dtype=dtype, xwin=xwin, ldsy=ldsy, nt=nt, repeat=2,
+                                        slabs=slabs, hot=hot)
         _check_format(arrays, col_t, val_t, fmt)
         exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
         for y in ys:
-            assert np.array_equal(y, exp), (case, m, n, sigma, mode, xwin, ldsy, nt, dtype,
+            assert np.array_equal(y, exp), (case, m, n, sigma, mode, xwin, ldsy, nt, slabs, hot, dtype,
                                             np.flatnonzero(y != exp)[:5])
 
 
