@@ -485,30 +485,50 @@ k_hot_threshold(int capacity, int min_count, const uint32_t *__restrict__ chist,
         thr[blockIdx.x] = (uint32_t)best;
 }
 
-// pass 0: every column with count >= thr gets a slot; pass 1: columns of the next lower count fill what is left
+// pass 0: every column with count >= thr gets a slot; pass 1: columns of the next lower count fill what is left.
+// A workgroup walks HOT_ASSIGN_COLS columns twice: first it counts the slots it wants per slab (LDS), reserves them with
+// ONE global add per slab, then hands them out from LDS counters (196 k adds on 16 words -- one per chosen column -- took
+// 0.9 ms per pass on R-MAT 24).
+constexpr int HOT_ASSIGN_COLS = 16384;
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_hot_assign(int n, const uint32_t *__restrict__ cnt, int bits, int shift, const uint32_t *__restrict__ thr,
              int capacity, int min_count, int pass, int32_t *__restrict__ hot_count, int32_t *__restrict__ hot_cols,
              int32_t *__restrict__ hotmap, unsigned long long *__restrict__ covered)
 {
-    const int c = blockIdx.x * SLAB_BLOCK + threadIdx.x;
-    const uint32_t v = c < n ? cnt[c] : 0u;
-    unsigned long long got = 0;
-    if (v) {
-        const uint32_t k = slab_of((uint32_t)c, shift, bits);
+    __shared__ int want[SLAB_MAX], base[SLAB_MAX], given[SLAB_MAX];
+    if (threadIdx.x < SLAB_MAX)
+        want[threadIdx.x] = given[threadIdx.x] = base[threadIdx.x] = 0;
+    __syncthreads();
+    const int first = blockIdx.x * HOT_ASSIGN_COLS;
+    const int last = first + HOT_ASSIGN_COLS < n ? first + HOT_ASSIGN_COLS : n;
+    auto chosen = [&](int c, uint32_t &k, uint32_t &v) -> bool {
+        v = cnt[c];
+        if (!v)
+            return false;
+        k = slab_of((uint32_t)c, shift, bits);
         const uint32_t bucket = v < HOT_BUCKETS - 1 ? v : HOT_BUCKETS - 1;
         const uint32_t b = thr[k];
-        const bool take = pass == 0 ? bucket >= b : (bucket + 1 == b && (int)bucket >= min_count);
-        if (take) {
-            const int slot = atomicAdd(&hot_count[k], 1);
+        return pass == 0 ? bucket >= b : (bucket + 1 == b && (int)bucket >= min_count);
+    };
+    uint32_t k = 0, v = 0;
+    for (int c = first + (int)threadIdx.x; c < last; c += SLAB_BLOCK)
+        if (chosen(c, k, v))
+            atomicAdd(&want[k], 1);
+    __syncthreads();
+    if (threadIdx.x < SLAB_MAX && want[threadIdx.x])
+        base[threadIdx.x] = atomicAdd(&hot_count[threadIdx.x], want[threadIdx.x]);
+    __syncthreads();
+    unsigned long long got = 0;
+    for (int c = first + (int)threadIdx.x; c < last; c += SLAB_BLOCK)
+        if (chosen(c, k, v)) {
+            const int slot = base[k] + atomicAdd(&given[k], 1);
             if (slot < capacity) {
                 hot_cols[(size_t)k * capacity + slot] = c;
                 hotmap[c] = slot;
-                got = v;
+                got += v;
             }
         }
-    }
-    // sampled non-zeros that found a slot: one increment per wavefront (196 k increments of one word on R-MAT 24)
+    // sampled non-zeros that found a slot: one increment per wavefront
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         got += __shfl_xor(got, d, OMEGA);
@@ -686,13 +706,12 @@ hipError_t slab_hot_select(int n, int nnz, int p_hist, int p, int T, int S, int 
     if (e != hipSuccess)
         return e;
     hipLaunchKernelGGL(k_col_count, dim3((unsigned)blocks), dim3(SLAB_BLOCK), 0, s, nnz, sample_stride, col2, cnt);
-    const dim3 cols_grid((n + SLAB_BLOCK - 1) / SLAB_BLOCK);
     hipLaunchKernelGGL(k_hot_hist, dim3((n + HOT_HIST_COLS - 1) / HOT_HIST_COLS), dim3(SLAB_BLOCK), 0, s, n, cnt, S, bits, shift,
                        chist);
     hipLaunchKernelGGL(k_hot_threshold, dim3(S), dim3(OMEGA), 0, s, capacity, min_count, chist, thr);
     for (int pass = 0; pass < 2; pass++)
-        hipLaunchKernelGGL(k_hot_assign, cols_grid, dim3(SLAB_BLOCK), 0, s, n, cnt, bits, shift, thr, capacity, min_count,
-                           pass, hot_count, hot_cols, hotmap, covered);
+        hipLaunchKernelGGL(k_hot_assign, dim3((n + HOT_ASSIGN_COLS - 1) / HOT_ASSIGN_COLS), dim3(SLAB_BLOCK), 0, s, n, cnt, bits,
+                           shift, thr, capacity, min_count, pass, hot_count, hot_cols, hotmap, covered);
     hipLaunchKernelGGL(k_hot_finish, dim3(1), dim3(SLAB_MAX + 1), 0, s, S, p_hist, p, T, nnz, capacity, chunk_start,
                        hot_count, tile0, slab_off);
     return hipGetLastError();
