@@ -274,3 +274,38 @@ def test_slab_cycles_and_mode_switch(oracle):
         assert A.asCSR() == 0
         assert torch.equal(ci, ci0) and torch.equal(va, va0), "asCSR restores the caller's arrays"
     A.close()
+
+
+def test_checkpoint_of_a_matrix_with_slabs(tmp_path):
+    """csr5hip_save stores the reference's arrays only; csr5hip_load re-derives them and then builds the slab structure
+    (auto rule) for the loaded matrix: same slab count, hot table and y as the handle that was saved."""
+    from benchmark_spmv_using_csr5_amd.handle import anonymouslibHandle
+    mat = _hub_columns_matrix(150000, 600000, 14, 800, 5)  # x = 4.8 MB: the auto rule turns the slabs on
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=6, mode="int")
+    rp, ci, va = _device_csr(mat, val, np.float64)
+    xd = torch.from_numpy(x).to(DEV)
+    y0 = torch.zeros(mat.m, dtype=torch.float64, device=DEV)
+    A = anonymouslibHandle(mat.m, mat.n)
+    assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0
+    assert A.setSigma(H.ANONYMOUSLIB_AUTO_TUNED_SIGMA) == 0 and A.asCSR5() == 0, _capi.last_error()
+    ia = A.info()
+    assert ia.column_slabs >= 8 and ia.slab_hot == 1, (ia.column_slabs, ia.slab_hot)
+    assert A.spmv(1.0, y0) == 0
+    torch.cuda.synchronize()
+    path = str(tmp_path / "slabs.csr5")
+    assert A.save(path) == 0
+    B = anonymouslibHandle.load(path)
+    ib = B.info()
+    got = (ib.column_slabs, ib.slab_hot, ib.slab_segments, ib.slab_tiles)
+    assert got == (ia.column_slabs, ia.slab_hot, ia.slab_segments, ia.slab_tiles)
+    y1 = torch.zeros_like(y0)
+    assert B.setX(xd) == 0 and B.spmv(1.0, y1) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    nonempty = np.diff(mat.row_ptr) > 0
+    ref = np.zeros(mat.m)
+    np.add.at(ref, np.repeat(np.arange(mat.m), np.diff(mat.row_ptr)), val * x[mat.col])
+    assert np.array_equal(y1.cpu().numpy()[nonempty], ref[nonempty])
+    B.close()
+    A.destroy()
+    A.close()
