@@ -730,8 +730,6 @@ static int build_slabs(csr5hip_handle h)
         // the per-wavefront y-compaction regions sit behind the table (k_spmv_hot)
         int lds = lds_max - HOT_WAVES * HOT_WAVE_LDS;
         lds = lds > HOT_LDS_BYTES ? HOT_LDS_BYTES : lds;
-        if (const char *e = getenv("CSR5HIP_EXPERIMENT_HOT_BYTES")) // experiment knob (scripts/experiments), never set by the product
-            lds = atoi(e) > 1024 && atoi(e) < lds ? atoi(e) : lds;
         hot_capacity = lds / (int)h->vsize();
         // Column use counts come from a sample of the non-zeros (one 64-element chunk in `stride`): ~4 M samples are
         // plenty to rank columns, and a full count serialises on the very columns it is looking for.
