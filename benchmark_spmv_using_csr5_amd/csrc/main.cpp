@@ -13,7 +13,7 @@
 // the rule-based sigma (tuned = measured selection); CSR5_MODE=0|1 picks two-pass/fused SpMV; three extra report lines (hipGraph replay
 // time, algorithmic-bytes roofline fraction, ingest phase times) are printed after the reference's lines; CSR5_RESULTS=<csv>
 // appends "file,GFlops,GB/s,roof fraction,m,nnz,sigma,tiles,us" per run (the avx512 backend's results.csv, extended).
-// CSR5_GPUS=G (G > 1) runs the same protocol on G GPUs through anonymouslibMultiHandle: nnz-balanced row blocks, one
+// CSR5_GPUS=G (G > 1) runs the same protocol on G GPUs through anonymouslibMultiHandle: cost-balanced (nnz + 2 per row) row blocks, one
 // RCCL broadcast of x, no per-SpMV collective (CSR5_GPU_LIST=0,0,.. overrides the device list, e.g. to put several
 // shards on one GPU).
 #include <cmath>

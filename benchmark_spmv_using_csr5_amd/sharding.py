@@ -2,8 +2,9 @@
 
 The reference is single-device (CSR5_cuda/main.cu:25-26 `cudaSetDevice(0)`); this is the MI355X-native
 addition named by BASELINE.json: rows are independent, so the matrix is cut into contiguous row blocks
-balanced by NON-ZEROS (split points = upper_bound(row_ptr, g*nnz/G), the same primitive the reference
-uses for tile_ptr, utils_cuda.h:25-53), every rank converts and multiplies its own block with its own
+balanced by COST = non-zeros + ROW_WEIGHT per row (split points = upper_bound of the cost prefix at g*total/G,
+the same primitive the reference uses for tile_ptr, utils_cuda.h:25-53; ROW_WEIGHT = 0 is the plain nnz
+balance), every rank converts and multiplies its own block with its own
 handle, x is replicated once by an RCCL broadcast over xGMI, y stays sharded.  There is no per-iteration
 collective.  One process per GPU, `torch.distributed` (backend "nccl" == RCCL on ROCm; "gloo" in the
 CPU tests).

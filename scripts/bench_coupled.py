@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Coupled iterations: power iteration x <- A x / |A x| on a square R-MAT cut into
-nnz-balanced row blocks, one rank per GPU.  Per iteration: CSR5 SpMV of the local block written straight into
+cost-balanced (nnz + 2 per row) row blocks, one rank per GPU.  Per iteration: CSR5 SpMV of the local block written straight into
 this rank's slot of the next x, ONE in-place all-gather over RCCL/xGMI, a dot and a norm.
 
   python scripts/bench_coupled.py --scale 20 --iters 200

@@ -1,4 +1,4 @@
-"""Multi-GPU path behind the C ABI (csr5hip_multi_*): nnz-balanced row blocks, one handle per shard, x replicated
+"""Multi-GPU path behind the C ABI (csr5hip_multi_*): cost-balanced (nnz + 2 per row) row blocks, one handle per shard, x replicated
 once, y sharded.  On a 1-GPU box every shard lives on device 0 (the device list repeats it), so the whole control
 flow -- device-side row cuts, shard copies + rebase, per-shard conversion, set_x, per-stream SpMV, gather -- runs;
 the RCCL broadcast itself needs >= 2 distinct devices and is exercised where they exist."""
@@ -113,7 +113,7 @@ def test_multi_real_data_fp32_and_graph_replay(oracle):
 
 def test_sharding_hip_local_spmv_single_process(oracle):
     """`sharding.ShardedSpmv.run` with the GPU kernel factory (the per-rank piece of the one-process-per-GPU form):
-    every nnz-balanced row block of one matrix through `hip_local_spmv`, concatenated == the full product."""
+    every cost-balanced row block of one matrix through `hip_local_spmv`, concatenated == the full product."""
     mat = M.scircuit_like(scale=0.2)
     val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=2, mode="int")
     ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)

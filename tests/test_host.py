@@ -184,7 +184,7 @@ def _gloo_worker(rank, world, port, q):
 
 
 def test_sharded_spmv_world2_gloo():
-    """N > 1 path on CPU: nnz-balanced row blocks, one broadcast of x, per-rank SpMV, y stays sharded."""
+    """N > 1 path on CPU: cost-balanced row blocks, one broadcast of x, per-rank SpMV, y stays sharded."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
