@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_desc(Geometry g, const uint3
             incl += v;
     }
     if ((raw >> 31) && lane == OMEGA - 1)
-        offset_ptr[t] = incl; // segments of this tile; scanned into offsets by k_offset_scan
+        offset_ptr[t] = incl; // segments of this tile; scanned into offsets by launch_offset_scan
     const int y_off = lane ? incl - segn - 1 : 0;
 
     const unsigned long long pmask = __ballot(present);

@@ -66,7 +66,7 @@ struct DeviceArrays {
     // fused mode only (not part of the reference format): per-run accumulator and arrival counter
     void *carry_acc;        // [p] of vT, all zero between launches
     uint32_t *carry_cnt;    // [p], all zero between launches
-    uint32_t *carry_meta;   // [p] x uint4 per tile: see k_carry_meta in csr5_format.hip
+    uint32_t *carry_meta;   // [p] x uint4 per tile: see tile_carry_meta in csr5_format.hip
     uint32_t *tile_hdr;     // [8p] fused kernel: carry_meta[t], carry_meta[t+1].x and the tile_ptr pair in ONE 32-B record
     uint32_t *counters;     // [16] conversion statistics: x-window tiles, covered non-zeros, long runs, gather lines; [4] = workgroups
                             // done; [8..15] = four 64-bit wall-clock stamps, one per conversion phase (k_row_scan, k_tile_desc, ...)

@@ -20,7 +20,8 @@
 //   exclusive scan  (rocprim) over hist in slab-major order = start of every (slab, tile) chunk in A'
 //   k_slab_scatter  workgroup / tile: stable rank of every element inside its slab (wave ballots + LDS chunk table),
 //                   scatter of column, value and the 64-bit key (slab << 32 | row)
-//   segment starts  = positions where the key changes: counted, then compacted into row_ptr' (rocprim::select)
+//   segment starts  = positions where the key changes: counted per chunk, scanned, then written into row_ptr' by
+//                   ballot rank (k_slab_count_segments, k_slab_scan_counts, k_slab_emit_segments)
 //   k_slab_tables   thread / segment: mask bit (atomicOr) and the per-64-row base index
 #include "csr5_internal.h"
 

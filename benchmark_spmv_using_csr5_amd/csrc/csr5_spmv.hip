@@ -395,7 +395,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
     uint32_t tp0 = 0, tp1 = 0, hw = 0;
     if constexpr (FUSED) {
-        // fused mode: the whole 32-byte tile header (k_tile_hdr) in one load, one word per lane (lanes 0..7)
+        // fused mode: the whole 32-byte tile header (k_tile_tables) in one load, one word per lane (lanes 0..7)
         hw = hdr[8 * (size_t)t + (lane & 7)];
     } else {
         tp0 = tile_ptr[t + vz];
@@ -483,7 +483,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         if constexpr (XWIN) {
             constexpr int XWIN_ELEMS = xwin_elems(sizeof(VT));
             // LDS x-window: carry_meta[t].w - 1 = first column of a XWIN_ELEMS-wide slice of x that
-            // covers most of this tile's columns (chosen at conversion, k_tile_window).  In-window lanes
+            // covers most of this tile's columns (chosen at conversion, k_tile_tables).  In-window lanes
             // gather from LDS (a ds_read costs a few cycles; a divergent global gather >= 34 clk per
             // wave instruction even on L1 hits); the others gather from memory as before and are
             // issued FIRST, so they overlap the window fetch.
