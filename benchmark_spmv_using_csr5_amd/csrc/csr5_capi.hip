@@ -5,6 +5,7 @@
 //   asCSR5   builds tile_ptr / tile_desc / offsets and transposes col/val IN PLACE  (:105-220)
 //   spmv     returns UNSUPPORTED_CSR_SPMV (-4) while the format is CSR              (:262-284)
 //   asCSR / destroy undo the transpose and drop the CSR5 arrays                     (:78-102, :286-291)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -743,7 +744,7 @@ static int build_slabs(csr5hip_handle h)
         } ht{tb + o_cnt, tb + o_hotmap, tb + o_chist, tb + o_thr, tb + o_count + 8};
         HIP_TRY(h->b_hot_cols.reserve((size_t)S * hot_capacity * 4));
         HIP_TRY(h->b_hot_count.reserve((size_t)S * 4));
-        HIP_TRY(h->b_hot_tile0.reserve(((size_t)S + 1) * 4));
+        HIP_TRY(h->b_hot_tile0.reserve(((size_t)2 * S + 1) * 4)); // tile0[S + 1], then the slab order of the XCDs [S]
         HIP_TRY(h->b_slab_off.reserve(((size_t)S + 1) * 4));
         HIP_TRY(hipMemsetAsync(ht.cnt, 0, nb, s));
         HIP_TRY(hipMemsetAsync(ht.hotmap, 0xFF, nb, s));
@@ -756,8 +757,33 @@ static int build_slabs(csr5hip_handle h)
                                 (int32_t *)h->b_hot_count.ptr, (int32_t *)h->b_hot_tile0.ptr, (int32_t *)h->b_slab_off.ptr,
                                 (unsigned long long *)ht.covered, s));
         unsigned long long covered = 0;
+        std::vector<int32_t> first_tile((size_t)S + 1);
         HIP_TRY(hipMemcpyAsync(&covered, ht.covered, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipMemcpyAsync(first_tile.data(), h->b_hot_tile0.ptr, ((size_t)S + 1) * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        // Which slabs an XCD walks.  Slabs differ in size (hub columns: the 16 slabs of R-MAT 24 span 0.86 .. 1.16 of the
+        // mean, and two consecutive ones still 1.12) and the kernel ends with its slowest XCD, so the slabs are dealt
+        // longest first onto the XCD with the least work that still has a round free.
+        {
+            const int rounds = S / NUM_XCD;
+            std::vector<int> by_size((size_t)S), order((size_t)S, 0), used(NUM_XCD, 0);
+            std::vector<long long> load(NUM_XCD, 0);
+            for (int k = 0; k < S; k++)
+                by_size[k] = k;
+            std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) {
+                return first_tile[a + 1] - first_tile[a] > first_tile[b + 1] - first_tile[b];
+            });
+            for (int k : by_size) {
+                int best = -1;
+                for (int x = 0; x < NUM_XCD; x++)
+                    if (used[x] < rounds && (best < 0 || load[x] < load[best]))
+                        best = x;
+                order[(size_t)best * rounds + used[best]++] = k;
+                load[best] += first_tile[k + 1] - first_tile[k];
+            }
+            HIP_TRY(hipMemcpyAsync((int32_t *)h->b_hot_tile0.ptr + S + 1, order.data(), (size_t)S * 4, hipMemcpyHostToDevice, s));
+            HIP_TRY(hipStreamSynchronize(s)); // (`order` is a local)
+        }
         h->hot_cover_pct = (int)(covered * (unsigned long long)stride * 100 / (unsigned long long)g.nnz); // estimate
         h->hot_cover_pct = h->hot_cover_pct > 100 ? 100 : h->hot_cover_pct;
         // worth it when a good part of the gathers leaves the vector memory path (measured, scripts/gpu_hot.sh)

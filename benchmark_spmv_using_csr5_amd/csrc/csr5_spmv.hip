@@ -839,7 +839,8 @@ struct HotParams {
     int slabs, rounds, capacity;     // S, S / 8, table capacity in elements
     const int32_t *cols;             // [slabs * capacity] hot column of every table slot
     const int32_t *count;            // [slabs] slots in use
-    const int32_t *tile0;            // [slabs + 1] first tile owned by each slab (tile0[S] = p - 1)
+    const int32_t *tile0;            // [slabs + 1] first tile owned by each slab (tile0[S] = p - 1); behind it [slabs]: the slabs of
+                                     // XCD 0 (one per round), of XCD 1, ... (dealt by size at conversion)
 };
 constexpr int HOT_BLOCK = 1024;
 
@@ -867,7 +868,7 @@ k_spmv_hot(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__ v
     constexpr int WAVES = HOT_BLOCK / OMEGA;
     char *wave_lds = LY ? smem + (size_t)hp.capacity * sizeof(VT) + (size_t)wave * HOT_WAVE_LDS : nullptr;
     for (int r = 0; r < hp.rounds; r++) {
-        const int k = xcd * hp.rounds + r;
+        const int k = hp.tile0[hp.slabs + 1 + xcd * hp.rounds + r];
         const int nhot = hp.count[k];
         const int32_t *hc = hp.cols + (size_t)k * hp.capacity;
         __syncthreads(); // every wavefront is done with the previous slab's table

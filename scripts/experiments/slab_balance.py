@@ -1,0 +1,18 @@
+import sys, os
+sys.path.insert(0, "/root/repo")
+import torch
+from benchmark_spmv_using_csr5_amd import matrices as M
+dev = torch.device("cuda:0")
+for scale, S in ((22, 8), (24, 16), (20, 8)):
+    mat = M.rmat_device_shard(scale, 16, 1, 0, 1, dev)
+    bits = S.bit_length() - 1
+    v = (mat.col.to(torch.int64) >> 4)
+    out = torch.zeros_like(v)
+    while int(v.max()) > 0:
+        out ^= v & (S - 1)
+        v >>= bits
+    cnt = torch.bincount(out, minlength=S).cpu().numpy()
+    print(scale, S, "slab nnz max/mean = %.3f" % (cnt.max() / cnt.mean()), "min/mean = %.3f" % (cnt.min() / cnt.mean()))
+    if S == 16:
+        pair = cnt.reshape(8, 2).sum(1)
+        print("   per XCD (2 consecutive slabs): max/mean = %.3f" % (pair.max() / pair.mean()))
