@@ -200,7 +200,7 @@ class Problem:
         # (CSR5_avx2/main.cpp:41-52: five asCSR5/asCSR rounds, then the timed one)
         # -- median of a few rounds, one sample is at the mercy of the host
         samples = []
-        for _ in range(5 if self.nnz < 50_000_000 else 2):
+        for _ in range(5 if self.nnz < 50_000_000 else 3):
             _ck(A.asCSR(), "asCSR")
             torch.cuda.synchronize()
             t0 = time.perf_counter()

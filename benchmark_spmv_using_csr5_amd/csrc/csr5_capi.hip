@@ -662,7 +662,12 @@ static int build_slabs(csr5hip_handle h)
     while ((1 << bits) < S)
         bits++;
     // all temporaries of the build in one allocation
-    constexpr size_t SLAB_TMP_KEEP = (size_t)64 << 20;
+    // Temporaries up to 1/64 of the device memory (4.5 GB of 288) stay with the handle between conversions: giving
+    // 2 GB back and asking for it again cost 120-170 ms per reconversion of R-MAT 24 until the runtime's pool had
+    // settled, ten times the 16 ms the conversion itself takes.
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const size_t SLAB_TMP_KEEP = std::max((size_t)64 << 20, total_b / 64);
     size_t scan_bytes = 0, sel_bytes = 0;
     HIP_TRY(slab_scan_tmp_bytes((size_t)S * g.p, &scan_bytes));
     HIP_TRY(slab_select_tmp_bytes(g.nnz, &sel_bytes));
@@ -677,14 +682,15 @@ static int build_slabs(csr5hip_handle h)
                  o_count = take(16), o_sel = take(sel_bytes), o_cnt = take(nb), o_hotmap = take(nb), o_chist = take(hb),
                  o_thr = take((size_t)S * 4);
     HIP_TRY(h->b_slab_tmp.reserve(off));
-    struct TmpGuard { // big temporaries (8 B per non-zero) do not outlive the build
+    struct TmpGuard { // very big temporaries (8 B per non-zero) do not outlive the build
         Buffer &b;
+        size_t keep;
         ~TmpGuard()
         {
-            if (b.cap > SLAB_TMP_KEEP)
+            if (b.cap > keep)
                 b.release();
         }
-    } tmp_guard{h->b_slab_tmp};
+    } tmp_guard{h->b_slab_tmp, SLAB_TMP_KEEP};
     char *tb = (char *)h->b_slab_tmp.ptr;
     struct {
         void *hist, *scan_tmp, *key, *count, *sel_tmp;
