@@ -1,5 +1,9 @@
-import sys, os
-sys.path.insert(0, "/root/repo")
+"""Size spread of the column slabs of R-MAT 20 / 22 / 24 under the xor-fold hash (max and min slab over the mean; for
+16 slabs also two consecutive slabs per XCD): why the hot kernel deals slabs to XCDs by size."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from benchmark_spmv_using_csr5_amd import matrices as M
 dev = torch.device("cuda:0")
