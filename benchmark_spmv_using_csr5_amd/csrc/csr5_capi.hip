@@ -646,11 +646,24 @@ static int slab_count_for(const csr5hip_handle_s *h)
     return xbytes < 64LL * 1024 * 1024 ? 8 : 16;
 }
 
+// Slab count when the hot table is NOT used (auto mode): without the table nothing ties the count to the 8 XCDs, and
+// fewer slabs mean fewer segments -- fewer partial sums to store and to combine -- as long as a slab's share of x stays
+// around half an XCD's L2 (2 MiB).  webbase-like (x = 8 MB, no popular columns): 4 slabs 24.4-24.9 us, 8 slabs
+// 25.4-26.1 us in the same GPU call, for every sigma.
+static int slab_count_without_table(const csr5hip_handle_s *h)
+{
+    const long long xbytes = (long long)h->g.n * (long long)h->vsize();
+    int S = 2;
+    while (S < 16 && (long long)S * (2LL << 20) < xbytes)
+        S *= 2;
+    return S;
+}
+
 static int build_slabs(csr5hip_handle h)
 {
     deactivate_slabs(h);
     h->t_slab = 0;
-    const int S = slab_count_for(h);
+    int S = slab_count_for(h);
     if (!S) {
         release_slabs(h); // not wanted (any more): give the memory back
         return CSR5HIP_SUCCESS;
@@ -658,29 +671,48 @@ static int build_slabs(csr5hip_handle h)
     const double t0 = now_ms();
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
-    int bits = 0;
-    while ((1 << bits) < S)
-        bits++;
-    // all temporaries of the build in one allocation
-    // Temporaries up to 1/64 of the device memory (4.5 GB of 288) stay with the handle between conversions: giving
-    // 2 GB back and asking for it again cost 120-170 ms per reconversion of R-MAT 24 until the runtime's pool had
-    // settled, ten times the 16 ms the conversion itself takes.
+    const bool auto_count = h->slab_request == 1;
+    const int S_plain = auto_count ? slab_count_without_table(h) : S; // the count if the table is not used
+
+    // LDS hot table for the persistent kernel (fused mode, S a multiple of the 8 XCDs, register budget of 16 waves/CU)?
+    const int hot_sigma = hot_child_sigma(g.sigma, (int)h->vsize());
+    const int hot_T = OMEGA * hot_sigma;
+    const int hot_p = (int)(((long long)g.nnz + hot_T - 1) / hot_T);
+    bool hot = h->hot_request != 0 && S % NUM_XCD == 0 && h->opt.mode == 1 && hot_sigma >= 4 && hot_p >= 2 &&
+               (long long)g.n * (long long)h->vsize() <= 0x7FFFFFFFLL;
+    int hot_capacity = 0;
+    if (hot) {
+        int dev = 0, lds_max = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+        // the per-wavefront y-compaction regions sit behind the table (k_spmv_hot)
+        int lds = lds_max - HOT_WAVES * HOT_WAVE_LDS;
+        lds = lds > HOT_LDS_BYTES ? HOT_LDS_BYTES : lds;
+        hot_capacity = lds / (int)h->vsize();
+    } else if (auto_count) {
+        S = S_plain; // table ruled out beforehand
+    }
+    const int S_alloc = S > S_plain ? S : S_plain;
+
+    // all temporaries of the build in one allocation.  Up to 1/64 of the device memory (4.5 GB of 288) they stay with
+    // the handle between conversions: giving 2 GB back and asking for it again cost 120-170 ms per reconversion of
+    // R-MAT 24 until the runtime's pool had settled, ten times the 16 ms the conversion itself takes.
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     const size_t SLAB_TMP_KEEP = std::max((size_t)64 << 20, total_b / 64);
     size_t scan_bytes = 0, sel_bytes = 0;
-    HIP_TRY(slab_scan_tmp_bytes((size_t)S * g.p, &scan_bytes));
+    HIP_TRY(slab_scan_tmp_bytes((size_t)S_alloc * g.p, &scan_bytes));
     HIP_TRY(slab_select_tmp_bytes(g.nnz, &sel_bytes));
-    const size_t nb = (size_t)(g.n > 0 ? g.n : 1) * 4, hb = (size_t)S * slab_hot_buckets() * 4;
+    const size_t nb = (size_t)(g.n > 0 ? g.n : 1) * 4, hb = (size_t)S_alloc * slab_hot_buckets() * 4;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
         off += (bytes + 255) & ~(size_t)255;
         return at;
     };
-    const size_t o_hist = take((size_t)S * g.p * 4), o_scan = take(scan_bytes), o_key = take((size_t)g.nnz * 8),
+    const size_t o_hist = take((size_t)S_alloc * g.p * 4), o_scan = take(scan_bytes), o_key = take((size_t)g.nnz * 8),
                  o_count = take(16), o_sel = take(sel_bytes), o_cnt = take(nb), o_hotmap = take(nb), o_chist = take(hb),
-                 o_thr = take((size_t)S * 4);
+                 o_thr = take((size_t)S_alloc * 4);
     HIP_TRY(h->b_slab_tmp.reserve(off));
     struct TmpGuard { // very big temporaries (8 B per non-zero) do not outlive the build
         Buffer &b;
@@ -695,6 +727,51 @@ static int build_slabs(csr5hip_handle h)
     struct {
         void *hist, *scan_tmp, *key, *count, *sel_tmp;
     } t{tb + o_hist, tb + o_scan, tb + o_key, tb + o_count, tb + o_sel};
+    struct {
+        void *cnt, *hotmap, *chist, *thr, *covered;
+    } ht{tb + o_cnt, tb + o_hotmap, tb + o_chist, tb + o_thr, tb + o_count + 8};
+
+    // Hot columns FIRST: the selection needs only the column indices (the parent's array, any order), and its verdict
+    // decides the slab count -- without a table fewer slabs are better, and the partition below then runs once.
+    int stride = 1;
+    if (hot) {
+        int bits_hot = 0;
+        while ((1 << bits_hot) < S)
+            bits_hot++;
+        // Column use counts come from a sample of the non-zeros (one 64-element chunk in `stride`): ~4 M samples are
+        // plenty to rank columns, and a full count serialises on the very columns it is looking for.
+        stride = (int)(g.nnz / (4LL * 1024 * 1024));
+        stride = stride < 1 ? 1 : (stride > 32 ? 32 : stride);
+        // a slot is staged by each of the ~32 workgroups of the slab's XCD in every SpMV: it must be used more often
+        int min_count = 48 / stride;
+        min_count = min_count < 2 ? 2 : min_count;
+        HIP_TRY(h->b_hot_cols.reserve((size_t)S * hot_capacity * 4));
+        HIP_TRY(h->b_hot_count.reserve((size_t)S * 4));
+        HIP_TRY(h->b_hot_tile0.reserve(((size_t)2 * S + 1) * 4)); // tile0[S + 1], then the slab order of the XCDs [S]
+        HIP_TRY(h->b_slab_off.reserve(((size_t)S + 1) * 4));
+        HIP_TRY(hipMemsetAsync(ht.cnt, 0, nb, s));
+        HIP_TRY(hipMemsetAsync(ht.hotmap, 0xFF, nb, s));
+        HIP_TRY(hipMemsetAsync(ht.chist, 0, (size_t)S * slab_hot_buckets() * 4, s));
+        HIP_TRY(hipMemsetAsync(ht.covered, 0, 8, s));
+        HIP_TRY(hipMemsetAsync(h->b_hot_cols.ptr, 0, (size_t)S * hot_capacity * 4, s));
+        HIP_TRY(slab_hot_select(g.n, g.nnz, S, bits_hot, h->slab_shift, hot_capacity, min_count, stride,
+                                (const int32_t *)h->d.col, (uint32_t *)ht.cnt, (int32_t *)ht.hotmap, (uint32_t *)ht.chist,
+                                (uint32_t *)ht.thr, (int32_t *)h->b_hot_cols.ptr, (int32_t *)h->b_hot_count.ptr,
+                                (unsigned long long *)ht.covered, s));
+        unsigned long long covered = 0;
+        HIP_TRY(hipMemcpyAsync(&covered, ht.covered, 8, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        h->hot_cover_pct = (int)(covered * (unsigned long long)stride * 100 / (unsigned long long)g.nnz); // estimate
+        h->hot_cover_pct = h->hot_cover_pct > 100 ? 100 : h->hot_cover_pct;
+        // worth it when a good part of the gathers leaves the vector memory path (measured, scripts/gpu_hot.sh)
+        hot = h->hot_request == 2 || h->hot_cover_pct >= 25;
+        if (!hot && auto_count)
+            S = S_plain; // the table was the reason for that slab count
+    }
+    int bits = 0;
+    while ((1 << bits) < S)
+        bits++;
+
     HIP_TRY(h->b_col2.reserve((size_t)g.nnz * 4));
     HIP_TRY(h->b_val2.reserve((size_t)g.nnz * h->vsize()));
     HIP_TRY(slab_partition(g, h->d, h->value_type, S, bits, h->slab_shift, (uint32_t *)t.hist, t.scan_tmp, scan_bytes,
@@ -721,85 +798,37 @@ static int build_slabs(csr5hip_handle h)
                         (uint32_t *)h->b_mask.ptr, (uint32_t *)h->b_base.ptr, s));
     HIP_TRY(h->b_P.reserve(((size_t)m2 + 1) * h->vsize()));
     HIP_TRY(hipMemsetAsync(h->b_P.ptr, 0, ((size_t)m2 + 1) * h->vsize(), s));
-    HIP_TRY(hipStreamSynchronize(s));
 
-    // LDS hot table for the persistent kernel (fused mode, S a multiple of the 8 XCDs, register budget of 16 waves/CU)
-    bool hot = false;
-    int hot_capacity = 0;
-    const int hot_sigma = hot_child_sigma(g.sigma, (int)h->vsize());
-    const int hot_T = OMEGA * hot_sigma;
-    const int hot_p = (int)(((long long)g.nnz + hot_T - 1) / hot_T);
-    if (h->hot_request != 0 && S % NUM_XCD == 0 && h->opt.mode == 1 && hot_sigma >= 4 && hot_p >= 2 &&
-        (long long)g.n * (long long)h->vsize() <= 0x7FFFFFFFLL) {
-        int dev = 0, lds_max = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-        // the per-wavefront y-compaction regions sit behind the table (k_spmv_hot)
-        int lds = lds_max - HOT_WAVES * HOT_WAVE_LDS;
-        lds = lds > HOT_LDS_BYTES ? HOT_LDS_BYTES : lds;
-        hot_capacity = lds / (int)h->vsize();
-        // Column use counts come from a sample of the non-zeros (one 64-element chunk in `stride`): ~4 M samples are
-        // plenty to rank columns, and a full count serialises on the very columns it is looking for.
-        int stride = (int)(g.nnz / (4LL * 1024 * 1024));
-        stride = stride < 1 ? 1 : (stride > 32 ? 32 : stride);
-        // a slot is staged by each of the ~32 workgroups of the slab's XCD in every SpMV: it must be used more often
-        int min_count = 48 / stride;
-        min_count = min_count < 2 ? 2 : min_count;
-        struct {
-            void *cnt, *hotmap, *chist, *thr, *covered;
-        } ht{tb + o_cnt, tb + o_hotmap, tb + o_chist, tb + o_thr, tb + o_count + 8};
-        HIP_TRY(h->b_hot_cols.reserve((size_t)S * hot_capacity * 4));
-        HIP_TRY(h->b_hot_count.reserve((size_t)S * 4));
-        HIP_TRY(h->b_hot_tile0.reserve(((size_t)2 * S + 1) * 4)); // tile0[S + 1], then the slab order of the XCDs [S]
-        HIP_TRY(h->b_slab_off.reserve(((size_t)S + 1) * 4));
-        HIP_TRY(hipMemsetAsync(ht.cnt, 0, nb, s));
-        HIP_TRY(hipMemsetAsync(ht.hotmap, 0xFF, nb, s));
-        HIP_TRY(hipMemsetAsync(ht.chist, 0, hb, s));
-        HIP_TRY(hipMemsetAsync(ht.covered, 0, 8, s));
-        HIP_TRY(hipMemsetAsync(h->b_hot_cols.ptr, 0, (size_t)S * hot_capacity * 4, s));
-        HIP_TRY(slab_hot_select(g.n, g.nnz, g.p, hot_p, hot_T, S, bits, h->slab_shift, hot_capacity, min_count, stride,
-                                (const int32_t *)h->b_col2.ptr, (const uint32_t *)t.hist, (uint32_t *)ht.cnt,
-                                (int32_t *)ht.hotmap, (uint32_t *)ht.chist, (uint32_t *)ht.thr, (int32_t *)h->b_hot_cols.ptr,
-                                (int32_t *)h->b_hot_count.ptr, (int32_t *)h->b_hot_tile0.ptr, (int32_t *)h->b_slab_off.ptr,
-                                (unsigned long long *)ht.covered, s));
-        unsigned long long covered = 0;
+    if (hot) {
+        HIP_TRY(slab_hot_finish(S, g.p, hot_p, hot_T, g.nnz, hot_capacity, (const uint32_t *)t.hist,
+                                (int32_t *)h->b_hot_count.ptr, (int32_t *)h->b_hot_tile0.ptr, (int32_t *)h->b_slab_off.ptr, s));
         std::vector<int32_t> first_tile((size_t)S + 1);
-        HIP_TRY(hipMemcpyAsync(&covered, ht.covered, 8, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipMemcpyAsync(first_tile.data(), h->b_hot_tile0.ptr, ((size_t)S + 1) * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         // Which slabs an XCD walks.  Slabs differ in size (hub columns: the 16 slabs of R-MAT 24 span 0.86 .. 1.16 of the
         // mean, and two consecutive ones still 1.12) and the kernel ends with its slowest XCD, so the slabs are dealt
         // longest first onto the XCD with the least work that still has a round free.
-        {
-            const int rounds = S / NUM_XCD;
-            std::vector<int> by_size((size_t)S), order((size_t)S, 0), used(NUM_XCD, 0);
-            std::vector<long long> load(NUM_XCD, 0);
-            for (int k = 0; k < S; k++)
-                by_size[k] = k;
-            std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) {
-                return first_tile[a + 1] - first_tile[a] > first_tile[b + 1] - first_tile[b];
-            });
-            for (int k : by_size) {
-                int best = -1;
-                for (int x = 0; x < NUM_XCD; x++)
-                    if (used[x] < rounds && (best < 0 || load[x] < load[best]))
-                        best = x;
-                order[(size_t)best * rounds + used[best]++] = k;
-                load[best] += first_tile[k + 1] - first_tile[k];
-            }
-            HIP_TRY(hipMemcpyAsync((int32_t *)h->b_hot_tile0.ptr + S + 1, order.data(), (size_t)S * 4, hipMemcpyHostToDevice, s));
-            HIP_TRY(hipStreamSynchronize(s)); // (`order` is a local)
+        const int rounds = S / NUM_XCD;
+        std::vector<int> by_size((size_t)S), order((size_t)S, 0), used(NUM_XCD, 0);
+        std::vector<long long> load(NUM_XCD, 0);
+        for (int k = 0; k < S; k++)
+            by_size[k] = k;
+        std::stable_sort(by_size.begin(), by_size.end(), [&](int a, int b) {
+            return first_tile[a + 1] - first_tile[a] > first_tile[b + 1] - first_tile[b];
+        });
+        for (int k : by_size) {
+            int best = -1;
+            for (int x = 0; x < NUM_XCD; x++)
+                if (used[x] < rounds && (best < 0 || load[x] < load[best]))
+                    best = x;
+            order[(size_t)best * rounds + used[best]++] = k;
+            load[best] += first_tile[k + 1] - first_tile[k];
         }
-        h->hot_cover_pct = (int)(covered * (unsigned long long)stride * 100 / (unsigned long long)g.nnz); // estimate
-        h->hot_cover_pct = h->hot_cover_pct > 100 ? 100 : h->hot_cover_pct;
-        // worth it when a good part of the gathers leaves the vector memory path (measured, scripts/gpu_hot.sh)
-        hot = h->hot_request == 2 || h->hot_cover_pct >= 25;
-        if (hot) {
-            HIP_TRY(slab_hot_encode(g.nnz, hot_T, hot_p, S, (const int32_t *)h->b_slab_off.ptr,
-                                    (const int32_t *)h->b_hot_tile0.ptr, (const int32_t *)ht.hotmap, (int32_t *)h->b_col2.ptr, s));
-            HIP_TRY(hipStreamSynchronize(s));
-        }
+        HIP_TRY(hipMemcpyAsync((int32_t *)h->b_hot_tile0.ptr + S + 1, order.data(), (size_t)S * 4, hipMemcpyHostToDevice, s));
+        HIP_TRY(slab_hot_encode(g.nnz, hot_T, hot_p, S, (const int32_t *)h->b_slab_off.ptr,
+                                (const int32_t *)h->b_hot_tile0.ptr, (const int32_t *)ht.hotmap, (int32_t *)h->b_col2.ptr, s));
     }
+    HIP_TRY(hipStreamSynchronize(s)); // (`order` and the temporaries are in use until here)
 
     // the stacked matrix: an ordinary CSR matrix with m2 rows, converted and multiplied by the ordinary kernels
     csr5hip_handle c = h->slab_child ? h->slab_child : new csr5hip_handle_s(); // (kept across asCSR/asCSR5 cycles)

@@ -101,10 +101,11 @@ hipError_t slab_count_segments(int nnz, const unsigned long long *key2, void *tm
 hipError_t slab_segments(int nnz, const unsigned long long *key2, const void *tmp, int32_t *row_ptr2, hipStream_t s);
 hipError_t slab_tables(int m2, int nnz, int S, int32_t *row_ptr2, const unsigned long long *key2, uint32_t *mask,
                        uint32_t *base, hipStream_t s);
-hipError_t slab_hot_select(int n, int nnz, int p_hist, int p, int T, int S, int bits, int shift, int capacity,
-                           int min_count, int sample_stride, const int32_t *col2, const uint32_t *chunk_start, uint32_t *cnt, int32_t *hotmap,
-                           uint32_t *chist, uint32_t *thr, int32_t *hot_cols, int32_t *hot_count, int32_t *tile0,
-                           int32_t *slab_off, unsigned long long *covered, hipStream_t s);
+hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capacity, int min_count, int sample_stride,
+                           const int32_t *col, uint32_t *cnt, int32_t *hotmap, uint32_t *chist, uint32_t *thr,
+                           int32_t *hot_cols, int32_t *hot_count, unsigned long long *covered, hipStream_t s);
+hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacity, const uint32_t *chunk_start,
+                           int32_t *hot_count, int32_t *tile0, int32_t *slab_off, hipStream_t s);
 hipError_t slab_hot_encode(int nnz, int T, int p, int S, const int32_t *slab_off, const int32_t *tile0,
                            const int32_t *hotmap, int32_t *col2, hipStream_t s);
 int slab_hot_buckets();

@@ -692,13 +692,13 @@ hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int
 
 namespace csr5 {
 
-// Selects the hot columns of every slab and fills hot_cols / hot_count / tile0 / slab_off; *covered = non-zeros whose
-// column got a slot.  cnt, hotmap, chist, thr: caller-provided scratch (n, n, S*HOT_BUCKETS, S words; cnt and chist
-// zeroed, hotmap set to -1).
-hipError_t slab_hot_select(int n, int nnz, int p_hist, int p, int T, int S, int bits, int shift, int capacity,
-                           int min_count, int sample_stride, const int32_t *col2, const uint32_t *chunk_start, uint32_t *cnt, int32_t *hotmap,
-                           uint32_t *chist, uint32_t *thr, int32_t *hot_cols, int32_t *hot_count, int32_t *tile0,
-                           int32_t *slab_off, unsigned long long *covered, hipStream_t s)
+// Selects the hot columns of every slab and fills hot_cols / hot_count; *covered = sampled non-zeros whose column got a
+// slot.  Needs only the column indices (any order: the parent's array), so it runs BEFORE the partition and its verdict
+// can still change the slab count.  cnt, hotmap, chist, thr: caller-provided scratch (n, n, S*HOT_BUCKETS, S words; cnt
+// and chist zeroed, hotmap filled with 0xFF by the caller).
+hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capacity, int min_count, int sample_stride,
+                           const int32_t *col, uint32_t *cnt, int32_t *hotmap, uint32_t *chist, uint32_t *thr,
+                           int32_t *hot_cols, int32_t *hot_count, unsigned long long *covered, hipStream_t s)
 {
     long long blocks = ((long long)nnz / sample_stride + SLAB_BLOCK * 8 - 1) / (SLAB_BLOCK * 8);
     blocks = blocks < 1 ? 1 : (blocks > 65536 ? 65536 : blocks);
@@ -706,13 +706,21 @@ hipError_t slab_hot_select(int n, int nnz, int p_hist, int p, int T, int S, int 
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)hot_count, 1, (size_t)S, s);
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(k_col_count, dim3((unsigned)blocks), dim3(SLAB_BLOCK), 0, s, nnz, sample_stride, col2, cnt);
+    hipLaunchKernelGGL(k_col_count, dim3((unsigned)blocks), dim3(SLAB_BLOCK), 0, s, nnz, sample_stride, col, cnt);
     hipLaunchKernelGGL(k_hot_hist, dim3((n + HOT_HIST_COLS - 1) / HOT_HIST_COLS), dim3(SLAB_BLOCK), 0, s, n, cnt, S, bits, shift,
                        chist);
     hipLaunchKernelGGL(k_hot_threshold, dim3(S), dim3(OMEGA), 0, s, capacity, min_count, chist, thr);
     for (int pass = 0; pass < 2; pass++)
         hipLaunchKernelGGL(k_hot_assign, dim3((n + HOT_ASSIGN_COLS - 1) / HOT_ASSIGN_COLS), dim3(SLAB_BLOCK), 0, s, n, cnt, bits,
                            shift, thr, capacity, min_count, pass, hot_count, hot_cols, hotmap, covered);
+    return hipGetLastError();
+}
+
+// after the partition: clamps the slot counts, first tile owned by every slab and the slab offsets
+// (chunk_start = the scanned (slab, tile) histogram of slab_partition; p_hist = tiles of the parent, p / T = the child's)
+hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacity, const uint32_t *chunk_start,
+                           int32_t *hot_count, int32_t *tile0, int32_t *slab_off, hipStream_t s)
+{
     hipLaunchKernelGGL(k_hot_finish, dim3(1), dim3(SLAB_MAX + 1), 0, s, S, p_hist, p, T, nnz, capacity, chunk_start,
                        hot_count, tile0, slab_off);
     return hipGetLastError();

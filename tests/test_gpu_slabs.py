@@ -74,7 +74,8 @@ def test_slabs_auto_rule_and_full_size_webbase(oracle):
     ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
     info = {}
     _, _, _, ys = _run(mat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, y0=0.0, info_out=info, repeat=2)
-    assert info["column_slabs"] >= 8, info
+    # no popular columns -> no hot table -> the slab count follows the size of x alone (8 MB / 2 MiB per slab)
+    assert info["column_slabs"] == 4 and info["slab_hot"] == 0, info
     assert np.array_equal(ys[0], ref) and np.array_equal(ys[1], ref)
     info = {}
     _, _, _, ys = _run(mat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, y0=0.0, slabs=0, info_out=info)
