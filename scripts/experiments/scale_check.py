@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Beyond the BASELINE size: R-MAT scale 25 / 26 (0.5 / 1.07 G non-zeros, index arithmetic close to 2^31) against an
+independent device-side CSR product (torch.sparse, checker only), default options; prints time and roofline fraction.
+
+    python scripts/experiments/scale_check.py --scale 25
+"""
+import argparse
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+
+def ck(rc, what):
+    if rc != 0:
+        from benchmark_spmv_using_csr5_amd import _capi
+        raise RuntimeError(f"{what} -> {rc}: {_capi.last_error()}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", type=int, default=25)
+    args = ap.parse_args()
+    import torch
+    from benchmark_spmv_using_csr5_amd import handle as H
+    from benchmark_spmv_using_csr5_amd import matrices as M
+
+    dev = torch.device("cuda:0")
+    mat = M.rmat_device_shard(args.scale, 16, 1, 0, 1, dev)
+    g = torch.Generator(device=dev).manual_seed(7)
+    va = torch.randint(0, 10, (mat.nnz,), generator=g, device=dev).to(torch.float64)
+    x = torch.randint(0, 10, (mat.n,), generator=g, device=dev).to(torch.float64)
+    # reference in row chunks (torch.sparse needs int64 indices: 8 B per non-zero)
+    ref = torch.empty(mat.m, dtype=torch.float64, device=dev)
+    step = 1 << 22
+    for lo in range(0, mat.m, step):
+        hi = min(mat.m, lo + step)
+        a, b = int(mat.row_ptr[lo]), int(mat.row_ptr[hi])
+        crow = (mat.row_ptr[lo:hi + 1].to(torch.int64) - a)
+        ref[lo:hi] = torch.sparse_csr_tensor(crow, mat.col[a:b].to(torch.int64), va[a:b], size=(hi - lo, mat.n)) @ x
+    nonempty = mat.row_ptr[1:] > mat.row_ptr[:-1]
+    y = torch.full((mat.m,), -3.0, dtype=torch.float64, device=dev)
+    A = H.anonymouslibHandle(mat.m, mat.n)
+    col0 = mat.col.clone()
+    ck(A.inputCSR(mat.nnz, mat.row_ptr, mat.col, va), "inputCSR")
+    ck(A.setX(x), "setX")
+    A.setSigma(-1)
+    ck(A.asCSR5(), "asCSR5")
+    i = A.info()
+    ck(A.spmv(1.0, y), "spmv")
+    torch.cuda.synchronize()
+    exact = bool(torch.equal(y[nonempty], ref[nonempty]))
+    ck(A.spmv_repeat(1.0, y, 3), "spmv_repeat")
+    torch.cuda.synchronize()
+    A.timer_start()
+    ck(A.spmv_repeat(1.0, y, 10), "spmv_repeat")
+    us = A.timer_stop() * 1e3 / 10
+    b_alg = M.algorithmic_bytes(mat.m, mat.n, mat.nnz, 8)
+    ck(A.destroy(), "destroy")
+    torch.cuda.synchronize()
+    restored = bool(torch.equal(mat.col, col0))
+    print(json.dumps({"scale": args.scale, "m": mat.m, "nnz": mat.nnz, "exact_vs_torch_sparse": exact, "csr_restored": restored,
+                      "sigma": i.sigma, "slabs": i.column_slabs, "hot": i.slab_hot, "cover_pct": i.slab_hot_cover_pct,
+                      "segments": i.slab_segments, "us": round(us, 1), "gflops": round(2 * mat.nnz / us / 1e3, 1),
+                      "frac": round(b_alg / (us * 1e-6) / 8e12, 3)}))
+    A.close()
+
+
+if __name__ == "__main__":
+    main()
