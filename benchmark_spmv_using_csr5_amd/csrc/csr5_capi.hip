@@ -124,6 +124,7 @@ struct csr5hip_handle_s {
     int slab_shift = 4;    // CSR5HIP_OPT_SLAB_SHIFT
     int zero_empty = 0;    // CSR5HIP_OPT_ZERO_EMPTY_ROWS
     bool is_child = false; // internal handle of a slab structure: never builds slabs itself
+    int slab_cap = 0;      // > 0: upper bound on the slab count (set when a build exceeded the 2-GiB partial-sum buffer)
     int slab_S = 0;        // > 0: spmv() runs child + combine
     int slab_m2 = 0;
     double t_slab = 0;
@@ -409,6 +410,7 @@ static int derive_geometry(csr5hip_handle h, int sigma)
     h->xwin_covered = 0;
     h->xwin_lines = 0;
     h->opt.long_runs = 0;
+    h->slab_cap = 0;
     h->t_malloc = h->t_tile_ptr = h->t_tile_desc = h->t_transpose = 0;
     h->drop_graphs();
     return CSR5HIP_SUCCESS;
@@ -643,7 +645,8 @@ static int slab_count_for(const csr5hip_handle_s *h)
     // one slab per XCD while a slab's share of x stays within a few L2 sizes; two per XCD beyond (measured with the hot
     // table on R-MAT 20 / 22 / 24, x = 8 / 34 / 134 MB: 8 slabs 73 / 329 / 1564 us, 16 slabs 85 / 357 / 1505 us, 32 slabs
     // 119 / 441 / 1674 us: every further round costs a table refill and a workgroup barrier)
-    return xbytes < 64LL * 1024 * 1024 ? 8 : 16;
+    // (beyond R-MAT 24 -- scale 25 / 26, x = 268 / 537 MB -- four slabs per XCD win again: 3 011 vs 3 113 us, 6 691 vs 6 970 us)
+    return xbytes < 64LL * 1024 * 1024 ? 8 : (xbytes < 256LL * 1024 * 1024 ? 16 : 32);
 }
 
 // Slab count when the hot table is NOT used (auto mode): without the table nothing ties the count to the 8 XCDs, and
@@ -664,6 +667,8 @@ static int build_slabs(csr5hip_handle h)
     deactivate_slabs(h);
     h->t_slab = 0;
     int S = slab_count_for(h);
+    if (S && h->slab_cap && S > h->slab_cap)
+        S = h->slab_cap;
     if (!S) {
         release_slabs(h); // not wanted (any more): give the memory back
         return CSR5HIP_SUCCESS;
@@ -672,7 +677,9 @@ static int build_slabs(csr5hip_handle h)
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
     const bool auto_count = h->slab_request == 1;
-    const int S_plain = auto_count ? slab_count_without_table(h) : S; // the count if the table is not used
+    int S_plain = auto_count ? slab_count_without_table(h) : S; // the count if the table is not used
+    if (h->slab_cap && S_plain > h->slab_cap)
+        S_plain = h->slab_cap;
 
     // LDS hot table for the persistent kernel (fused mode, S a multiple of the 8 XCDs, register budget of 16 waves/CU)?
     const int hot_sigma = hot_child_sigma(g.sigma, (int)h->vsize());
@@ -782,7 +789,12 @@ static int build_slabs(csr5hip_handle h)
     HIP_TRY(hipStreamSynchronize(s));
     if ((unsigned long long)m2 * h->vsize() > 0x7FFFFFFFull) {
         // the combine reads the partial sums through a raw buffer (2-GiB limit): more segments than that only occur
-        // with > 268 M (fp64) non-empty (row, slab) pairs -- fall back to the plain path
+        // with > 268 M (fp64) non-empty (row, slab) pairs -- retry with half as many slabs (fewer segments), down to
+        // the plain path
+        if (S > 2) {
+            h->slab_cap = S / 2;
+            return build_slabs(h);
+        }
         release_slabs(h);
         return CSR5HIP_SUCCESS;
     }
