@@ -51,3 +51,11 @@ for k in range(7):
 life = (ts[:, 7] - ts[:, 0]) * 10
 print("tile time ns: mean %.0f p10 %d p50 %d p90 %d max %d" % ((life.mean(),) + tuple(np.percentile(life, [10, 50, 90, 100]))))
 print("tiles per wave-slot = %.1f ; sum of tile times / (256 CUs * 16 waves) = %.1f us" % (len(ts) / 4096, life.sum() / 4096 / 1e3))
+# completion curve: when had x % of the tiles finished (share of the kernel span)?  A long tail = load imbalance between
+# wavefronts / workgroups / XCDs under the static tile assignment.
+end = np.sort(ts[:, 7] - t0).astype(np.float64)
+span = end[-1]
+print("completion curve (share of the span at which N % of the tiles were done):",
+      {q: round(float(end[int(len(end) * q / 100) - 1] / span), 3) for q in (25, 50, 75, 90, 95, 98, 99, 100)})
+start = np.sort(ts[:, 0] - t0).astype(np.float64)
+print("start curve:", {q: round(float(start[int(len(start) * q / 100) - 1] / span), 3) for q in (25, 50, 75, 90, 95, 99, 100)})
