@@ -124,18 +124,17 @@ struct csr5hip_handle_s {
     int slab_shift = 4;    // CSR5HIP_OPT_SLAB_SHIFT
     int zero_empty = 0;    // CSR5HIP_OPT_ZERO_EMPTY_ROWS
     bool is_child = false; // internal handle of a slab structure: never builds slabs itself
-    int slab_cap = 0;      // > 0: upper bound on the slab count (set when a build exceeded the 2-GiB partial-sum buffer)
     int slab_S = 0;        // > 0: spmv() runs child + combine
     int slab_m2 = 0;
     double t_slab = 0;
     csr5hip_handle_s *slab_child = nullptr;
-    Buffer b_row_ptr2, b_col2, b_val2, b_P, b_mask, b_base;
+    Buffer b_row_ptr2, b_col2, b_val2, b_P, b_rowidx, b_base, b_nonempty;
     Buffer b_slab_tmp; // temporaries of the slab build; kept between conversions only while small (SLAB_TMP_KEEP)
     // LDS hot table of the slab child (k_spmv_hot): chosen at conversion, see csr5_slab.hip
     int hot_request = 1;      // CSR5HIP_OPT_SLAB_HOT: 0 off, 1 auto, 2 force
     bool hot_enabled = false; // (child) column words are hot-encoded: spmv must use the persistent hot kernel
     int hot_cover_pct = 0;    // (parent) share of the non-zeros whose column got a table slot
-    Buffer b_hot_cols, b_hot_count, b_hot_tile0, b_slab_off;
+    Buffer b_hot_cols, b_hot_count, b_hot_tile0, b_slab_off, b_lead;
 
     // csr5hip_spmv_rotate: one graph over several handles (cold-cache measurement protocol)
     hipGraphExec_t rotate_exec = nullptr;
@@ -410,7 +409,6 @@ static int derive_geometry(csr5hip_handle h, int sigma)
     h->xwin_covered = 0;
     h->xwin_lines = 0;
     h->opt.long_runs = 0;
-    h->slab_cap = 0;
     h->t_malloc = h->t_tile_ptr = h->t_tile_desc = h->t_transpose = 0;
     h->drop_graphs();
     return CSR5HIP_SUCCESS;
@@ -604,8 +602,8 @@ static void release_slabs(csr5hip_handle h)
         csr5hip_free(h->slab_child);
         h->slab_child = nullptr;
     }
-    for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_mask, &h->b_base, &h->b_hot_cols,
-                      &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_slab_tmp})
+    for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty, &h->b_hot_cols,
+                      &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_slab_tmp})
         b->release();
     h->slab_S = 0;
     h->slab_m2 = 0;
@@ -667,8 +665,6 @@ static int build_slabs(csr5hip_handle h)
     deactivate_slabs(h);
     h->t_slab = 0;
     int S = slab_count_for(h);
-    if (S && h->slab_cap && S > h->slab_cap)
-        S = h->slab_cap;
     if (!S) {
         release_slabs(h); // not wanted (any more): give the memory back
         return CSR5HIP_SUCCESS;
@@ -678,8 +674,6 @@ static int build_slabs(csr5hip_handle h)
     hipStream_t s = h->stream;
     const bool auto_count = h->slab_request == 1;
     int S_plain = auto_count ? slab_count_without_table(h) : S; // the count if the table is not used
-    if (h->slab_cap && S_plain > h->slab_cap)
-        S_plain = h->slab_cap;
 
     // LDS hot table for the persistent kernel (fused mode, S a multiple of the 8 XCDs, register budget of 16 waves/CU)?
     const int hot_sigma = hot_child_sigma(g.sigma, (int)h->vsize());
@@ -756,6 +750,7 @@ static int build_slabs(csr5hip_handle h)
         HIP_TRY(h->b_hot_count.reserve((size_t)S * 4));
         HIP_TRY(h->b_hot_tile0.reserve(((size_t)2 * S + 1) * 4)); // tile0[S + 1], then the slab order of the XCDs [S]
         HIP_TRY(h->b_slab_off.reserve(((size_t)S + 1) * 4));
+        HIP_TRY(h->b_lead.reserve((size_t)S * HOT_RANGES_PER_SLAB * h->vsize())); // one leading partial per wavefront range
         HIP_TRY(hipMemsetAsync(ht.cnt, 0, nb, s));
         HIP_TRY(hipMemsetAsync(ht.hotmap, 0xFF, nb, s));
         HIP_TRY(hipMemsetAsync(ht.chist, 0, (size_t)S * slab_hot_buckets() * 4, s));
@@ -787,27 +782,13 @@ static int build_slabs(csr5hip_handle h)
     unsigned int m2 = 0;
     HIP_TRY(hipMemcpyAsync(&m2, t.count, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    if ((unsigned long long)m2 * h->vsize() > 0x7FFFFFFFull) {
-        // the combine reads the partial sums through a raw buffer (2-GiB limit): more segments than that only occur
-        // with > 268 M (fp64) non-empty (row, slab) pairs -- retry with half as many slabs (fewer segments), down to
-        // the plain path
-        if (S > 2) {
-            h->slab_cap = S / 2;
-            return build_slabs(h);
-        }
-        release_slabs(h);
-        return CSR5HIP_SUCCESS;
-    }
     HIP_TRY(h->b_row_ptr2.reserve(((size_t)m2 + 1) * 4));
     HIP_TRY(slab_segments(g.nnz, (const unsigned long long *)t.key, t.sel_tmp, (int32_t *)h->b_row_ptr2.ptr, s));
-    const size_t mask_words = ((size_t)g.m * S + 31) / 32 + 1;
-    const size_t base_words = ((size_t)g.m + OMEGA - 1) / OMEGA * S;
-    HIP_TRY(h->b_mask.reserve(mask_words * 4));
-    HIP_TRY(h->b_base.reserve(base_words * 4));
-    HIP_TRY(hipMemsetAsync(h->b_mask.ptr, 0, mask_words * 4, s));
-    HIP_TRY(hipMemsetAsync(h->b_base.ptr, 0, base_words * 4, s));
-    HIP_TRY(slab_tables((int)m2, g.nnz, S, (int32_t *)h->b_row_ptr2.ptr, (const unsigned long long *)t.key,
-                        (uint32_t *)h->b_mask.ptr, (uint32_t *)h->b_base.ptr, s));
+    HIP_TRY(h->b_rowidx.reserve((size_t)m2 + 1));
+    HIP_TRY(h->b_base.reserve(slab_base_words(g.m, S) * 4));
+    HIP_TRY(h->b_nonempty.reserve(((size_t)g.m / 32 + 16) * 4));
+    HIP_TRY(slab_tables(g.m, (int)m2, g.nnz, S, h->d.row_ptr, (int32_t *)h->b_row_ptr2.ptr, (const unsigned long long *)t.key,
+                        (unsigned char *)h->b_rowidx.ptr, (uint32_t *)h->b_base.ptr, (uint32_t *)h->b_nonempty.ptr, s));
     HIP_TRY(h->b_P.reserve(((size_t)m2 + 1) * h->vsize()));
     HIP_TRY(hipMemsetAsync(h->b_P.ptr, 0, ((size_t)m2 + 1) * h->vsize(), s));
 
@@ -862,6 +843,7 @@ static int build_slabs(csr5hip_handle h)
     c->d.hot_tile0 = (const int32_t *)h->b_hot_tile0.ptr;
     c->d.hot_slabs = S;
     c->d.hot_capacity = hot_capacity;
+    c->d.range_lead = h->b_lead.ptr;
     int rc = csr5hip_input_csr(c, g.nnz, (int32_t *)h->b_row_ptr2.ptr, (int32_t *)h->b_col2.ptr, h->b_val2.ptr);
     c->sigma_request = hot ? hot_sigma : g.sigma;
     if (rc == CSR5HIP_SUCCESS)
@@ -886,8 +868,8 @@ static hipError_t enqueue_spmv(csr5hip_handle h, void *d_y, hipStream_t s)
         if (e != hipSuccess)
             return e;
         return launch_slab_combine(h->g.m, h->g.tail_start, h->zero_empty, h->slab_S, h->value_type,
-                                   (const uint32_t *)h->b_mask.ptr, (const uint32_t *)h->b_base.ptr, h->b_P.ptr, h->slab_m2,
-                                   d_y, s);
+                                   (const uint32_t *)h->b_base.ptr, (const unsigned char *)h->b_rowidx.ptr,
+                                   (const uint32_t *)h->b_nonempty.ptr, h->b_P.ptr, h->slab_m2, d_y, s);
     }
     if (h->zero_empty && h->g.m > 0) {
         // every row that owns a non-zero is overwritten by the kernel; this defines the others

@@ -1,0 +1,472 @@
+// csr5_hot.hip -- the persistent kernel of the column-slab child with an LDS hot table (csr5_slab.hip), round 3.
+//
+// What it computes is the reference's tile kernel (CSR5_cuda/detail/cuda/csr5_spmv_cuda.h:59-311: fast / normal track,
+// lane-local flag walk, cross-lane segmented sum) on the child's CSR5 arrays; how the work is laid out is ours:
+//   * one 1024-thread workgroup per CU stays resident; XCD x walks its slabs in order, refilling the LDS table with
+//     the slab's hot x entries (hot gathers = ds_read_b64, cold ones = range-checked buffer loads);
+//   * every WAVEFRONT owns ONE CONTIGUOUS RANGE of the slab's tiles (512 ranges per slab).  The row that is open at a
+//     tile boundary therefore meets its continuation in the registers of the same wavefront: a tile needs no header,
+//     no re-read of its successor's first elements, no carry slot and no atomic -- the reference's calibrate pass
+//     (csr5_spmv_cuda.h:313-382) shrinks to ONE leading partial per range (`lead`), added by k_range_finish;
+//   * a tile's finished partial sums are compacted in LDS and leave as one contiguous run P[row_start ...]: the
+//     stores of a wavefront are sequential over its whole range.
+// Round 2's form (tiles dealt round robin, per-tile 32-byte header, short-spill re-reads, arrival protocol) is gone.
+#include "csr5_internal.h"
+#include "csr5_wave.h"
+
+#include <type_traits>
+
+namespace csr5 {
+
+constexpr int HOT_BLOCK = 1024;
+
+template <typename VT, int SIGMA>
+struct TileRegs {
+    int32_t c[SIGMA];
+    VT v[SIGMA];
+    uint32_t w0, tp0, tp1;
+};
+
+// every load of tile t: column words first (the gathers wait for them only), then the descriptor word, the tile_ptr
+// pair (vector loads of wave-uniform words: they return in order with the rest) and the values
+template <typename VT, int SIGMA, bool NT>
+__device__ __forceinline__ void range_load(TileRegs<VT, SIGMA> &r, const int32_t *__restrict__ col,
+                                           const VT *__restrict__ val, const uint32_t *__restrict__ tile_desc,
+                                           const uint32_t *__restrict__ tile_ptr, int t, int lane, int vz)
+{
+    constexpr int T = OMEGA * SIGMA;
+    const int32_t *ct = col + (size_t)t * T + lane;
+    const VT *vt = val + (size_t)t * T + lane;
+#pragma unroll
+    for (int i = 0; i < SIGMA; i++)
+        r.c[i] = NT ? __builtin_nontemporal_load(ct + i * OMEGA) : ct[i * OMEGA];
+    r.w0 = tile_desc[(size_t)t * OMEGA + lane];
+    r.tp0 = tile_ptr[t + vz];
+    r.tp1 = tile_ptr[t + 1 + vz];
+#pragma unroll
+    for (int i = 0; i < SIGMA; i++)
+        r.v[i] = NT ? __builtin_nontemporal_load(vt + i * OMEGA) : vt[i * OMEGA];
+}
+
+// State of the row that is open at the current tile boundary (wave-uniform).
+template <typename VT>
+struct OpenRow {
+    int row;      // child row (segment) of the open partial
+    VT val;       // its partial sum so far (same value in every lane)
+    bool is_lead; // the row was already open when the range began: the partial goes to lead[range], not to P
+};
+
+template <typename VT, int SIGMA, bool NT, int DEPTH>
+__global__ void __launch_bounds__(HOT_BLOCK)
+k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__ val, const VT *__restrict__ x,
+             const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc, VT *__restrict__ P,
+             VT *__restrict__ lead, HotParams hp)
+{
+    static_assert(num_packet_of(SIGMA) == 1, "a hot child keeps one descriptor packet");
+    using word_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
+    constexpr int bit_y = bit_y_of(SIGMA), bit_all = bit_y + BIT_SS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // typed LDS pointer: keeps the table reads on ds_read (a generic pointer would merge the hot/cold select into one
+    // flat_load)
+    auto *hot = (__attribute__((address_space(3))) VT *)(smem);
+    const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, nwg = gridDim.x / NUM_XCD;
+    const int lane = threadIdx.x & (OMEGA - 1), wave = threadIdx.x >> 6;
+    VT *seg = reinterpret_cast<VT *>(smem + (size_t)hp.capacity * sizeof(VT) + (size_t)wave * HOT_WAVE_LDS);
+    const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(x), (short)0, g.n * (int)sizeof(VT), 0x00020000);
+    int vz; // opaque per-lane zero: keeps the wave-uniform tile_ptr words on the vector memory path (in-order return)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+
+    for (int r = 0; r < hp.rounds; r++) {
+        const int k = hp.tile0[hp.slabs + 1 + xcd * hp.rounds + r];
+        const int nhot = hp.count[k];
+        const int32_t *hc = hp.cols + (size_t)k * hp.capacity;
+        __syncthreads(); // every wavefront is done with the previous slab's table
+        // Refill in batches of 16 slots per thread: all column words first (coalesced), then all gathers, then the
+        // LDS writes -- two memory round trips per batch instead of two dependent ones per slot.
+        for (int j0 = 0; j0 < nhot; j0 += HOT_BLOCK * 16) {
+            int32_t cw[16];
+            VT xw[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
+                cw[q] = hc[j < nhot ? j : 0]; // (unconditional load at a clamped index: a select on the LOADED value compiles to
+                                              //  sixteen branches with a full wait each)
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                xw[q] = x[(uint32_t)cw[q]];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
+                if (j < nhot)
+                    hot[j] = j ? xw[q] : (VT)0; // slot 0 = +0.0: what the cold lanes read
+            }
+        }
+        __syncthreads();
+
+        // this wavefront's contiguous range of the slab's tiles
+        const int t0 = hp.tile0[k], n = hp.tile0[k + 1] - t0;
+        const int nr = nwg * (HOT_BLOCK / OMEGA), rho = wg * (HOT_BLOCK / OMEGA) + wave;
+        const int q = n / nr, rem = n % nr;
+        const int tb = __builtin_amdgcn_readfirstlane(t0 + rho * q + (rho < rem ? rho : rem));
+        const int te = __builtin_amdgcn_readfirstlane(tb + q + (rho < rem ? 1 : 0));
+        VT *const my_lead = lead + (size_t)k * nr + rho;
+        if (tb >= te) {
+            if (lane == 0)
+                *my_lead = 0;
+            continue;
+        }
+
+        OpenRow<VT> open{-1, (VT)0, true};
+        // the partial of the open row is complete (its row ended): to P, or -- the row was open when the range began --
+        // to this range's lead word
+        auto emit_open = [&]() {
+            if (lane == 0)
+                *(open.is_lead ? my_lead : P + open.row) = open.val;
+        };
+        // One x gather per element, branch-free: cold lanes (plain column word) read x through a raw buffer load; hot
+        // lanes (bit 31 set) carry the byte offset 0xFFFFFFFF there, which the buffer's range check turns into "return
+        // 0, touch no memory".  Every lane then reads the LDS table (cold lanes slot 0 = +0.0) and a bitwise OR merges
+        // the two words exactly.
+        auto cold_word = [&](int32_t cw) -> word_t {
+            const unsigned off = cw < 0 ? 0xFFFFFFFFu : (unsigned)cw * (unsigned)sizeof(VT);
+            if constexpr (sizeof(VT) == 8)
+                return __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
+            else
+                return __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b32(xbuf, off, 0, 0));
+        };
+        auto table_word = [&](int32_t cw) -> word_t {
+            return __builtin_bit_cast(word_t, hot[cw < 0 ? (unsigned)cw & 0x7FFFFFFFu : 0u]);
+        };
+
+        // ---- one tile whose loads (streams in `tr`, cold gathers in `xg`) are in flight or done -------------------------
+        auto compute = [&](const TileRegs<VT, SIGMA> &tr, const word_t (&xg)[SIGMA]) {
+            VT mx[SIGMA];
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++)
+                mx[i] = __builtin_bit_cast(VT, (word_t)(xg[i] | table_word(tr.c[i])));
+            const uint32_t tp0 = __builtin_amdgcn_readfirstlane(tr.tp0), tp1 = __builtin_amdgcn_readfirstlane(tr.tp1);
+            const int rs = (int)(tp0 & ROW_MASK);
+            // decode before any data-dependent branch (loads consumed only inside a branch get sunk into it)
+            const uint32_t flags = tr.w0 << bit_all; // element i -> bit 31-i
+            int y_off = (int)(tr.w0 >> (32 - bit_y));
+            const bool f0 = (flags >> 31) | (lane == 0);
+            const bool present = f0 | ((flags & 0x7FFFFFFFu) != 0);
+            if (open.row < 0)
+                open.row = rs; // first tile of the range
+            if (rs != open.row) {
+                // the tile begins with a new row: the open one ended exactly on the boundary
+                emit_open();
+                open.row = rs;
+                open.val = 0;
+                open.is_lead = false;
+            }
+            if (tp0 == tp1) {
+                // fast track: the whole tile lies inside the open row (csr5_spmv_cuda.h:59-90)
+                VT s = 0;
+#pragma unroll
+                for (int i = 0; i < SIGMA; i++)
+                    s = __builtin_fma(tr.v[i], mx[i], s);
+                open.val += wave_sum(s);
+                return;
+            }
+            const unsigned long long pmask = __ballot(present);
+            bool direct = f0 && lane != 0;
+            VT sum = tr.v[0] * mx[0];
+            VT first_sum = 0;
+#pragma unroll
+            for (int i = 1; i < SIGMA; i++) {
+                if ((flags >> (31 - i)) & 1u) {
+                    if (direct)
+                        seg[y_off] = sum;
+                    else
+                        first_sum = sum;
+                    y_off += direct;
+                    direct = true;
+                    sum = 0;
+                }
+                sum = __builtin_fma(tr.v[i], mx[i], sum);
+            }
+            if (!direct)
+                first_sum = sum;
+            // cross-lane step: backward segmented scan R[j] = lead[j] + (present[j] ? 0 : R[j+1]) on DPP row shifts and
+            // v_readlane row carries; steps no lane needs are skipped by scalar tests on the flag-owner mask
+            VT R = f0 ? (VT)0 : first_sum;
+            const unsigned long long z1 = ~pmask;
+            if (z1) {
+                const unsigned long long ahead = pmask >> lane;
+                const int dist = ahead ? __builtin_ctzll(ahead) : OMEGA - 1 - lane;
+                {
+                    const VT up = dpp_move<DPP_ROW_SHL1>(R);
+                    R += dist >= 1 ? up : (VT)0;
+                }
+                const unsigned long long z2 = z1 & (z1 >> 1);
+                if (z2) {
+                    {
+                        const VT up = dpp_move<DPP_ROW_SHL2>(R);
+                        R += dist >= 2 ? up : (VT)0;
+                    }
+                    const unsigned long long z4 = z2 & (z2 >> 2);
+                    if (z4) {
+                        {
+                            const VT up = dpp_move<DPP_ROW_SHL4>(R);
+                            R += dist >= 4 ? up : (VT)0;
+                        }
+                        if (z4 & (z4 >> 4)) {
+                            const VT up = dpp_move<DPP_ROW_SHL8>(R);
+                            R += dist >= 8 ? up : (VT)0;
+                        }
+                    }
+                }
+                const int reach = lane + dist;
+#pragma unroll
+                for (int edge = 48; edge >= 16; edge -= 16) {
+                    if (!((pmask >> (edge - 1)) & 1ull)) { // lane edge-1 owns no flag: its run crosses the edge
+                        const VT carry_in = bcast_lane(R, edge);
+                        R += ((lane >> 4) == (edge >> 4) - 1 && reach >= edge) ? carry_in : (VT)0;
+                    }
+                }
+            }
+            const VT S = lane_above(R); // lane 63 gets 0
+            if (present)
+                sum += S;
+            // leading run of the tile (elements before the first row start at position >= 1): continues the open row
+            const VT leading = bcast_lane(direct ? first_sum : sum, 0);
+            const unsigned long long dmask = __ballot(direct);
+            if (!dmask) {
+                open.val += leading; // no row starts inside the tile
+                return;
+            }
+            // Rows rs .. rs + nslot: row rs (the open row) is complete now, slots 0..nslot-2 are rows that start and end
+            // inside the tile, slot nslot-1 -- the last segment of the highest flag-owning lane -- stays open.
+            const int last = 63 - __builtin_clzll(pmask);
+            const int nslot = __builtin_amdgcn_readlane(y_off, last) + 1;
+            const VT closing = bcast_lane(sum, last);
+            if (direct && lane != last)
+                seg[y_off] = sum;
+            const VT done = open.val + leading;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            VT *const out = P + rs;
+            // one contiguous run P[rs .. rs + nslot): element 0 = the finished open row (or this range's lead word)
+            for (int j = lane; j < nslot; j += OMEGA) {
+                const VT vj = j == 0 ? done : seg[j > 0 ? j - 1 : 0];
+                if (j > 0 || !open.is_lead)
+                    out[j] = vj;
+            }
+            if (open.is_lead && lane == 0)
+                *my_lead = done;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // the next tile's LDS writes stay behind these reads
+            __builtin_amdgcn_wave_barrier();
+            open.row = rs + nslot;
+            open.val = closing;
+            open.is_lead = false;
+        };
+
+        if constexpr (DEPTH == 1) {
+            for (int t = tb; t < te; t++) {
+                TileRegs<VT, SIGMA> a;
+                word_t xa[SIGMA];
+                range_load<VT, SIGMA, NT>(a, col, val, tile_desc, tile_ptr, t, lane, vz);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < SIGMA; i++)
+                    xa[i] = cold_word(a.c[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(a, xa);
+            }
+        } else {
+            // DEPTH 2: the next tile's streams go out right behind this tile's gathers and are in flight while it
+            // computes.  Tiles are taken in pairs (two register sets, no copies) and an odd last tile is peeled: a
+            // `break` in the middle of the pair loop leaves the compiler a path on which the second set's loads are
+            // still pending at the loop head, and it then drains the whole queue (s_waitcnt vmcnt(0)) in front of
+            // every pair's gathers.
+            TileRegs<VT, SIGMA> a, b;
+            word_t xa[SIGMA];
+            range_load<VT, SIGMA, NT>(a, col, val, tile_desc, tile_ptr, tb, lane, vz);
+            int t = tb;
+            for (; t + 1 < te; t += 2) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < SIGMA; i++)
+                    xa[i] = cold_word(a.c[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                range_load<VT, SIGMA, NT>(b, col, val, tile_desc, tile_ptr, t + 1, lane, vz);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(a, xa);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < SIGMA; i++)
+                    xa[i] = cold_word(b.c[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                range_load<VT, SIGMA, NT>(a, col, val, tile_desc, tile_ptr, t + 2 < te ? t + 2 : t + 1, lane, vz);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(b, xa);
+            }
+            if (t < te) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < SIGMA; i++)
+                    xa[i] = cold_word(a.c[i]);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(a, xa);
+            }
+        }
+        emit_open(); // the last open row of the range: a later range may continue it (its lead is added by k_range_finish)
+    }
+}
+
+// ---- after the persistent kernel: the CSR tail tile and the range seams -------------------------------------------------
+// One thread per range R (and one for the CSR tail, "range" S * ranges_per_slab), 256 per workgroup.
+// Tail (csr5_spmv_cuda.h:384-419): rows tail_start .. m-1, at most T <= 1024 non-zeros and (no empty rows in a slab child)
+//   at most as many rows.  Every workgroup multiplies the tail's elements into LDS (one round trip, a few hundred
+//   elements) so that it knows the partial of the first tail row -- the "lead" of the tail -- without waiting for another
+//   workgroup; workgroup 0 also stores the other tail rows.
+// Seams: for every row that is open at the start of a range (or of the tail), in range order:
+//   P[row] = (the partial stored by the range in which the row begins, unless it begins exactly with this range)
+//          + the leads of all consecutive ranges that start inside the row -- the reference's calibrate pass
+//   (csr5_spmv_cuda.h:313-382) with a fixed association, so results are bit-reproducible.  The thread of the FIRST range
+//   of a row does the additions; a row spanning k ranges costs it k loads (hub rows: a few hundred at most per slab).
+struct RangeHead {
+    int row;            // first row of the range, -1 = the range holds no tile
+    long long first;    // index of its first element
+};
+__device__ __forceinline__ RangeHead range_head(const Geometry &g, const HotParams &hp, const uint32_t *__restrict__ tile_ptr,
+                                                int R, int nranges, int ranges_per_slab)
+{
+    if (R < 0)
+        return RangeHead{-1, 0};
+    if (R >= nranges)
+        return RangeHead{g.tail_start < g.m ? g.tail_start : -1, (long long)(g.p - 1) * g.tile_elems};
+    const int k = R / ranges_per_slab, rho = R % ranges_per_slab;
+    const int t0 = hp.tile0[k], n = hp.tile0[k + 1] - t0;
+    const int q = n / ranges_per_slab, rem = n % ranges_per_slab;
+    const int tb = t0 + rho * q + (rho < rem ? rho : rem);
+    if (q + (rho < rem ? 1 : 0) <= 0)
+        return RangeHead{-1, 0};
+    return RangeHead{(int)(tile_ptr[tb] & ROW_MASK), (long long)tb * g.tile_elems};
+}
+
+template <typename VT>
+__global__ void __launch_bounds__(256)
+k_range_finish(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+               const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
+               VT *__restrict__ P, const VT *__restrict__ lead, HotParams hp, int ranges_per_slab)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    VT *sprod = reinterpret_cast<VT *>(smem); // [T] tail products
+    __shared__ VT tail_lead;
+    const int tid = threadIdx.x;
+    const int T = g.tile_elems;
+    const long long first_tail = (long long)(g.p - 1) * T;
+    const int E = (int)((long long)g.nnz - first_tail);
+    const int nranges = hp.slabs * ranges_per_slab;
+    const int R = blockIdx.x * 256 + tid;
+    // this thread's range and its neighbours: their loads go out together with the tail's
+    const RangeHead me = range_head(g, hp, tile_ptr, R <= nranges ? R : -1, nranges, ranges_per_slab);
+    RangeHead prev = range_head(g, hp, tile_ptr, R <= nranges ? R - 1 : -1, nranges, ranges_per_slab);
+    for (int e = tid; e < E; e += 256) {
+        const int32_t c = col[first_tail + e];
+        sprod[e] = val[first_tail + e] * x[(uint32_t)c];
+    }
+    __syncthreads();
+    if (g.tail_start < g.m) {
+        // first tail row (it may be all of the tail): strided partial sums, then a fixed-shape reduction -- the other rows
+        // only in workgroup 0
+        {
+            __shared__ VT part[4];
+            const int b = (int)((long long)row_ptr[g.tail_start + 1] - first_tail);
+            VT s0 = 0;
+            for (int k = tid; k < b; k += 256)
+                s0 += sprod[k];
+            s0 = wave_sum(s0);
+            if ((tid & (OMEGA - 1)) == 0)
+                part[tid >> 6] = s0;
+            __syncthreads();
+            if (tid == 0)
+                tail_lead = (part[0] + part[1]) + (part[2] + part[3]);
+        }
+        if (blockIdx.x == 0)
+            for (int r = g.tail_start + 1 + tid; r < g.m; r += 256) {
+                const int a = (int)((long long)row_ptr[r] - first_tail), b = (int)((long long)row_ptr[r + 1] - first_tail);
+                VT s1 = 0;
+                for (int k = a; k < b; k++)
+                    s1 += sprod[k];
+                P[r] = s1;
+            }
+    }
+    __syncthreads();
+    if (R > nranges || me.row < 0)
+        return;
+    for (int Rp = R - 2; prev.row < 0 && Rp >= 0; Rp--) // (empty ranges: only in slabs with fewer tiles than wavefronts)
+        prev = range_head(g, hp, tile_ptr, Rp, nranges, ranges_per_slab);
+    if (prev.row == me.row)
+        return; // not the first range of its row
+    // the row begins exactly with this range (nobody stored a partial for it) or inside an earlier one
+    VT sum = (long long)row_ptr[me.row] == me.first ? (VT)0 : P[me.row];
+    sum += R == nranges ? tail_lead : lead[R];
+    for (int R2 = R + 1; R2 <= nranges; R2++) {
+        const RangeHead h2 = range_head(g, hp, tile_ptr, R2, nranges, ranges_per_slab);
+        if (h2.row < 0)
+            continue;
+        if (h2.row != me.row)
+            break;
+        sum += R2 == nranges ? tail_lead : lead[R2];
+    }
+    P[me.row] = sum;
+}
+
+// ---- dispatch ----------------------------------------------------------------------------------------------------------
+template <typename VT, int SIGMA, bool NT>
+static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const void *x, void *y, hipStream_t s)
+{
+    HotParams hp{d.hot_slabs, d.hot_slabs / NUM_XCD, d.hot_capacity, d.hot_cols, d.hot_count, d.hot_tile0};
+    const size_t lds = (size_t)d.hot_capacity * sizeof(VT) + (size_t)HOT_WAVES * HOT_WAVE_LDS;
+    constexpr int DEPTH = CSR5_HOT_DEPTH;
+    auto kern = k_spmv_range<VT, SIGMA, NT, DEPTH>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess)
+        return e;
+    if (g.p > 1) {
+        hipLaunchKernelGGL(kern, dim3(NUM_XCD * HOT_WGS_PER_XCD), dim3(HOT_BLOCK), lds, s, g, d.col, (const VT *)d.val,
+                           (const VT *)x, d.tile_ptr, d.tile_desc, (VT *)y, (VT *)d.range_lead, hp);
+        e = hipGetLastError();
+        if (e != hipSuccess)
+            return e;
+    }
+    const int ranges = HOT_RANGES_PER_SLAB;
+    const int blocks = (d.hot_slabs * ranges + 1 + 255) / 256;
+    hipLaunchKernelGGL(k_range_finish<VT>, dim3(blocks), dim3(256), (size_t)g.tile_elems * sizeof(VT), s, g, d.row_ptr, d.col,
+                       (const VT *)d.val, (const VT *)x, d.tile_ptr, (VT *)y, (const VT *)d.range_lead, hp, ranges);
+    return hipGetLastError();
+}
+
+template <typename VT>
+static hipError_t launch_range_sigma(const Geometry &g, const DeviceArrays &d, const void *x, void *y, bool nt, hipStream_t s)
+{
+    switch (g.sigma) {
+#define CSR5_HOT_CASE(S)                                                                                               \
+    case S:                                                                                                            \
+        if constexpr ((size_t)OMEGA * S * sizeof(VT) <= (size_t)HOT_WAVE_LDS)                                          \
+            return nt ? launch_range<VT, S, true>(g, d, x, y, s) : launch_range<VT, S, false>(g, d, x, y, s);         \
+        else                                                                                                           \
+            return hipErrorInvalidValue;
+        CSR5_HOT_CASE(4) CSR5_HOT_CASE(5) CSR5_HOT_CASE(6) CSR5_HOT_CASE(7) CSR5_HOT_CASE(8) CSR5_HOT_CASE(9)
+        CSR5_HOT_CASE(10) CSR5_HOT_CASE(11) CSR5_HOT_CASE(12) CSR5_HOT_CASE(13) CSR5_HOT_CASE(14) CSR5_HOT_CASE(15)
+        CSR5_HOT_CASE(16)
+#undef CSR5_HOT_CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// the slab child's SpMV when its column words are hot-encoded: P = A' x (y = the partial-sum array of the parent)
+hipError_t launch_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, void *y,
+                           const SpmvOptions &opt, hipStream_t s)
+{
+    if (g.p <= 0)
+        return hipSuccess;
+    return value_type == CSR5HIP_F64 ? launch_range_sigma<double>(g, d, x, y, opt.stream_nt != 0, s)
+                                     : launch_range_sigma<float>(g, d, x, y, opt.stream_nt != 0, s);
+}
+
+} // namespace csr5

@@ -73,8 +73,9 @@ struct DeviceArrays {
     // column-slab child with an LDS hot table (csr5_slab.hip / k_spmv_hot): column words with bit 31 set index the table
     const int32_t *hot_cols;   // [hot_slabs * hot_capacity]
     const int32_t *hot_count;  // [hot_slabs]
-    const int32_t *hot_tile0;  // [hot_slabs + 1]
+    const int32_t *hot_tile0;  // [hot_slabs + 1] first tile of every slab, then [hot_slabs] the slabs each XCD walks
     int hot_slabs, hot_capacity;
+    void *range_lead;          // [hot_slabs * HOT_RANGES_PER_SLAB] of vT: leading partial of every wavefront range (csr5_hot.hip)
 };
 
 // ---- conversion (csr5_format.hip) ----
@@ -99,8 +100,9 @@ hipError_t slab_partition(const Geometry &g, const DeviceArrays &d, int value_ty
                           unsigned long long *key2, hipStream_t s);
 hipError_t slab_count_segments(int nnz, const unsigned long long *key2, void *tmp, unsigned int *d_count, hipStream_t s);
 hipError_t slab_segments(int nnz, const unsigned long long *key2, const void *tmp, int32_t *row_ptr2, hipStream_t s);
-hipError_t slab_tables(int m2, int nnz, int S, int32_t *row_ptr2, const unsigned long long *key2, uint32_t *mask,
-                       uint32_t *base, hipStream_t s);
+size_t slab_base_words(int m, int S);
+hipError_t slab_tables(int m, int m2, int nnz, int S, const int32_t *row_ptr, int32_t *row_ptr2, const unsigned long long *key2,
+                       unsigned char *rowidx, uint32_t *base, uint32_t *nonempty, hipStream_t s);
 hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capacity, int min_count, int sample_stride,
                            const int32_t *col, uint32_t *cnt, int32_t *hotmap, uint32_t *chist, uint32_t *thr,
                            int32_t *hot_cols, int32_t *hot_count, unsigned long long *covered, hipStream_t s);
@@ -109,8 +111,9 @@ hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacit
 hipError_t slab_hot_encode(int nnz, int T, int p, int S, const int32_t *slab_off, const int32_t *tile0,
                            const int32_t *hotmap, int32_t *col2, hipStream_t s);
 int slab_hot_buckets();
-hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int value_type, const uint32_t *mask,
-                               const uint32_t *base, const void *P, int segments, void *y, hipStream_t s);
+hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int value_type, const uint32_t *base,
+                               const unsigned char *rowidx, const uint32_t *nonempty, const void *P, int segments, void *y,
+                               hipStream_t s);
 
 // ---- SpMV (csr5_spmv.hip) ----
 struct SpmvOptions {
@@ -122,9 +125,22 @@ struct SpmvOptions {
     int long_runs;   // resolved: the matrix has rows spanning > RUN_SERIAL_MAX tiles (fused mode adds k_calibrate)
     int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_hot + tail launch
 };
-constexpr int HOT_LDS_BYTES = 128 * 1024;  // LDS table of hot x entries per workgroup (k_spmv_hot) without y compaction
-constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_hot (16 wavefronts)
+constexpr int HOT_LDS_BYTES = 128 * 1024;  // upper bound of the LDS table of hot x entries per workgroup (k_spmv_range)
+constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_range (16 wavefronts)
 constexpr int HOT_WAVES = 16;
+constexpr int HOT_WGS_PER_XCD = 32;        // one 1024-thread workgroup per CU
+constexpr int HOT_RANGES_PER_SLAB = HOT_WGS_PER_XCD * HOT_WAVES; // every wavefront of the slab's XCD owns one tile range
+#ifndef CSR5_HOT_DEPTH
+#define CSR5_HOT_DEPTH 2                   // tiles whose streams are in flight per wavefront (1 or 2)
+#endif
+// what the persistent kernel needs to know about the slabs (device arrays built by csr5_slab.hip)
+struct HotParams {
+    int slabs, rounds, capacity;     // S, S / 8, table capacity in elements
+    const int32_t *cols;             // [slabs * capacity] hot column of every table slot
+    const int32_t *count;            // [slabs] slots in use
+    const int32_t *tile0;            // [slabs + 1] first tile owned by each slab (tile0[S] = p - 1); behind it [slabs]: the slabs of
+                                     // XCD 0 (one per round), of XCD 1, ... (dealt by size at conversion)
+};
 // child sigma of a hot slab structure: small enough for the y-compaction region (measured: the hot kernel is flat in
 // sigma between 8 and 16, R-MAT 22 320 / 324 / 329 us at 8 / 12 / 16)
 constexpr int hot_child_sigma(int parent_sigma, int value_size)
@@ -134,5 +150,8 @@ constexpr int hot_child_sigma(int parent_sigma, int value_size)
 }
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s);
+// csr5_hot.hip: the slab child's SpMV when its column words are hot-encoded (persistent range kernel + finish)
+hipError_t launch_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, void *y,
+                           const SpmvOptions &opt, hipStream_t s);
 
 } // namespace csr5

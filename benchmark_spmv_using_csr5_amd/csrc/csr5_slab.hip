@@ -10,10 +10,12 @@
 // at least one non-zero is a contiguous SEGMENT.  Stacking the S sub-matrices vertically gives ONE CSR matrix A'
 // with m' = number of segments rows, the same n and the same non-zeros -- which is converted to CSR5 and multiplied
 // by the ordinary tile kernel (an internal child handle).  With XCD-contiguous tile ranges every XCD works on its
-// own slab(s): the eight L2s hold eight DIFFERENT parts of x.  P = A' x holds one partial per segment and
-//      y[r] = sum over the slabs k in mask[r] of P[ base[r / 64][k] + (number of rows < r in r's 64-block with bit k) ]
-// is applied by k_slab_combine (mask: S bits per row; base: S words per 64 rows).  Deterministic: partials are added
-// in slab order, no floating-point atomics.
+// own slab(s): the eight L2s hold eight DIFFERENT parts of x.  P = A' x holds one partial per segment, slab after slab
+// and row after row inside a slab, so the partials of slab k that belong to the 256 rows of a row block are ONE
+// contiguous run of P.  k_slab_combine gives every wavefront a row block: it streams the block's S runs (run bounds:
+// `base`, S words per block; the row of every partial inside its block: `rowidx`, one byte per segment) and adds them
+// into 256 accumulators in LDS, slab after slab.  Deterministic: partials are added in slab order, no floating-point
+// atomics; rows without non-zeros are not written (`nonempty`, one bit per row).
 //
 // Build (all on the device, reading the parent's tile-ordered column_index / value through the transpose map):
 //   k_slab_hist     workgroup / tile: slab histogram of the tile                       -> hist[slab][tile]
@@ -22,7 +24,9 @@
 //                   scatter of column, value and the 64-bit key (slab << 32 | row)
 //   segment starts  = positions where the key changes: counted per chunk, scanned, then written into row_ptr' by
 //                   ballot rank (k_slab_count_segments, k_slab_scan_counts, k_slab_emit_segments)
-//   k_slab_tables   thread / segment: mask bit (atomicOr) and the per-64-row base index
+//   k_slab_rowidx   thread / segment: row of the segment inside its 256-row block
+//   k_slab_base     thread / (row block, slab): first segment of the run (binary search on the sorted segment keys)
+//   k_slab_nonempty thread / row: one bit per row of the parent
 #include "csr5_internal.h"
 
 #include <rocprim/device/device_scan.hpp>
@@ -270,122 +274,135 @@ k_slab_emit_segments(int nnz, const unsigned long long *__restrict__ key, const 
     }
 }
 
-// one thread per segment s: mask bit of (row, slab); the first segment of a slab inside a 64-row block records its
-// index as the block's base for that slab
+// Row-block tables of the combine (COMBINE_ROWS rows per block = one wavefront of k_slab_combine).
+constexpr int COMBINE_ROWS = 256;
+
+// one thread per segment s: its row inside the row block (one byte); thread 0 also closes row_ptr'
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_slab_tables(int m2, int nnz, int S, const int32_t *__restrict__ row_ptr2, const unsigned long long *__restrict__ key,
-              uint32_t *__restrict__ mask, uint32_t *__restrict__ base, int32_t *__restrict__ row_ptr2_end)
+k_slab_rowidx(int m2, int nnz, const int32_t *__restrict__ row_ptr2, const unsigned long long *__restrict__ key,
+              unsigned char *__restrict__ rowidx, int32_t *__restrict__ row_ptr2_end)
 {
     const int s = blockIdx.x * SLAB_BLOCK + threadIdx.x;
     if (s == 0)
-        *row_ptr2_end = nnz; // row_ptr'[m'] (the select wrote the m' starts)
+        *row_ptr2_end = nnz; // row_ptr'[m'] (the segment pass wrote the m' starts)
     if (s >= m2)
         return;
-    const unsigned long long kv = key[row_ptr2[s]];
-    const uint32_t r = (uint32_t)kv, k = (uint32_t)(kv >> 32);
-    const unsigned long long bit = (unsigned long long)r * S + k;
-    atomicOr(&mask[bit >> 5], 1u << (bit & 31));
-    bool first = s == 0;
-    if (!first) {
-        const unsigned long long pv = key[row_ptr2[s - 1]];
-        first = (uint32_t)(pv >> 32) != k || ((uint32_t)pv >> 6) != (r >> 6);
-    }
-    if (first)
-        base[(size_t)(r >> 6) * S + k] = (uint32_t)s;
+    rowidx[s] = (unsigned char)((uint32_t)key[row_ptr2[s]] & (COMBINE_ROWS - 1));
 }
 
-// y[r] = sum of the partials of row r, in slab order.  One wavefront per COMBINE_BLOCKS consecutive 64-row blocks, one
-// thread per row of a block: the mask and base words of all its blocks are requested first, then the partials (one
-// block per wavefront was two short dependent round trips per wave: 262 k waves of them on R-MAT 24, 200 us).
-constexpr int COMBINE_BLOCKS = 4;
+// base[b * S + k] = first segment whose (slab, row block) is >= (k, b): the segments are sorted by (slab, row), so the
+// partials of (block b, slab k) are P[base[b][k] .. base[b + 1][k]); entry b = nblk of slab k is the first segment of
+// slab k + 1.  One thread per entry, a binary search each (no atomics, no serial gap filling).
+__global__ void __launch_bounds__(SLAB_BLOCK)
+k_slab_base(int m2, int S, int nblk, const int32_t *__restrict__ row_ptr2, const unsigned long long *__restrict__ key,
+            uint32_t *__restrict__ base)
+{
+    const long long e = (long long)blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    if (e >= (long long)(nblk + 1) * S)
+        return;
+    const int b = (int)(e / S), k = (int)(e % S);
+    const unsigned long long want = ((unsigned long long)k << 32) | ((unsigned long long)b * COMBINE_ROWS);
+    int lo = 0, hi = m2; // first segment with key >= want (a block index of nblk is beyond every row of slab k)
+    while (lo < hi) {
+        const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+        if (key[row_ptr2[mid]] < want)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    base[e] = (uint32_t)lo;
+}
 
+// one bit per row of the parent: the row owns a non-zero (rows without one are not written by SpMV)
+__global__ void __launch_bounds__(SLAB_BLOCK)
+k_slab_nonempty(int m, const int32_t *__restrict__ row_ptr, uint32_t *__restrict__ bits)
+{
+    const int r = blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    const bool on = r < m && row_ptr[r + 1] > row_ptr[r];
+    const unsigned long long b = __ballot(on);
+    const int lane = threadIdx.x & (OMEGA - 1);
+    if ((lane & 31) == 0 && r < m + 32)
+        bits[r >> 5] = (uint32_t)(b >> lane);
+}
+
+// y[r] = sum of the partials of row r.  One wavefront per COMBINE_ROWS consecutive rows.  First round trip: the block's
+// 2 S run bounds (one coalesced load) and its non-empty bits; then, round after round, the next 64 partials and row
+// bytes of EVERY run are requested together (lanes beyond a run's end re-read its last element: no branch, no extra
+// line) and added into the block's accumulators in LDS, slab after slab -- inside one wavefront the LDS operations are
+// ordered, inside a run every row occurs once, and masked lanes add into a dummy slot of their own, so the whole round
+// is straight-line code.  A row's partials are therefore added in the fixed order (round, slab): deterministic, no
+// floating-point atomics.  Most blocks need one round; a block whose 256 rows all own a segment in some slab needs four.
+// (Round 2 gave a wavefront 64 rows and fetched the partials row-wise: one 15 %-full load instruction per (block, slab),
+// 4.2 M of them on R-MAT 24, and 16 ballots per block to index them.)
 template <typename VT, int S>
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_slab_combine(int m, int tail_start, int zero_empty, const uint32_t *__restrict__ mask,
-               const uint32_t *__restrict__ base, const VT *__restrict__ P, int p_bytes, VT *__restrict__ y)
+k_slab_combine(int m, int tail_start, int zero_empty, int m2, const uint32_t *__restrict__ base,
+               const unsigned char *__restrict__ rowidx, const uint32_t *__restrict__ nonempty,
+               const VT *__restrict__ P, VT *__restrict__ y)
 {
-    const int lane = threadIdx.x & (OMEGA - 1);
-    const int wave = blockIdx.x * (SLAB_BLOCK / OMEGA) + (threadIdx.x >> 6);
-    const int r0 = wave * COMBINE_BLOCKS * OMEGA + lane;
-    unsigned long long mk[COMBINE_BLOCKS];
-    uint32_t bv[COMBINE_BLOCKS];
-    // every mask / base word of the wavefront's blocks in ONE round trip: unconditional loads at clamped addresses
-    // (a branch per block made the compiler wait for each block's words before it requested the next ones)
-    uint32_t w0[COMBINE_BLOCKS], w1[COMBINE_BLOCKS];
-    const int last_block = (m - 1) >> 6;
+    __shared__ VT acc_all[SLAB_BLOCK / OMEGA][COMBINE_ROWS + OMEGA]; // + one dummy slot per lane
+    const int lane = threadIdx.x & (OMEGA - 1), w = threadIdx.x >> 6;
+    const int blk = blockIdx.x * (SLAB_BLOCK / OMEGA) + w;
+    const int r0 = blk * COMBINE_ROWS;
+    if (r0 >= m)
+        return;
+    VT *acc = acc_all[w];
+    // run bounds of the block: words [blk * S, blk * S + 2 S) = this block's and the next block's starts
+    constexpr int BW = (2 * S + OMEGA - 1) / OMEGA;
+    uint32_t bw[BW];
 #pragma unroll
-    for (int b = 0; b < COMBINE_BLOCKS; b++) {
-        const int r = r0 + b * OMEGA;
-        const int rc = r < m ? r : m - 1;
-        if constexpr (S == 64) {
-            w0[b] = mask[2 * (size_t)rc];
-            w1[b] = mask[2 * (size_t)rc + 1];
-        } else {
-            w0[b] = mask[((unsigned long long)rc * S) >> 5];
-            w1[b] = 0;
-        }
-        const int blk = (r - lane) >> 6; // wave-uniform
-        bv[b] = base[(size_t)(blk < last_block ? blk : last_block) * S + (lane < S ? lane : 0)];
+    for (int i = 0; i < BW; i++) {
+        const int e = i * OMEGA + lane;
+        bw[i] = base[(size_t)blk * S + (e < 2 * S ? e : 0)];
     }
+    uint32_t ne[COMBINE_ROWS / OMEGA];
 #pragma unroll
-    for (int b = 0; b < COMBINE_BLOCKS; b++) {
-        const int r = r0 + b * OMEGA;
-        if constexpr (S == 64) {
-            mk[b] = (unsigned long long)w0[b] | ((unsigned long long)w1[b] << 32);
-        } else {
-            const uint32_t w = w0[b] >> (((unsigned long long)(r < m ? r : m - 1) * S) & 31);
-            mk[b] = S == 32 ? w : (w & ((1u << (S & 31)) - 1u));
+    for (int j = 0; j < COMBINE_ROWS / OMEGA; j++)
+        ne[j] = nonempty[(r0 >> 5) + 2 * j + (lane >> 5)];
+#pragma unroll
+    for (int j = 0; j < COMBINE_ROWS / OMEGA; j++)
+        acc[j * OMEGA + lane] = 0;
+    auto bound = [&](int e) -> int { return __builtin_amdgcn_readlane((int)bw[e / OMEGA], e % OMEGA); };
+    constexpr int G = S < 16 ? S : 16; // runs whose loads are in flight together
+    const unsigned dummy = COMBINE_ROWS + lane;
+#pragma unroll
+    for (int k0 = 0; k0 < S; k0 += G) {
+        int lo[G], len[G], longest = 0;
+#pragma unroll
+        for (int q = 0; q < G; q++) {
+            lo[q] = bound(k0 + q);
+            len[q] = bound(S + k0 + q) - lo[q];
+            longest = len[q] > longest ? len[q] : longest;
         }
-        if (r >= m)
-            mk[b] = 0;
-    }
-    // up to 32 partial loads in flight per lane: all slabs of GROUP blocks at once, no branch between them.
-    // Index arithmetic is the larger half of this kernel (ablation: 106 of 193 us on R-MAT 24), so it is kept to the
-    // minimum: one compare per (block, slab) whose result IS the ballot, v_mbcnt for the rank below the lane, one fused
-    // add-shift for the byte offset, and a raw buffer load whose inactive lanes carry the offset 0xFFFFFFFF -- the
-    // range check returns 0 for them without touching memory, so there is neither an exec-mask branch nor a select.
-    const auto pbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(P), (short)0, p_bytes, 0x00020000);
-    constexpr int GROUP = S >= 32 ? 1 : (32 / S < COMBINE_BLOCKS ? 32 / S : COMBINE_BLOCKS);
+        for (int off = 0; off < longest; off += OMEGA) {
+            VT part[G];
+            unsigned idx[G];
 #pragma unroll
-    for (int b0 = 0; b0 < COMBINE_BLOCKS; b0 += GROUP) {
-        VT part[GROUP][S];
+            for (int q = 0; q < G; q++) {
+                // element off + lane of run q, or -- beyond its end -- its last one (an empty run reads its neighbour's)
+                int j = off + lane < len[q] ? off + lane : len[q] - 1;
+                j += lo[q];
+                j = j < 0 ? 0 : (j < m2 ? j : m2 - 1);
+                part[q] = P[j];
+                idx[q] = rowidx[j];
+            }
 #pragma unroll
-        for (int g = 0; g < GROUP; g++) {
-#pragma unroll
-            for (int k = 0; k < S; k++) {
-                const bool bit = (mk[b0 + g] >> k) & 1ull;
-                const unsigned long long bl = __ballot(bit);
-                const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(bl >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bl, 0u));
-                const unsigned off = bit ? ((unsigned)__builtin_amdgcn_readlane((int)bv[b0 + g], k) + rank) * (unsigned)sizeof(VT)
-                                         : 0xFFFFFFFFu;
-#if defined(CSR5_COMBINE_ABLATE) && (CSR5_COMBINE_ABLATE & 1) // experiment build only: no partial loads
-                part[g][k] = (VT)off;
-#else
-                if constexpr (sizeof(VT) == 8)
-                    part[g][k] = __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b64(pbuf, off, 0, 0));
-                else
-                    part[g][k] = __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b32(pbuf, off, 0, 0));
-#endif
+            for (int q = 0; q < G; q++) {
+                const unsigned slot = off + lane < len[q] ? idx[q] : dummy;
+                acc[slot] += part[q];
             }
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int g = 0; g < GROUP; g++) {
-            const int r = r0 + (b0 + g) * OMEGA;
-            VT sum = 0;
-#pragma unroll
-            for (int k = 0; k < S; k++)
-                sum += part[g][k];
-#if defined(CSR5_COMBINE_ABLATE) && (CSR5_COMBINE_ABLATE & 2) // experiment build only: no y stores
-            asm volatile("" ::"v"(sum));
-            if (r < m && sum == (VT)-12345.678) {
-#else
-            if (r < m) {
-#endif
-                if (mk[b0 + g])
-                    y[r] = sum;
-                else if (zero_empty || r >= tail_start)
-                    y[r] = 0;
-            }
+    for (int j = 0; j < COMBINE_ROWS / OMEGA; j++) {
+        const int r = r0 + j * OMEGA + lane;
+        if (r < m) {
+            if ((ne[j] >> (lane & 31)) & 1u)
+                y[r] = acc[j * OMEGA + lane];
+            else if (zero_empty || r >= tail_start)
+                y[r] = 0;
         }
     }
 }
@@ -647,26 +664,32 @@ hipError_t slab_segments(int nnz, const unsigned long long *key2, const void *tm
     return hipGetLastError();
 }
 
-hipError_t slab_tables(int m2, int nnz, int S, int32_t *row_ptr2, const unsigned long long *key2, uint32_t *mask,
-                       uint32_t *base, hipStream_t s)
+// tables of the combine: row byte per segment, run starts per (row block, slab), non-empty bit per parent row
+size_t slab_base_words(int m, int S) { return ((size_t)(m + COMBINE_ROWS - 1) / COMBINE_ROWS + 2) * (size_t)S; }
+hipError_t slab_tables(int m, int m2, int nnz, int S, const int32_t *row_ptr, int32_t *row_ptr2, const unsigned long long *key2,
+                       unsigned char *rowidx, uint32_t *base, uint32_t *nonempty, hipStream_t s)
 {
-    const int blocks = ((m2 > 0 ? m2 : 1) + SLAB_BLOCK - 1) / SLAB_BLOCK;
-    hipLaunchKernelGGL(k_slab_tables, dim3(blocks), dim3(SLAB_BLOCK), 0, s, m2, nnz, S, row_ptr2, key2, mask, base,
-                       row_ptr2 + m2);
+    const int nblk = (m + COMBINE_ROWS - 1) / COMBINE_ROWS;
+    hipLaunchKernelGGL(k_slab_rowidx, dim3(((m2 > 0 ? m2 : 1) + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, s, m2, nnz,
+                       row_ptr2, key2, rowidx, row_ptr2 + m2);
+    const long long entries = (long long)(nblk + 1) * S;
+    hipLaunchKernelGGL(k_slab_base, dim3((unsigned)((entries + SLAB_BLOCK - 1) / SLAB_BLOCK)), dim3(SLAB_BLOCK), 0, s, m2, S, nblk,
+                       row_ptr2, key2, base);
+    hipLaunchKernelGGL(k_slab_nonempty, dim3((m + 32 + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, s, m, row_ptr, nonempty);
     return hipGetLastError();
 }
 
 template <typename VT>
-static hipError_t combine_typed(int m, int tail_start, int zero_empty, int S, const uint32_t *mask, const uint32_t *base,
-                                const void *P, int p_bytes, void *y, hipStream_t s)
+static hipError_t combine_typed(int m, int tail_start, int zero_empty, int S, int m2, const uint32_t *base,
+                                const unsigned char *rowidx, const uint32_t *nonempty, const void *P, void *y, hipStream_t s)
 {
-    const int rows_per_block = SLAB_BLOCK * COMBINE_BLOCKS;
+    const int rows_per_block = COMBINE_ROWS * (SLAB_BLOCK / OMEGA);
     const dim3 grid((m + rows_per_block - 1) / rows_per_block), block(SLAB_BLOCK);
     switch (S) {
 #define CSR5_SLAB_CASE(N)                                                                                              \
     case N:                                                                                                            \
-        hipLaunchKernelGGL((k_slab_combine<VT, N>), grid, block, 0, s, m, tail_start, zero_empty, mask, base,          \
-                           (const VT *)P, p_bytes, (VT *)y);                                                           \
+        hipLaunchKernelGGL((k_slab_combine<VT, N>), grid, block, 0, s, m, tail_start, zero_empty, m2, base, rowidx,    \
+                           nonempty, (const VT *)P, (VT *)y);                                                          \
         break;
         CSR5_SLAB_CASE(2) CSR5_SLAB_CASE(4) CSR5_SLAB_CASE(8) CSR5_SLAB_CASE(16) CSR5_SLAB_CASE(32) CSR5_SLAB_CASE(64)
 #undef CSR5_SLAB_CASE
@@ -675,17 +698,14 @@ static hipError_t combine_typed(int m, int tail_start, int zero_empty, int S, co
     return hipGetLastError();
 }
 
-hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int value_type, const uint32_t *mask,
-                               const uint32_t *base, const void *P, int segments, void *y, hipStream_t s)
+hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int value_type, const uint32_t *base,
+                               const unsigned char *rowidx, const uint32_t *nonempty, const void *P, int segments, void *y,
+                               hipStream_t s)
 {
-    if (m <= 0)
+    if (m <= 0 || segments <= 0)
         return hipSuccess;
-    // P is read through a raw buffer (32-bit byte offsets, int record count): build_slabs keeps it below 2 GiB
-    const long long bytes = (long long)segments * (value_type == CSR5HIP_F64 ? 8 : 4);
-    if (bytes > 0x7FFFFFFFLL)
-        return hipErrorInvalidValue;
-    return value_type == CSR5HIP_F64 ? combine_typed<double>(m, tail_start, zero_empty, S, mask, base, P, (int)bytes, y, s)
-                                     : combine_typed<float>(m, tail_start, zero_empty, S, mask, base, P, (int)bytes, y, s);
+    return value_type == CSR5HIP_F64 ? combine_typed<double>(m, tail_start, zero_empty, S, segments, base, rowidx, nonempty, P, y, s)
+                                     : combine_typed<float>(m, tail_start, zero_empty, S, segments, base, rowidx, nonempty, P, y, s);
 }
 
 } // namespace csr5

@@ -25,108 +25,11 @@
 // value is consumed (two memory round trips per tile); column_index/value loads are fully coalesced
 // 256-B / 512-B wave accesses thanks to the tile transpose.
 #include "csr5_internal.h"
+#include "csr5_wave.h"
 
 #include <type_traits>
 
 namespace csr5 {
-
-// Optional per-wave timestamp probe (built only into libcsr5hip_timing.so by `make timing`; never in
-// the product library): slot k of tile t receives the 100 MHz wall clock at stage k.
-#ifdef CSR5_TIMING_PROBE
-__device__ unsigned long long *csr5_timing_buf = nullptr;
-#define CSR5_TSTAMP(tile, k)                                                                       \
-    do {                                                                                           \
-        if (csr5_timing_buf && (threadIdx.x & 63) == 0)                                            \
-            csr5_timing_buf[(size_t)(tile) * 8 + (k)] = wall_clock64();                            \
-    } while (0)
-extern "C" int csr5hip_debug_set_timing_buffer(void *dptr)
-{
-    return (int)hipMemcpyToSymbol(HIP_SYMBOL(csr5_timing_buf), &dptr, sizeof(dptr));
-}
-#else
-#define CSR5_TSTAMP(tile, k) do { } while (0)
-#endif
-
-// ---- cross-lane helpers on DPP (data-parallel primitives: lane moves folded into VALU operands, no LDS
-//      crossbar round trip as with ds_bpermute).  A 64-bit value moves as two 32-bit halves. -------------
-// Full row/bank masks: bound_ctrl makes source lanes outside the row / wave read 0 and leaves no "old"
-// operand to initialise (2 VALU less per 64-bit move).  Partial masks: masked lanes keep old = 0.
-template <int CTRL, int ROW_MASK_ = 0xF, int BANK_MASK_ = 0xF>
-__device__ __forceinline__ int dpp_word(int w)
-{
-    constexpr bool FULL = ROW_MASK_ == 0xF && BANK_MASK_ == 0xF;
-    return __builtin_amdgcn_update_dpp(0, w, CTRL, ROW_MASK_, BANK_MASK_, FULL);
-}
-template <int CTRL, int ROW_MASK_ = 0xF, int BANK_MASK_ = 0xF>
-__device__ __forceinline__ float dpp_move(float v)
-{
-    return __builtin_bit_cast(float, dpp_word<CTRL, ROW_MASK_, BANK_MASK_>(__builtin_bit_cast(int, v)));
-}
-template <int CTRL, int ROW_MASK_ = 0xF, int BANK_MASK_ = 0xF>
-__device__ __forceinline__ double dpp_move(double v)
-{
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-    const int lo = dpp_word<CTRL, ROW_MASK_, BANK_MASK_>((int)(unsigned)b);
-    const int hi = dpp_word<CTRL, ROW_MASK_, BANK_MASK_>((int)(unsigned)(b >> 32));
-    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-// lanes masked off by row/bank masks or shifted in from outside a row read 0 (old = 0, bound_ctrl off)
-constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
-constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHL8 = 0x108;
-constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHL1 = 0x130;
-
-// value of lane `src` (wave-uniform index) in every lane: v_readlane, no LDS crossbar trip
-template <typename VT>
-__device__ __forceinline__ VT bcast_lane(VT v, int src)
-{
-    if constexpr (sizeof(VT) == 8) {
-        const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
-        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), src);
-        return __builtin_bit_cast(VT, ((unsigned long long)hi << 32) | lo);
-    } else {
-        return __builtin_bit_cast(VT, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
-    }
-}
-
-// sum over the 64 lanes, result in every lane (6 DPP steps + one readlane broadcast).  Only lane 63 has
-// to end up right, so the two row broadcasts run with full row masks as well: rows that receive a value
-// they should not are never read again.
-template <typename VT>
-__device__ __forceinline__ VT wave_sum(VT v)
-{
-    v += dpp_move<DPP_ROW_SHR1>(v);                 // pairs
-    v += dpp_move<DPP_ROW_SHR2>(v);                 // quads
-    v += dpp_move<DPP_ROW_SHR4>(v);                 // 8
-    v += dpp_move<DPP_ROW_SHR8>(v);                 // lane 15 of every row holds the row sum
-    v += dpp_move<DPP_ROW_BCAST15>(v);              // lane 16r+15 += total of row r-1
-    v += dpp_move<DPP_ROW_BCAST31>(v);              // rows 2,3 += lane 31 -> lane 63 = wave sum
-    return bcast_lane(v, OMEGA - 1);
-}
-// sum over lanes 0..count-1 of a value that is ZERO in every other lane (count wave-uniform, 1..64)
-template <typename VT>
-__device__ __forceinline__ VT head_sum(VT v, int count)
-{
-    if (count <= 4) {
-        v += dpp_move<DPP_ROW_SHR1>(v);
-        v += dpp_move<DPP_ROW_SHR2>(v);
-        return bcast_lane(v, 3);
-    }
-    if (count <= 16) {
-        v += dpp_move<DPP_ROW_SHR1>(v);
-        v += dpp_move<DPP_ROW_SHR2>(v);
-        v += dpp_move<DPP_ROW_SHR4>(v);
-        v += dpp_move<DPP_ROW_SHR8>(v);
-        return bcast_lane(v, 15);
-    }
-    return wave_sum(v);
-}
-// value of lane l+1 (lane 63 receives 0)
-template <typename VT>
-__device__ __forceinline__ VT lane_above(VT v)
-{
-    return dpp_move<DPP_WAVE_SHL1>(v);
-}
 
 // ---- fused-mode carry protocol ------------------------------------------------------------------
 // Slot h (= first tile of a run of tiles that begin inside the same row r) collects every partial of
@@ -198,10 +101,6 @@ __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, VT *calibra
                                              const uint32_t *tile_ptr, int slot, uint32_t meta_x,
                                              int my_tile, bool is_closing, VT v, VT *y)
 {
-#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 8)
-    asm volatile("" ::"v"(v), "s"(slot));
-    return;
-#endif
     using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
     const uint32_t expected = meta_x & 0x00FFFFFFu;
     VT *row_y = y + (tile_ptr[slot] & ROW_MASK);
@@ -355,24 +254,15 @@ __device__ __forceinline__ void tail_rows(const Geometry &g, const int32_t *__re
 // SIGMA > 0: compile-time sigma (loads hoisted into registers, flag walk fully unrolled).
 // SIGMA == 0: run-time sigma (any 1..32), same code shape, used for sigma < 4 and as a cross-check.
 // One tile, one wavefront.  `wave_lds` = this wavefront's private LDS region (x-window / y segments).
-// HOT (column-slab child only, csr5_slab.hip): column words with bit 31 set index the workgroup's LDS table of hot
-// x entries (`hot`) instead of x itself.
-template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT, bool HOT>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT>
 __device__ __forceinline__ void
 tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restrict__ col, const VT *__restrict__ val,
           const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc,
           const int32_t *__restrict__ offset_ptr, const int32_t *__restrict__ offset, VT *__restrict__ calibrator,
           VT *__restrict__ y, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta, const uint32_t *__restrict__ hdr,
-          char *wave_lds, const __attribute__((address_space(3))) VT *hot)
+          char *wave_lds)
 {
-    // one x gather: from the LDS hot table when the column word carries bit 31 (HOT), else from memory
-    auto gather = [&](int32_t cw) -> VT {
-        if constexpr (HOT)
-            return cw < 0 ? hot[cw & 0x7FFFFFFF] : x[(uint32_t)cw];
-        else
-            return x[(uint32_t)cw];
-    };
-    CSR5_TSTAMP(t, 0);
+    auto gather = [&](int32_t cw) -> VT { return x[(uint32_t)cw]; };
     const int sigma = SIGMA > 0 ? SIGMA : g.sigma;
     const int bit_y = SIGMA > 0 ? bit_y_of(SIGMA > 0 ? SIGMA : 1) : g.bit_y;
     const int bit_all = bit_y + BIT_SS;
@@ -416,9 +306,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         const size_t nb = (size_t)(t + 1) * T;
         size_t pos = (t + 1 == g.p - 1) ? nb + lane : nb + (size_t)(lane % sigma) * OMEGA + lane / sigma;
         spill_pos = pos < (size_t)g.nnz ? pos : (size_t)g.nnz - 1;
-#if !(defined(CSR5_ABLATE) && (CSR5_ABLATE & 32))
         spill_c = col[spill_pos];
-#endif
     }
     constexpr int NREG = SIGMA > 0 ? SIGMA : 1;
     int32_t c[NREG];
@@ -438,10 +326,8 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     const uint32_t w0 = d[lane];
     const uint32_t w1 = num_packet > 1 ? d[OMEGA + lane] : 0u;
     if constexpr (FUSED) {
-#if !(defined(CSR5_ABLATE) && (CSR5_ABLATE & 32))
         spill_v = val[spill_pos];
-#endif
-        if constexpr (SIGMA > 0 && !HOT)
+        if constexpr (SIGMA > 0)
             __builtin_amdgcn_sched_barrier(0); // keep it AHEAD of the value stream (see the pin below)
     }
 
@@ -464,7 +350,6 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         }
         // everything above is in flight before anything below consumes a loaded value
         __builtin_amdgcn_sched_barrier(0);
-        CSR5_TSTAMP(t, 1);
         if constexpr (FUSED) {
             mt = make_uint4(__builtin_amdgcn_readlane(hw, 0), __builtin_amdgcn_readlane(hw, 1),
                             __builtin_amdgcn_readlane(hw, 2), __builtin_amdgcn_readlane(hw, 3));
@@ -475,9 +360,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             // optimiser otherwise sinks them below that test (behind the header's arrival: a third dependent round
             // trip for every tile with a short spill).  Costs nothing: vector loads return in order and these two
             // were requested right after the column words the gathers below wait for anyway.
-            // (The persistent hot kernel keeps them up front by itself and runs 3-7 % slower with the pin: measured.)
-            if constexpr (!HOT)
-                asm volatile("" : "+v"(spill_c), "+v"(spill_v));
+            asm volatile("" : "+v"(spill_c), "+v"(spill_v));
         }
         VT xv[NREG];
         if constexpr (XWIN) {
@@ -508,54 +391,12 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
                 for (int i = 0; i < SIGMA; i++)
                     xv[i] = x[(uint32_t)c[i]];
             }
-        } else if constexpr (!HOT) {
+        } else {
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
-#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 1)
-                xv[i] = (VT)c[i]; // experiment build only: no x gather
-#else
                 xv[i] = gather(c[i]);
-#endif
         }
-        if constexpr (HOT) {
-            // Branch-free hot/cold gather.  Cold lanes (plain column word) read x through a raw buffer load; hot lanes
-            // (bit 31 set) get the byte offset 0xFFFFFFFF there, which the buffer's range check turns into "return 0,
-            // touch no memory".  Every lane then reads the LDS table: hot lanes their slot, cold lanes slot 0, which
-            // always holds +0.0 (reserved at conversion).  One of the two words is therefore all-zero bits and a
-            // bitwise OR merges them exactly (no select, no control flow: exec-masked branches per element made the
-            // compiler drain the vector memory counter in front of every table read).
-            const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(x), (short)0, g.n * (int)sizeof(VT), 0x00020000);
-            using word_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
-            word_t xg[SIGMA], sg = 0;
-            auto cold_word = [&](int32_t cw) -> word_t {
-                const unsigned off = cw < 0 ? 0xFFFFFFFFu : (unsigned)cw * (unsigned)sizeof(VT);
-                if constexpr (sizeof(VT) == 8)
-                    return __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
-                else
-                    return __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b32(xbuf, off, 0, 0));
-            };
-            auto table_word = [&](int32_t cw) -> word_t {
-                return __builtin_bit_cast(word_t, hot[cw < 0 ? (unsigned)cw & 0x7FFFFFFFu : 0u]);
-            };
-#pragma unroll
-            for (int i = 0; i < SIGMA; i++)
-                xg[i] = cold_word(c[i]);
-            // the short-spill gather of tile t+1's first elements rides in the same batch, the same way (lanes
-            // beyond the spill length read column 0: one line)
-            const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
-            const int32_t scw = lane < L ? spill_c : 0;
-            if constexpr (FUSED)
-                sg = cold_word(scw);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < SIGMA; i++)
-                xv[i] = __builtin_bit_cast(VT, (word_t)(xg[i] | table_word(c[i])));
-            if constexpr (FUSED) {
-                const VT sx = __builtin_bit_cast(VT, (word_t)(sg | table_word(scw)));
-                lead_next = lane < L ? spill_v * sx : (VT)0;
-            }
-        }
-        if constexpr (FUSED && !HOT) {
+        if constexpr (FUSED) {
             // the closing row of this tile spills mt.z <= 64 elements into tile t+1 and ends there:
             // gather x for exactly those lanes; the other lanes re-read x[0] (one cache line), so the
             // gather is unconditional and rides in the same round trip as the tile's own gathers
@@ -564,16 +405,11 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             lead_next = lane < L ? spill_v * sx : (VT)0;
         }
         __builtin_amdgcn_sched_barrier(0);
-        CSR5_TSTAMP(t, 2);
 #pragma unroll
         for (int i = 0; i < SIGMA; i++) {
             mv[i] = v[i];
             mx[i] = xv[i];
         }
-#ifdef CSR5_TIMING_PROBE
-        asm volatile("" ::"v"(mx[SIGMA - 1]), "v"(lead_next));
-        CSR5_TSTAMP(t, 3);
-#endif
     } else if constexpr (FUSED) {
         mt = make_uint4(__builtin_amdgcn_readlane(hw, 0), __builtin_amdgcn_readlane(hw, 1),
                         __builtin_amdgcn_readlane(hw, 2), __builtin_amdgcn_readlane(hw, 3));
@@ -634,12 +470,11 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         return;
     }
 
-    const bool empty_rows = HOT ? false : (bool)(rs_raw >> 31); // (a slab child has no empty rows)
+    const bool empty_rows = (bool)(rs_raw >> 31);
     const int row_start = (int)(rs_raw & ROW_MASK);
     VT *y_local = y + row_start + 1;
     const int32_t *off_local = empty_rows ? offset + offset_ptr[t] : nullptr;
 
-    CSR5_TSTAMP(t, 4);
     constexpr bool LDSY = use_ldsy<VT, SIGMA, LDSY_REQ>();
     VT *seg = reinterpret_cast<VT *>(wave_lds);
     // store of the segment that owns slot `idx` of this tile's row range
@@ -657,11 +492,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     for (int i = 1; i < sigma; i++) {
         if ((flags >> (31 - i)) & 1u) {
             if (direct) {
-#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 2)
-                asm volatile("" ::"v"(sum), "v"(y_off)); // experiment build only: no y store
-#else
                 put(y_off, sum);
-#endif
                 stored_hi = y_off + 1;
             } else {
                 first_sum = sum;
@@ -678,7 +509,6 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     // cross-lane step: every lane that owns a flag adds the leading partials of the lanes behind it,
     // up to and including the next lane that owns a flag:  S[l] = R[l+1],
     // R[j] = lead[j] + (present[j] ? 0 : R[j+1])  -- backward segmented scan, 6 shuffle steps.
-    CSR5_TSTAMP(t, 5);
     VT R = f0 ? (VT)0 : first_sum;
     // All on DPP / readlane (a ds_bpermute shuffle costs an LDS round trip per step): 4 in-row steps
     // (row_shl reads 0 across a 16-lane row edge), then the three row edges top-down: the lanes whose
@@ -723,7 +553,6 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     if (present)
         sum += S;
 
-    CSR5_TSTAMP(t, 6);
     const int last_present = 63 - __builtin_clzll(pmask);
     bool closing_to_protocol = false; // this lane's last segment goes to the arrival protocol
     if constexpr (FUSED) {
@@ -734,11 +563,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         closing_to_protocol = direct && close_carry && !close_local && lane == last_present;
     }
     if (direct && !closing_to_protocol) {
-#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 16)
-        asm volatile("" ::"v"(sum), "v"(y_off));
-#else
         put(y_off, sum);
-#endif
         stored_hi = y_off + 1;
     }
     if constexpr (LDSY) {
@@ -752,13 +577,11 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             // Two loops, not one with a select: the offset load would sit in the loop of every tile, and a store
             // whose address depends on a load makes the compiler drain the vector-memory counter -- i.e. the previous
             // iteration's STORE -- before it issues the next one (one store round trip per 64 segments).
-            if constexpr (!HOT) { // (a slab child has no empty rows)
-                if (empty_rows) {
-                    for (int j = lane; j < nseg; j += OMEGA)
-                        y_local[off_local[j]] = seg[j];
-                }
+            if (empty_rows) {
+                for (int j = lane; j < nseg; j += OMEGA)
+                    y_local[off_local[j]] = seg[j];
             }
-            if (HOT || !empty_rows) {
+            if (!empty_rows) {
                 for (int j = lane; j < nseg; j += OMEGA)
                     y_local[j] = seg[j];
             }
@@ -777,7 +600,6 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         if (lane == 0)
             calibrator[t] = direct ? first_sum : sum;
     }
-    CSR5_TSTAMP(t, 7);
 }
 
 // One tile per wavefront, WAVES_PER_BLOCK tiles per workgroup; the CSR tail = extra workgroups of the same grid.
@@ -800,9 +622,6 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int blk = blockIdx.x;
     if (blk >= tile_blocks) {
-#if defined(CSR5_ABLATE) && (CSR5_ABLATE & 4)
-        return;
-#endif
         tail_rows<VT, SIGMA, FUSED>(g, row_ptr, col, val, x, calibrator, y, blk - tile_blocks, acc, cnt,
                              meta, tile_ptr, reinterpret_cast<VT *>(smem));
         return;
@@ -818,87 +637,9 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     const int t = __builtin_amdgcn_readfirstlane(blk * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6));
     if (t >= g.p - 1)
         return;
-    tile_body<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, false>(
+    tile_body<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT>(
         g, t, lane, col, val, x, tile_ptr, tile_desc, offset_ptr, offset, calibrator, y, acc, cnt, meta, hdr,
-        smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>(), nullptr);
-}
-
-// ---- persistent hot-set kernel (column-slab child, csr5_slab.hip) --------------------------------------------------
-// One 1024-thread workgroup per CU stays resident for the whole SpMV.  XCD x (= workgroup index % 8, observed
-// placement, used for locality only) walks its `rounds` slabs in order; for every slab the workgroup first stages the
-// slab's hot x entries -- the columns that carry most of the slab's non-zeros, chosen at conversion -- into a
-// 128-KB LDS table, then its 16 wavefronts take the slab's tiles round robin (tiles have equal work by construction,
-// so a static split balances).  Hot gathers become ds_read_b64 (a few cycles per wave instruction instead of a
-// 128-byte L2->L1 line per lane); only the cold remainder goes through the vector memory path.
-// Correct under ANY placement or scheduling: the table only depends on the slab, every tile is processed by exactly
-// one wavefront, and the carry protocol never waits.
-// (Tried and dropped: a software pipeline with the NEXT tile's column / value / descriptor loads in flight during the
-// current tile's computation -- 128 VGPRs, same time to the microsecond on R-MAT 22 and 24: the kernel is bound by the
-// bytes it moves, 4.1-4.6 TB/s, not by per-wave latency.)
-struct HotParams {
-    int slabs, rounds, capacity;     // S, S / 8, table capacity in elements
-    const int32_t *cols;             // [slabs * capacity] hot column of every table slot
-    const int32_t *count;            // [slabs] slots in use
-    const int32_t *tile0;            // [slabs + 1] first tile owned by each slab (tile0[S] = p - 1); behind it [slabs]: the slabs of
-                                     // XCD 0 (one per round), of XCD 1, ... (dealt by size at conversion)
-};
-constexpr int HOT_BLOCK = 1024;
-
-// LDSY: when a tile's segment buffer fits HOT_WAVE_LDS bytes (fp64: sigma <= 8, fp32: sigma <= 16) every wavefront also
-// gets its own y-compaction region behind the table (coalesced stores of the partial sums: 6-9 % on R-MAT, whose
-// slab rows hold 4-9 non-zeros); the table then has (160 KB - 16 * 4 KB) / sizeof(vT) slots.
-template <typename VT, int SIGMA>
-constexpr bool hot_ldsy() { return (size_t)OMEGA * SIGMA * sizeof(VT) <= (size_t)HOT_WAVE_LDS; }
-
-template <typename VT, int SIGMA, bool NT>
-__global__ void __launch_bounds__(HOT_BLOCK)
-k_spmv_hot(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__ val, const VT *__restrict__ x,
-           const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc,
-           const int32_t *__restrict__ offset_ptr, const int32_t *__restrict__ offset, VT *__restrict__ calibrator,
-           VT *__restrict__ y, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta, const uint32_t *__restrict__ hdr,
-           HotParams hp)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // typed LDS pointer: keeps the table reads on ds_read (a generic pointer would merge the hot/cold select into one
-    // flat_load)
-    auto *hot = (__attribute__((address_space(3))) VT *)(smem);
-    constexpr bool LY = hot_ldsy<VT, SIGMA>();
-    const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, nwg = gridDim.x / NUM_XCD;
-    const int lane = threadIdx.x & (OMEGA - 1), wave = threadIdx.x >> 6;
-    constexpr int WAVES = HOT_BLOCK / OMEGA;
-    char *wave_lds = LY ? smem + (size_t)hp.capacity * sizeof(VT) + (size_t)wave * HOT_WAVE_LDS : nullptr;
-    for (int r = 0; r < hp.rounds; r++) {
-        const int k = hp.tile0[hp.slabs + 1 + xcd * hp.rounds + r];
-        const int nhot = hp.count[k];
-        const int32_t *hc = hp.cols + (size_t)k * hp.capacity;
-        __syncthreads(); // every wavefront is done with the previous slab's table
-        // Refill in batches of 16 slots per thread: all column words first (coalesced), then all gathers, then the
-        // LDS writes -- two memory round trips per batch instead of two dependent ones per slot.
-        for (int j0 = 0; j0 < nhot; j0 += HOT_BLOCK * 16) {
-            int32_t cw[16];
-            VT xw[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
-                cw[q] = j < nhot ? hc[j] : 0;
-            }
-#pragma unroll
-            for (int q = 0; q < 16; q++)
-                xw[q] = x[(uint32_t)cw[q]];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
-                if (j < nhot)
-                    hot[j] = j ? xw[q] : (VT)0; // slot 0 = +0.0: what the cold lanes read (tile_body)
-            }
-        }
-        __syncthreads();
-        const int t1 = hp.tile0[k + 1];
-        for (int t = hp.tile0[k] + wg * WAVES + wave; t < t1; t += nwg * WAVES)
-            tile_body<VT, SIGMA, true, false, LY, NT, true>(g, __builtin_amdgcn_readfirstlane(t), lane, col, val, x,
-                                                            tile_ptr, tile_desc, offset_ptr, offset, calibrator, y, acc,
-                                                            cnt, meta, hdr, wave_lds, hot);
-    }
+        smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>());
 }
 
 // ---- carry resolution by a second launch ---------------------------------------------------------
@@ -983,46 +724,6 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
     return hipGetLastError();
 }
 
-// hot child: persistent tile kernel, then the CSR tail (the ordinary kernel with zero tile workgroups), then -- only
-// for matrices with such rows -- the long-run calibrate
-template <typename VT, int SIGMA, bool NT>
-static hipError_t launch_hot(const Geometry &g, const DeviceArrays &d, const void *x, void *y, const SpmvOptions &opt,
-                             hipStream_t s)
-{
-    HotParams hp{d.hot_slabs, d.hot_slabs / NUM_XCD, d.hot_capacity, d.hot_cols, d.hot_count, d.hot_tile0};
-    const size_t lds = (size_t)d.hot_capacity * sizeof(VT) + (hot_ldsy<VT, SIGMA>() ? (size_t)(HOT_BLOCK / OMEGA) * HOT_WAVE_LDS : 0);
-    auto kern = k_spmv_hot<VT, SIGMA, NT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess)
-        return e;
-    if (g.p > 1) {
-        hipLaunchKernelGGL(kern, dim3(NUM_XCD * 32), dim3(HOT_BLOCK), lds, s, g, d.col, (const VT *)d.val, (const VT *)x,
-                           d.tile_ptr, d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y,
-                           (VT *)d.carry_acc, d.carry_cnt, reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr, hp);
-        e = hipGetLastError();
-        if (e != hipSuccess)
-            return e;
-    }
-    const int tail_rows_n = g.m - g.tail_start;
-    const int tail_blocks = tail_rows_n > 0 ? (tail_rows_n + BLOCK - 1) / BLOCK : 0;
-    if (tail_blocks > 0) {
-        hipLaunchKernelGGL((k_spmv<VT, SIGMA, true, false, false, NT>), dim3(tail_blocks), dim3(BLOCK),
-                           (size_t)g.tile_elems * sizeof(VT), s, g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x,
-                           d.tile_ptr, d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, 0, 0,
-                           (VT *)d.carry_acc, d.carry_cnt, reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr);
-        e = hipGetLastError();
-        if (e != hipSuccess)
-            return e;
-    }
-    if (!opt.long_runs)
-        return hipSuccess;
-    hipLaunchKernelGGL((k_calibrate<VT, true>), dim3((g.p + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, g, d.tile_ptr,
-                       reinterpret_cast<const uint4 *>(d.carry_meta), (const VT *)d.calibrator, (const VT *)d.carry_acc,
-                       (VT *)y);
-    return hipGetLastError();
-}
-
 template <typename VT, bool FUSED>
 static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
                                const SpmvOptions &opt, hipStream_t s)
@@ -1031,13 +732,6 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
 #define CSR5_CASE(S)                                                                               \
     case S:                                                                                        \
         if constexpr (FUSED) {                                                                     \
-            if (opt.hot) {                                                                         \
-                if constexpr (hot_ldsy<VT, S>()) /* a hot child is converted at sigma <= 8 (fp64) / 16 (fp32) */ \
-                    return opt.stream_nt ? launch_hot<VT, S, true>(g, d, x, y, opt, s)             \
-                                         : launch_hot<VT, S, false>(g, d, x, y, opt, s);           \
-                else                                                                               \
-                    return hipErrorInvalidValue;                                                   \
-            }                                                                                      \
             if (opt.x_window)                                                                      \
                 return opt.lds_y ? launch_one<VT, S, FUSED, true, true>(g, d, x, y, opt, s)        \
                                  : launch_one<VT, S, FUSED, true, false>(g, d, x, y, opt, s);      \
@@ -1045,11 +739,9 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
                 return opt.lds_y ? launch_one<VT, S, FUSED, false, true, true>(g, d, x, y, opt, s) \
                                  : launch_one<VT, S, FUSED, false, false, true>(g, d, x, y, opt, s); \
         }                                                                                          \
-        if (opt.hot) /* hot-encoded column words are only understood by the fused persistent kernel */ \
-            return hipErrorInvalidValue;                                                           \
         return opt.lds_y ? launch_one<VT, S, FUSED, false, true>(g, d, x, y, opt, s)               \
                          : launch_one<VT, S, FUSED, false, false>(g, d, x, y, opt, s);
-#if defined(CSR5_ABLATE) || defined(CSR5_FEW_SIGMAS) // experiment builds: few instantiations only
+#if defined(CSR5_FEW_SIGMAS) // experiment builds: few instantiations only
         CSR5_CASE(4) CSR5_CASE(5) CSR5_CASE(8) CSR5_CASE(12) CSR5_CASE(16) CSR5_CASE(20) CSR5_CASE(32)
 #else
         CSR5_CASE(4) CSR5_CASE(5) CSR5_CASE(6) CSR5_CASE(7) CSR5_CASE(8) CSR5_CASE(9) CSR5_CASE(10)
@@ -1059,7 +751,7 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
         CSR5_CASE(29) CSR5_CASE(30) CSR5_CASE(31) CSR5_CASE(32)
 #endif
 #undef CSR5_CASE
-    default: return opt.hot ? hipErrorInvalidValue : launch_one<VT, 0, FUSED, false, false>(g, d, x, y, opt, s);
+    default: return launch_one<VT, 0, FUSED, false, false>(g, d, x, y, opt, s);
     }
 }
 
@@ -1091,6 +783,8 @@ hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type,
 {
     if (g.p <= 0)
         return hipSuccess;
+    if (opt.hot) // column words are hot-encoded: only the persistent range kernel understands them (csr5_hot.hip)
+        return opt.mode == 1 ? launch_spmv_hot(g, d, value_type, x, y, opt, s) : hipErrorInvalidValue;
     return value_type == CSR5HIP_F64 ? launch_spmv_f64(g, d, x, y, opt, s) : launch_spmv_f32(g, d, x, y, opt, s);
 }
 #endif

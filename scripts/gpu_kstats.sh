@@ -8,6 +8,6 @@ python3 - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/ks/**/*kernel_stats.csv', recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    if any(k in r['Name'] for k in ('k_spmv', 'k_slab_combine', 'k_calibrate')):
+    if any(k in r['Name'] for k in ('k_spmv', 'k_slab_combine', 'k_calibrate', 'k_range')):
         print(f"   {r['Name'].split('(')[0][:70]:70s} calls={r['Calls']:>5s} avg={float(r['AverageNs'])/1e3:9.2f} us")
 PY

@@ -205,10 +205,14 @@ def test_slab_hot_real_data_and_auto(oracle):
     _, _, _, y_hot = _run(mat, val, x, 16, H.SPMV_FUSED, slabs=8, hot=1, info_out=info)
     assert info["slab_hot"] == 1 and info["slab_hot_cover_pct"] >= 60, info
     assert info["slab_sigma"] == 8, "the hot child is converted at sigma <= 8 (room for the y-compaction regions in LDS)"
-    # same stacked matrix at the same child sigma without the table: the very same additions in the same order
+    # same stacked matrix at the same child sigma without the table: the same partial sums per (row, slab) up to the
+    # association of the additions at tile seams (the range kernel adds a row's pieces in tile order inside one
+    # wavefront, the one-tile kernel through its carry protocol); run to run the hot path is bit-reproducible
     _, _, _, y_plain = _run(mat, val, x, 8, H.SPMV_FUSED, slabs=8, hot=0)
+    _, _, _, y_again = _run(mat, val, x, 16, H.SPMV_FUSED, slabs=8, hot=1)
     nonempty = np.diff(mat.row_ptr) > 0  # (which EMPTY rows get a 0 depends on the parent's tail start, i.e. on its sigma)
-    assert np.array_equal(y_hot[0][nonempty], y_plain[0][nonempty])
+    assert np.array_equal(y_hot[0][nonempty], y_again[0][nonempty])
+    assert np.all(np.abs(y_hot[0] - y_plain[0])[nonempty] <= 1e-13 * np.maximum(scale, 1.0)[nonempty])
     assert np.all(np.abs(y_hot[0] - exp) <= 1e-12 * np.maximum(scale, 1.0))
     flat = M.webbase_like(scale=0.3)
     val, x = M.fill_values(flat.nnz, flat.n, np.float64, seed=9, mode="int")
