@@ -90,6 +90,8 @@ def parse_args():
     ap.add_argument("--slabs", default="auto", help="column slabs: auto (default), 0 = off, 2..64 = that many")
     ap.add_argument("--slab-shift", type=int, default=None)
     ap.add_argument("--slab-hot", default="auto", choices=["auto", "off", "force"], help="LDS hot table of the slab kernel")
+    ap.add_argument("--zero-empty", type=int, default=0, choices=[0, 1],
+                    help="1 = rows without non-zeros are written as 0 (CSR5HIP_OPT_ZERO_EMPTY_ROWS; the coupled-iteration setting)")
     ap.add_argument("--scaling", default=None, choices=[None, "weak", "strong"],
                     help="N > 1: strong (default for R-MAT) = ONE global matrix cut into cost-balanced (nnz + 2 * rows) row blocks; "
                          "weak = one fixed-size row block per GPU")
@@ -186,6 +188,8 @@ class Problem:
         if args.slab_shift is not None:
             _ck(A.setSlabShift(args.slab_shift), "setSlabShift")
         _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
+        if getattr(args, "zero_empty", 0):
+            _ck(A.setZeroEmptyRows(1), "setZeroEmptyRows")
         A.warmup()
         torch.cuda.synchronize()
         if tuned:  # setup, outside every timed region (like asCSR5)
@@ -281,7 +285,7 @@ def roofline_dict(prob, ev_ms_per_step, wall_ms_per_step, extra=None):
         "clock": "HIP events on the launch stream around the K timed steps (frac_wall: the same from the wall clock)",
         "frac_wall": round(prob.b_alg / (wall_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "traffic": None,
-        "kernel": ("csr5::k_spmv_hot" if info.slab_hot else "csr5::k_spmv") +
+        "kernel": ("csr5::k_spmv_range" if info.slab_hot else "csr5::k_spmv") +
                   (" + csr5::k_slab_combine (both inside the step time)" if info.column_slabs else ""),
         "algorithmic_bytes_per_launch": prob.b_alg,
         # diagnostic: bytes the CSR5 kernel actually streams = B_alg with row_ptr replaced by

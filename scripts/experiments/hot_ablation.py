@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Experiment-only: build variants of libcsr5hip whose range kernel (csr5_hot.hip) has one piece of work removed, by
+patching a TEMPORARY COPY of the product source (the product file carries no ablation switches).  Results of these
+builds are wrong by design; they only answer "what does this piece cost".
+
+    python scripts/experiments/hot_ablation.py            # builds scripts/probes/libcsr5hip_abl_<name>.so for every variant
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SRC = os.path.join(ROOT, "benchmark_spmv_using_csr5_amd", "csrc")
+
+VARIANTS = {
+    # name: list of (old, new) replacements in csr5_hot.hip
+    "nocold": [("            const unsigned off = cw < 0 ? 0xFFFFFFFFu : (unsigned)cw * (unsigned)sizeof(VT);",
+                "            const unsigned off = 0xFFFFFFFFu; (void)cw;")],
+    "nogather": [("                    xa[i] = cold_word(a.c[i]);", "                    xa[i] = 0;"),
+                 ("                    xa[i] = cold_word(b.c[i]);", "                    xa[i] = 0;")],
+    "nostore": [("                if (j > 0 || !open.is_lead)\n                    out[j] = vj;",
+                 "                if (vj == (VT)-1.2345e-300)\n                    out[j] = vj;")],
+    # (not an ablation: a candidate) partial sums stored with the non-temporal hint
+    "ntstore": [("                if (j > 0 || !open.is_lead)\n                    out[j] = vj;",
+                 "                if (j > 0 || !open.is_lead)\n                    __builtin_nontemporal_store(vj, out + j);")],
+    "notable": [("            return __builtin_bit_cast(word_t, hot[cw < 0 ? (unsigned)cw & 0x7FFFFFFFu : 0u]);",
+                 "            return (word_t)(unsigned)cw;")],
+}
+
+
+def main():
+    names = sys.argv[1:] or list(VARIANTS)
+    for name in names:
+        tmp = tempfile.mkdtemp(prefix=f"csr5_abl_{name}_")
+        for f in os.listdir(SRC):
+            if f.endswith((".hip", ".h", ".cpp")):
+                shutil.copy(os.path.join(SRC, f), tmp)
+        path = os.path.join(tmp, "csr5_hot.hip")
+        text = open(path).read()
+        for old, new in VARIANTS[name]:
+            if old not in text:
+                raise SystemExit(f"{name}: pattern not found: {old[:60]}...")
+            text = text.replace(old, new)
+        open(path, "w").write(text)
+        flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-function",
+                 f"-I{ROOT}/include", f"-I{tmp}", "-DCSR5_FEW_SIGMAS"]
+        objs = []
+        procs = []
+        for f in ("csr5_format", "csr5_capi", "csr5_ingest", "csr5_slab", "csr5_multi", "csr5_hot"):
+            o = os.path.join(tmp, f + ".o")
+            objs.append(o)
+            procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, "-c", os.path.join(tmp, f + ".hip"), "-o", o]))
+        for t, d in (("f64", "-DCSR5_SPMV_ONLY_F64"), ("f32", "-DCSR5_SPMV_ONLY_F32")):
+            o = os.path.join(tmp, f"csr5_spmv_{t}.o")
+            objs.append(o)
+            procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc", *flags, d, "-c", os.path.join(tmp, "csr5_spmv.hip"), "-o", o]))
+        for p in procs:
+            if p.wait() != 0:
+                raise SystemExit(f"{name}: compile failed")
+        out = os.path.join(ROOT, "scripts", "probes", f"libcsr5hip_abl_{name}.so")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", out, *objs, "-ldl"])
+        shutil.rmtree(tmp)
+        print("built", out)
+
+
+if __name__ == "__main__":
+    main()
