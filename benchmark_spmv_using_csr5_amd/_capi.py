@@ -36,6 +36,7 @@ OPT_COLUMN_SLABS = 6
 OPT_SLAB_SHIFT = 7
 OPT_ZERO_EMPTY_ROWS = 8
 OPT_SLAB_HOT = 9
+OPT_SLAB_MEMORY_MIB = 10
 MULTI_OPT_ROW_WEIGHT = 100  # csr5hip_multi_set_option only (before input_csr)
 
 
@@ -53,7 +54,8 @@ class Csr5Info(C.Structure):
         ("t_tile_desc_ms", C.c_double), ("t_transpose_ms", C.c_double),
         ("column_slabs", C.c_int), ("slab_shift", C.c_int), ("slab_segments", C.c_int),
         ("slab_sigma", C.c_int), ("slab_tiles", C.c_int), ("t_slab_ms", C.c_double),
-        ("slab_hot", C.c_int), ("slab_hot_cover_pct", C.c_int),
+        ("slab_hot", C.c_int), ("slab_hot_cover_pct", C.c_int), ("slab_fallback", C.c_int),
+        ("device_bytes", C.c_longlong),
     ]
 
 

@@ -124,6 +124,9 @@ struct csr5hip_handle_s {
     int slab_shift = 4;    // CSR5HIP_OPT_SLAB_SHIFT
     int zero_empty = 0;    // CSR5HIP_OPT_ZERO_EMPTY_ROWS
     bool is_child = false; // internal handle of a slab structure: never builds slabs itself
+    int slab_mem_mib = 0;  // CSR5HIP_OPT_SLAB_MEMORY_MIB: cap on the structure's device memory (0 = none)
+    bool slab_fallback = false; // the structure was wanted but could not be built: plain kernel in use
+    unsigned generation = 0;    // bumped whenever captured graphs of this handle go stale (csr5hip_spmv_rotate keys on it)
     int slab_S = 0;        // > 0: spmv() runs child + combine
     int slab_m2 = 0;
     double t_slab = 0;
@@ -143,6 +146,7 @@ struct csr5hip_handle_s {
     size_t vsize() const { return value_type == CSR5HIP_F64 ? 8 : 4; }
     void drop_graphs()
     {
+        generation++;
         for (auto &kv : graphs)
             (void)hipGraphExecDestroy(kv.second);
         graphs.clear();
@@ -311,6 +315,7 @@ int csr5hip_set_sigma(csr5hip_handle h, int sigma)
 }
 
 static int build_slabs(csr5hip_handle h);
+static int build_slabs_impl(csr5hip_handle h);
 
 int csr5hip_set_option(csr5hip_handle h, int option, int value)
 {
@@ -380,6 +385,15 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         break;
     case CSR5HIP_OPT_ZERO_EMPTY_ROWS:
         h->zero_empty = value ? 1 : 0;
+        break;
+    case CSR5HIP_OPT_SLAB_MEMORY_MIB:
+        if (value < 0)
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->slab_mem_mib = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5) {
+            h->drop_graphs();
+            return build_slabs(h);
+        }
         break;
     default:
         return CSR5HIP_INVALID_ARGUMENT;
@@ -592,7 +606,16 @@ int csr5hip_as_csr5(csr5hip_handle h)
     }
     resolve_variants(h);
     h->format = CSR5HIP_FORMAT_CSR5;
-    return build_slabs(h);
+    rc = build_slabs(h);
+    if (rc != CSR5HIP_SUCCESS) {
+        // only when the structure was requested explicitly: a failed asCSR5 leaves CSR, as in the reference
+        // (anonymouslib_cuda.h:105-220 returns before _format changes)
+        const std::string why = g_last_error;
+        if (csr5hip_as_csr(h) != CSR5HIP_SUCCESS)
+            h->format = -1; // the arrays could not be restored: unusable until inputCSR
+        g_last_error = why;
+    }
+    return rc;
 }
 
 // ---- column slabs (csr5_slab.hip) ------------------------------------------------------------------
@@ -660,7 +683,26 @@ static int slab_count_without_table(const csr5hip_handle_s *h)
     return S;
 }
 
+// The column-slab structure is an optional accelerator: when it cannot be built (allocation failure, memory cap) the
+// handle stays a valid CSR5 matrix on the plain tile kernel.  Returns SUCCESS in that case -- csr5hip_info.slab_fallback
+// and csr5hip_last_error() say what happened -- unless the caller REQUESTED the structure (slab_request >= 2): then the
+// error code is returned (the matrix is still usable on the plain path; csr5hip_as_csr5 additionally rolls back to CSR).
 static int build_slabs(csr5hip_handle h)
+{
+    h->slab_fallback = false;
+    const int rc = build_slabs_impl(h);
+    if (rc == CSR5HIP_SUCCESS)
+        return rc;
+    const std::string why = g_last_error;
+    (void)hipGetLastError(); // clear a sticky allocation error
+    release_slabs(h);
+    h->slab_fallback = true;
+    h->drop_graphs();
+    g_last_error = "column slabs not built, plain tile kernel in use: " + why;
+    return h->slab_request >= 2 ? rc : CSR5HIP_SUCCESS;
+}
+
+static int build_slabs_impl(csr5hip_handle h)
 {
     deactivate_slabs(h);
     h->t_slab = 0;
@@ -686,13 +728,19 @@ static int build_slabs(csr5hip_handle h)
         int dev = 0, lds_max = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-        // the per-wavefront y-compaction regions sit behind the table (k_spmv_hot)
+        // the per-wavefront y-compaction regions sit behind the table (k_spmv_range)
         int lds = lds_max - HOT_WAVES * HOT_WAVE_LDS;
         lds = lds > HOT_LDS_BYTES ? HOT_LDS_BYTES : lds;
         hot_capacity = lds / (int)h->vsize();
-    } else if (auto_count) {
-        S = S_plain; // table ruled out beforehand
+        // a device (or runtime) that offers little LDS gets no table, forced or not: slot 0 is reserved and the
+        // threshold search needs room above it
+        if (hot_capacity < 1024) {
+            hot = false;
+            hot_capacity = 0;
+        }
     }
+    if (!hot && auto_count)
+        S = S_plain; // table ruled out beforehand
     const int S_alloc = S > S_plain ? S : S_plain;
 
     // all temporaries of the build in one allocation.  Up to 1/64 of the device memory (4.5 GB of 288) they stay with
@@ -714,6 +762,13 @@ static int build_slabs(csr5hip_handle h)
     const size_t o_hist = take((size_t)S_alloc * g.p * 4), o_scan = take(scan_bytes), o_key = take((size_t)g.nnz * 8),
                  o_count = take(16), o_sel = take(sel_bytes), o_cnt = take(nb), o_hotmap = take(nb), o_chist = take(hb),
                  o_thr = take((size_t)S_alloc * 4);
+    if (h->slab_mem_mib > 0) {
+        // second copy of column_index / value + build temporaries + (upper bound) one partial sum per non-zero row piece
+        const unsigned long long need = (unsigned long long)g.nnz * (4 + h->vsize()) + off +
+                                        (unsigned long long)g.m * (h->vsize() + 5);
+        if (need > (unsigned long long)h->slab_mem_mib << 20)
+            return fail_hip(hipErrorOutOfMemory, "column slabs: CSR5HIP_OPT_SLAB_MEMORY_MIB");
+    }
     HIP_TRY(h->b_slab_tmp.reserve(off));
     struct TmpGuard { // very big temporaries (8 B per non-zero) do not outlive the build
         Buffer &b;
@@ -1193,6 +1248,9 @@ int csr5hip_spmv_rotate(csr5hip_handle *hs, void **d_ys, int k, double alpha, in
     for (int i = 0; i < k; i++) {
         key.push_back(hs[i]);
         key.push_back(d_ys[i]);
+        // the graph bakes in every handle's x, format arrays and slab buffers: any change of handle i (set_x, set_option,
+        // asCSR / asCSR5, set_stream) bumps its generation and must invalidate the graph cached on hs[0]
+        key.push_back((void *)(uintptr_t)hs[i]->generation);
     }
     if (!h0->rotate_exec || h0->rotate_key != key) {
         if (h0->rotate_exec)
@@ -1241,15 +1299,19 @@ int csr5hip_autotune_sigma(csr5hip_handle h, void *d_y, int *best_sigma, double 
     if (rc != CSR5HIP_SUCCESS)
         return rc;
     static const int candidates[] = {4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
-    int best = 0;
+    int best = 0, capped_child_sigma = 0;
     double best_ms = 1e300;
     for (int sigma : candidates) {
         if ((long long)OMEGA * sigma > (long long)h->g.nnz && sigma != 4)
             continue; // fewer non-zeros than one tile: nothing to choose
+        if (capped_child_sigma && sigma > capped_child_sigma)
+            continue; // SpMV runs on the slab child, whose sigma is capped: this candidate would time the same kernel again
         h->sigma_request = sigma;
         rc = csr5hip_as_csr5(h);
         if (rc != CSR5HIP_SUCCESS)
             return rc;
+        if (h->slab_S > 0 && h->slab_child && h->slab_child->hot_enabled && h->slab_child->g.sigma < sigma)
+            capped_child_sigma = sigma; // (every larger parent sigma gives this same child)
         for (int i = 0; i < 3 && rc == CSR5HIP_SUCCESS; i++)
             rc = csr5hip_spmv(h, 1.0, d_y);
         // size the timed batch to ~0.5 ms from one timed probe launch
@@ -1324,6 +1386,14 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->t_slab_ms = h->t_slab;
     info->slab_hot = h->slab_S > 0 && h->slab_child->hot_enabled ? 1 : 0;
     info->slab_hot_cover_pct = h->hot_cover_pct;
+    info->slab_fallback = h->slab_fallback ? 1 : 0;
+    long long bytes = (long long)h->b_arena.cap;
+    for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
+                            &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_slab_tmp})
+        bytes += (long long)b->cap;
+    if (h->slab_child)
+        bytes += (long long)h->slab_child->b_arena.cap;
+    info->device_bytes = bytes;
     return CSR5HIP_SUCCESS;
 }
 

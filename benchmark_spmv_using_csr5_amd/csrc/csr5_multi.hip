@@ -2,8 +2,9 @@
 //
 // The reference is single-device (CSR5_cuda/main.cu:25-26 `cudaSetDevice(0)`); this is the MI355X-native addition
 // BASELINE.json names: SpMV rows are independent, so the matrix is cut into G contiguous row blocks balanced by
-// NON-ZEROS -- split points = upper_bound(row_ptr, g*nnz/G) - 1, the primitive the reference uses for tile_ptr
-// (utils_cuda.h:25-53) -- every block gets its own ordinary handle (own CSR5 conversion, own stream) on its
+// COST = non-zeros + weight * rows (default weight 2; weight 0 = plain non-zeros) -- split points =
+// upper_bound(row_ptr[r] + weight * r, g * total / G) - 1, the primitive the reference uses for tile_ptr
+// (utils_cuda.h:25-53) on the cost prefix -- every block gets its own ordinary handle (own CSR5 conversion, own stream) on its
 // device, x is replicated ONCE by a single RCCL broadcast over xGMI at set_x time, y stays sharded on the devices,
 // and there is no per-SpMV collective.  One host thread drives all devices (launches are asynchronous).
 //
@@ -72,6 +73,16 @@ int fail(hipError_t e, const char *what)
         if (e_ != hipSuccess)                                                                      \
             return fail(e_, #expr);                                                                \
     } while (0)
+// Every entry point leaves the caller's current device as it found it, on every return path.
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { (void)hipGetDevice(&dev); }
+    ~DeviceGuard()
+    {
+        if (dev >= 0)
+            (void)hipSetDevice(dev);
+    }
+};
 #define MRC(expr)                                                                                  \
     do {                                                                                           \
         int rc_ = (expr);                                                                          \
@@ -163,11 +174,16 @@ int csr5hip_multi_create(csr5hip_multi *out, const int *devices, int G, int m, i
     mh->x_owned.assign(G, 0);
     mh->ev0.assign(G, nullptr), mh->ev1.assign(G, nullptr);
     mh->cut.assign(G + 1, 0), mh->shard_nnz.assign(G, 0);
+    DeviceGuard restore_device;
     for (int g = 0; g < G; g++) {
-        MHIP(hipSetDevice(mh->dev[g]));
-        MHIP(hipStreamCreateWithFlags(&mh->stream[g], hipStreamNonBlocking));
-        MHIP(hipEventCreate(&mh->ev0[g]));
-        MHIP(hipEventCreate(&mh->ev1[g]));
+        hipError_t e = hipSetDevice(mh->dev[g]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&mh->stream[g], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreate(&mh->ev0[g]);
+        if (e == hipSuccess) e = hipEventCreate(&mh->ev1[g]);
+        if (e != hipSuccess) {
+            (void)csr5hip_multi_free(mh); // releases the streams and events created so far
+            return fail(e, "csr5hip_multi_create: stream / event creation");
+        }
     }
     *out = mh;
     return CSR5HIP_SUCCESS;
@@ -177,6 +193,7 @@ int csr5hip_multi_free(csr5hip_multi mh)
 {
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
+    DeviceGuard restore_device;
     for (void *c : mh->comm)
         if (c && rccl().ok())
             (void)rccl().CommDestroy(c);
@@ -193,7 +210,6 @@ int csr5hip_multi_free(csr5hip_multi mh)
         if (mh->ev1[g]) (void)hipEventDestroy(mh->ev1[g]);
         if (mh->stream[g]) (void)hipStreamDestroy(mh->stream[g]);
     }
-    (void)hipSetDevice(mh->dev[0]);
     delete mh;
     return CSR5HIP_SUCCESS;
 }
@@ -201,6 +217,7 @@ int csr5hip_multi_free(csr5hip_multi mh)
 int csr5hip_multi_input_csr(csr5hip_multi mh, int nnz, const int32_t *d_row_ptr, const int32_t *d_col_idx,
                             const void *d_val)
 {
+    DeviceGuard restore_device;
     if (!mh || nnz < 0 || !d_row_ptr || (nnz > 0 && (!d_col_idx || !d_val)))
         return CSR5HIP_INVALID_ARGUMENT;
     mh->nnz = nnz;
@@ -264,6 +281,7 @@ int csr5hip_multi_input_csr(csr5hip_multi mh, int nnz, const int32_t *d_row_ptr,
 
 int csr5hip_multi_set_sigma(csr5hip_multi mh, int sigma)
 {
+    DeviceGuard restore_device;
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
     for (int g = 0; g < mh->G; g++)
@@ -274,6 +292,7 @@ int csr5hip_multi_set_sigma(csr5hip_multi mh, int sigma)
 
 int csr5hip_multi_set_option(csr5hip_multi mh, int option, int value)
 {
+    DeviceGuard restore_device;
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
     if (option == CSR5HIP_MULTI_OPT_ROW_WEIGHT) { // takes effect at the next input_csr
@@ -292,6 +311,7 @@ int csr5hip_multi_set_option(csr5hip_multi mh, int option, int value)
 
 int csr5hip_multi_as_csr5(csr5hip_multi mh)
 {
+    DeviceGuard restore_device;
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
     for (int g = 0; g < mh->G; g++) {
@@ -306,6 +326,7 @@ int csr5hip_multi_as_csr5(csr5hip_multi mh)
 
 int csr5hip_multi_destroy(csr5hip_multi mh)
 {
+    DeviceGuard restore_device;
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
     for (int g = 0; g < mh->G; g++)
@@ -320,6 +341,7 @@ int csr5hip_multi_destroy(csr5hip_multi mh)
 // x lives on devices[0]; every other device receives its copy by ONE broadcast.  Shards on devices[0] read d_x itself.
 int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x)
 {
+    DeviceGuard restore_device;
     if (!mh || !d_x)
         return CSR5HIP_INVALID_ARGUMENT;
     const size_t bytes = (size_t)mh->n * mh->vsize();
@@ -360,7 +382,10 @@ int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x)
             // the ONE collective of the sharded SpMV: n * sizeof(vT) bytes from devices[0] to all, over xGMI
             int rc = rccl().GroupStart();
             for (int g = 0; g < G && rc == 0; g++) {
-                MHIP(hipSetDevice(mh->dev[g]));
+                if (hipSetDevice(mh->dev[g]) != hipSuccess) { // (no early return: the group must be closed)
+                    rc = -1;
+                    break;
+                }
                 rc = rccl().Broadcast(g == 0 ? d_x : mh->x[g], mh->x[g], bytes, NCCL_UINT8, 0, mh->comm[g], mh->stream[g]);
             }
             const int rc2 = rccl().GroupEnd();
@@ -396,6 +421,7 @@ int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x)
 
 int csr5hip_multi_spmv(csr5hip_multi mh, double alpha)
 {
+    DeviceGuard restore_device;
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
     for (int g = 0; g < mh->G; g++) {
@@ -407,6 +433,7 @@ int csr5hip_multi_spmv(csr5hip_multi mh, double alpha)
 
 int csr5hip_multi_spmv_repeat(csr5hip_multi mh, double alpha, int count)
 {
+    DeviceGuard restore_device;
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
     for (int g = 0; g < mh->G; g++) {
@@ -418,6 +445,7 @@ int csr5hip_multi_spmv_repeat(csr5hip_multi mh, double alpha, int count)
 
 int csr5hip_multi_synchronize(csr5hip_multi mh)
 {
+    DeviceGuard restore_device;
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
     for (int g = 0; g < mh->G; g++) {
@@ -430,6 +458,7 @@ int csr5hip_multi_synchronize(csr5hip_multi mh)
 
 int csr5hip_multi_timer_start(csr5hip_multi mh)
 {
+    DeviceGuard restore_device;
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
     for (int g = 0; g < mh->G; g++) {
@@ -442,6 +471,7 @@ int csr5hip_multi_timer_start(csr5hip_multi mh)
 // elapsed device time between timer_start and now: the MAXIMUM over the shards' streams
 int csr5hip_multi_timer_stop(csr5hip_multi mh, double *ms_max)
 {
+    DeviceGuard restore_device;
     if (!mh || !ms_max)
         return CSR5HIP_INVALID_ARGUMENT;
     for (int g = 0; g < mh->G; g++) {
@@ -463,6 +493,7 @@ int csr5hip_multi_timer_stop(csr5hip_multi mh, double *ms_max)
 
 int csr5hip_multi_shard(csr5hip_multi mh, int g, csr5hip_shard *out)
 {
+    DeviceGuard restore_device;
     if (!mh || !out || g < 0 || g >= mh->G)
         return CSR5HIP_INVALID_ARGUMENT;
     out->device = mh->dev[g];
@@ -478,6 +509,7 @@ int csr5hip_multi_shard(csr5hip_multi mh, int g, csr5hip_shard *out)
 // correctness checks only: collect the y shards into one HOST vector of m values (G device-to-host copies)
 int csr5hip_multi_gather_y(csr5hip_multi mh, void *h_y)
 {
+    DeviceGuard restore_device;
     if (!mh || !h_y)
         return CSR5HIP_INVALID_ARGUMENT;
     const size_t vs = mh->vsize();
@@ -496,6 +528,7 @@ int csr5hip_multi_gather_y(csr5hip_multi mh, void *h_y)
 // y shards pre-filled with a value pattern (tests: rows without non-zeros must stay untouched)
 int csr5hip_multi_fill_y(csr5hip_multi mh, int byte_value)
 {
+    DeviceGuard restore_device;
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
     for (int g = 0; g < mh->G; g++) {

@@ -49,6 +49,10 @@ static const char *g_filename = "";
 static double g_ingest_ms[3] = {0, 0, 0};  // parse, H2D, device COO->CSR
 
 // the reference protocol (main.cu:59-104) on G GPUs
+// exit code of a multi-GPU run that completed without the RCCL broadcast it should have used (0..-4 are the reference's)
+static const int EXIT_RCCL_FALLBACK = 6;
+static bool g_rccl_fallback = false;
+
 static int call_anonymouslib_multi(const std::vector<int> &devs, int m, int n, int nnzA, int *csrRowPtrA,
                                    int *csrColIdxA, VALUE_TYPE *csrValA, VALUE_TYPE *x, VALUE_TYPE *y, VALUE_TYPE alpha)
 {
@@ -95,6 +99,18 @@ static int call_anonymouslib_multi(const std::vector<int> &devs, int m, int n, i
     cout << "x replicated on " << G << " GPUs in " << bcast_timer.stop() << " ms ("
          << (s0.x_broadcast == 1 ? "one RCCL broadcast" : s0.x_broadcast == 2 ? "device-to-device copies" : "shared device")
          << ")." << endl;
+    {
+        // distinct devices should have used the RCCL broadcast: say so loudly when they did not (library missing,
+        // ncclCommInitAll / ncclBroadcast failed) and make the process exit code show it (EXIT_RCCL_FALLBACK)
+        bool distinct = true;
+        for (size_t a = 0; a < devs.size(); a++)
+            for (size_t b = a + 1; b < devs.size(); b++)
+                distinct = distinct && devs[a] != devs[b];
+        if (distinct && s0.x_broadcast != 1) {
+            cerr << "warning: RCCL broadcast not used (" << csr5hip_last_error() << "); x was replicated by device-to-device copies" << endl;
+            g_rccl_fallback = true;
+        }
+    }
 
     err = A.spmv(alpha); // correctness run
     A.gatherY(y);
@@ -372,5 +388,5 @@ int main(int argc, char **argv)
     free(x);
     free(y);
     free(y_ref);
-    return 0;
+    return g_rccl_fallback ? EXIT_RCCL_FALLBACK : 0;
 }

@@ -140,6 +140,11 @@ class anonymouslibHandle:
         """column slabs: 0 = no LDS hot table, 1 = auto (default), 2 = force (csr5hip.h CSR5HIP_OPT_SLAB_HOT)"""
         return self.setOption(_capi.OPT_SLAB_HOT, int(value))
 
+    def setSlabMemoryMiB(self, value: int) -> int:
+        """upper bound (MiB) on the device memory of the column-slab structure, 0 = none: a structure that would not fit
+        is not built and spmv() runs the plain kernel (info().slab_fallback == 1)"""
+        return self.setOption(_capi.OPT_SLAB_MEMORY_MIB, int(value))
+
     def setZeroEmptyRows(self, value: int) -> int:
         """1 = spmv() also stores 0 into rows without non-zeros (solver coupling); 0 = reference behaviour"""
         return self.setOption(_capi.OPT_ZERO_EMPTY_ROWS, int(value))

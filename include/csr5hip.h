@@ -80,6 +80,14 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       without the caller zeroing it -- what a solver that feeds y back as x needs);
                                       0 = reference behaviour (default): empty rows before the tail are left untouched */
 
+#define CSR5HIP_OPT_SLAB_MEMORY_MIB 10 /* upper bound, in MiB, on the device memory the column-slab structure may take
+                                      (second copy of column_index / value, partial sums, build temporaries); 0 = none
+                                      (default).  A structure that would exceed it -- or whose allocation fails -- is
+                                      not built: asCSR5() still succeeds and spmv() runs the plain tile kernel
+                                      (csr5hip_info.slab_fallback = 1, csr5hip_last_error() says why).  Only a structure
+                                      that was REQUESTED (CSR5HIP_OPT_COLUMN_SLABS >= 2) makes asCSR5() fail, after the
+                                      matrix has been put back into CSR. */
+
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
 /* Host-visible snapshot of the handle's private state (anonymouslib_cuda.h:27-52). */
@@ -111,6 +119,10 @@ typedef struct csr5hip_info {
     double t_slab_ms;              /* time asCSR5 spent building the slab structure                       */
     int slab_hot;                  /* 1 if the slab kernel gathers hot columns from an LDS table          */
     int slab_hot_cover_pct;        /* share of the non-zeros whose column has a slot in its slab's table  */
+    int slab_fallback;             /* 1 = the column-slab structure was wanted but could not be built (memory): the
+                                      plain kernel is in use                                                */
+    long long device_bytes;        /* device memory held by the handle (CSR5 arrays, kernel tables, slab structure,
+                                      build temporaries it keeps); the caller's CSR, x and y are not counted */
 } csr5hip_info;
 
 /* anonymouslibHandle(m, n) -- anonymouslib_cuda.h:15.  Uses the current HIP device. */

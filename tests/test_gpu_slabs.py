@@ -314,3 +314,55 @@ def test_checkpoint_of_a_matrix_with_slabs(tmp_path):
     B.close()
     A.destroy()
     A.close()
+
+
+def test_slab_build_failure_falls_back_to_plain_kernel(oracle):
+    """The slab structure is an optional accelerator: when it cannot be built -- here: a memory cap of 1 MiB
+    -- an AUTO request leaves a valid CSR5 matrix on the plain kernel and asCSR5 succeeds (info says so); a structure that
+    was REQUESTED makes asCSR5 fail, and then the matrix is back in CSR with the caller's arrays restored, as the
+    reference's failed asCSR5 leaves it (anonymouslib_cuda.h:105-220)."""
+    mat = _hub_columns_matrix(150000, 700000, 12, 3000, 11)  # x = 5.6 MB, scattered columns: auto picks slabs
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=4, mode="int")
+    exp = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    nonempty = np.diff(mat.row_ptr) > 0
+    rp, ci, va = _device_csr(mat, val, np.float64)
+    ci0, va0 = ci.clone(), va.clone()
+    xd = torch.from_numpy(x).to(DEV)
+    yd = torch.zeros(mat.m, dtype=torch.float64, device=DEV)
+    A = H.anonymouslibHandle(mat.m, mat.n)
+    assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0 and A.setSigma(16) == 0
+    # auto, no cap: the structure is built
+    assert A.asCSR5() == 0
+    i = A.info()
+    assert i.column_slabs > 0 and i.slab_fallback == 0 and i.device_bytes > mat.nnz * 12
+    with_slabs = i.device_bytes
+    assert A.asCSR() == 0
+    # auto + cap: plain kernel, success, reason recorded
+    assert A.setSlabMemoryMiB(1) == 0
+    assert A.asCSR5() == 0, _capi.last_error()
+    i = A.info()
+    assert i.column_slabs == 0 and i.slab_fallback == 1 and i.format == 1
+    assert "column slabs not built" in _capi.last_error()
+    assert i.device_bytes < with_slabs // 4
+    assert A.spmv(1.0, yd) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy()[nonempty], exp[nonempty])
+    # a cap raised on the converted matrix builds the structure after all
+    assert A.setSlabMemoryMiB(0) == 0
+    i = A.info()
+    assert i.column_slabs > 0 and i.slab_fallback == 0
+    yd.zero_()
+    assert A.spmv(1.0, yd) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy()[nonempty], exp[nonempty])
+    assert A.asCSR() == 0
+    # requested + cap: asCSR5 fails and leaves CSR with the caller's arrays as they were
+    assert A.setSlabMemoryMiB(1) == 0 and A.setColumnSlabs(8) == 0
+    assert A.asCSR5() != 0
+    torch.cuda.synchronize()
+    assert A.info().format == 0
+    assert torch.equal(ci, ci0) and torch.equal(va, va0)
+    assert A.spmv(1.0, yd) == -4  # UNSUPPORTED_CSR_SPMV: still a CSR matrix
+    assert A.setSlabMemoryMiB(0) == 0 and A.asCSR5() == 0 and A.info().column_slabs == 8
+    assert A.destroy() == 0
+    A.close()
