@@ -507,7 +507,7 @@ static int derive_kernel_tables(csr5hip_handle h)
             h->wall_clock_khz = 100000.0; // gfx9: 100 MHz
     }
     // carry_meta + x-windows + fused-kernel headers in one launch, then the export of the host's words
-    HIP_TRY(launch_tile_tables(g, h->d, (int)h->vsize(), h->host_words, s));
+    HIP_TRY(launch_tile_tables(g, h->d, (int)h->vsize(), h->host_words, h->is_child && h->hot_enabled, s));
     HIP_TRY(hipStreamSynchronize(s));
     const uint32_t *w = h->host_words;
     h->scalar_words[0] = w[0];

@@ -455,11 +455,13 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
                                                        const uint32_t *__restrict__ hdr,
                                                        const int32_t *__restrict__ offset_ptr,
                                                        uint32_t *__restrict__ counters,
-                                                       uint32_t *__restrict__ host_words)
+                                                       uint32_t *__restrict__ host_words, int export_only)
 {
     __shared__ unsigned part[16][3];
     unsigned on = 0, in = 0, lines = 0;
-    for (int t = blockIdx.x * 1024 + threadIdx.x; t < g.p - 1; t += gridDim.x * 1024) {
+    if (export_only)
+        stamp_phase(counters, 3); // (k_tile_tables, which stamps this phase, did not run)
+    for (int t = blockIdx.x * 1024 + threadIdx.x; t < (export_only ? 0 : g.p - 1); t += gridDim.x * 1024) {
         const unsigned v = hdr[8 * (size_t)t + 7];
         on += v != 0;
         in += v & 0xFFFFu;
@@ -633,11 +635,19 @@ hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_
     return hipGetLastError();
 }
 
-hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int value_size, uint32_t *host_words,
+// export_only: the matrix is a column-slab child served by the range kernel (csr5_hot.hip), which uses neither carry meta nor
+// tile headers nor x-windows: only the host's words are exported (k_tile_tables reads every column word: 0.86 ms of the
+// 3.2-ms child conversion of R-MAT 24)
+hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int value_size, uint32_t *host_words, bool export_only,
                               hipStream_t s)
 {
     if (g.p <= 0)
         return hipSuccess;
+    if (export_only) {
+        hipLaunchKernelGGL(k_stats_export, dim3(1), dim3(1024), 0, s, g, d.tile_ptr, d.tile_hdr, d.offset_ptr, d.counters,
+                           host_words, 1);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_tile_tables, dim3(div_up(g.p, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
                        d.tile_ptr, d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.tile_hdr, d.counters,
                        xwin_elems(value_size), value_size == 8 ? 4 : 5);
@@ -647,7 +657,7 @@ hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int valu
     int blocks = div_up(g.p, 1024 * 16);
     blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
     hipLaunchKernelGGL(k_stats_export, dim3(blocks), dim3(1024), 0, s, g, d.tile_ptr, d.tile_hdr, d.offset_ptr,
-                       d.counters, host_words);
+                       d.counters, host_words, 0);
     return hipGetLastError();
 }
 

@@ -86,7 +86,8 @@ hipError_t launch_offset_scan(const Geometry &g, const DeviceArrays &d, void *tm
 hipError_t launch_desc_offset(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c,
                             hipStream_t s);
-hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int value_size, uint32_t *host_words, hipStream_t s);
+hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int value_size, uint32_t *host_words, bool export_only,
+                              hipStream_t s);
 hipError_t launch_warmup(hipStream_t s);
 // flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)
 hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,
@@ -123,7 +124,7 @@ struct SpmvOptions {
     int lds_y;       // resolved: 1 = compact y segments through LDS before storing them
     int stream_nt;   // resolved: 1 = column/value streams use non-temporal loads
     int long_runs;   // resolved: the matrix has rows spanning > RUN_SERIAL_MAX tiles (fused mode adds k_calibrate)
-    int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_hot + tail launch
+    int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_range + k_range_finish
 };
 constexpr int HOT_LDS_BYTES = 128 * 1024;  // upper bound of the LDS table of hot x entries per workgroup (k_spmv_range)
 constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_range (16 wavefronts)

@@ -599,8 +599,6 @@ k_hot_encode(int nnz, int T, int p, int S, const int32_t *__restrict__ slab_off,
     const int mine = slab_at((long long)pos);
     if (slab_at((long long)t * T) != mine)
         return; // element of the NEXT slab inside a tile owned by the previous one: that tile holds another table
-    if (t == tile0[mine] && pos - (size_t)t * T < (size_t)OMEGA)
-        return; // the previous slab's last tile may read these as its short spill
     const int h = hotmap[(uint32_t)col2[pos]];
     if (h >= 0)
         col2[pos] = (int32_t)(0x80000000u | (uint32_t)h);
