@@ -115,6 +115,8 @@ def parse_args():
     ap.add_argument("--values", default="int", choices=["int", "real"],
                     help="int = rand()%%10 (reference CLI data, exact); real = uniform(-1, 1)")
     ap.add_argument("--cold", action="store_true", help="time the headline workload with the cold-cache protocol too")
+    ap.add_argument("--no-cold", action="store_true",
+                    help="skip the cold-cache protocol that a cache-sized working set gets by default (profiling runs: one protocol per trace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-configs", action="store_true", help="skip the per-config array (N = 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -560,7 +562,7 @@ def main():
             roof["per_gpu_note"] = ("achieved/frac: rank 0's shard bytes (incl. the whole x it reads) over the "
                                     "max-over-ranks event time; largest shard = %d bytes; every rank's own figures: multi_gpu.ranks"
                                     % int(max_b_alg))
-        if world == 1 and (args.cold or small_working_set(prob)):
+        if world == 1 and (args.cold or (small_working_set(prob) and not args.no_cold)):
             cold_ms, k, cs = timed_cold(lambda: Problem(mat, label, dtype_name, args, dev, args.seed + 13), prob,
                                         steps, warmup)
             if small_working_set(prob):

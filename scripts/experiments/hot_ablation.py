@@ -25,6 +25,10 @@ VARIANTS = {
     # (not an ablation: a candidate) partial sums stored with the non-temporal hint
     "ntstore": [("                if (j > 0 || !open.is_lead)\n                    out[j] = vj;",
                  "                if (j > 0 || !open.is_lead)\n                    __builtin_nontemporal_store(vj, out + j);")],
+    # (candidates) cache policy of the cold x gathers: gfx940+ aux bits sc0 = 1, nt = 2, sc1 = 16
+    "gather_nt": [("__builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));\n            else", "__builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 2));\n            else")],
+    "gather_sc1": [("__builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));\n            else", "__builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 16));\n            else")],
+    "gather_sc0sc1": [("__builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));\n            else", "__builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 17));\n            else")],
     "notable": [("            return __builtin_bit_cast(word_t, hot[cw < 0 ? (unsigned)cw & 0x7FFFFFFFu : 0u]);",
                  "            return (word_t)(unsigned)cw;")],
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs on the GPU box (scripts/gpu_profiles_r02.sh): condenses one workload's rocprofv3 output into <tag>_pmc.json.
+"""Runs on the GPU box (scripts/gpu_profiles.sh): condenses one workload's rocprofv3 output into <tag>_pmc.json.
 
 Per SpMV step = every dispatch of the step's kernels (tile kernel, its tail-only launch, slab combine, calibrate).
 traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB summed over those dispatches / number of steps: FETCH_SIZE / WRITE_SIZE are
@@ -12,8 +12,8 @@ import os
 import sys
 
 tag, d, out = sys.argv[1], sys.argv[2], sys.argv[3]
-STEP = ("k_spmv", "k_slab_combine", "k_calibrate")
-MAIN = ("k_spmv_hot", "k_spmv<")
+STEP = ("k_spmv", "k_slab_combine", "k_calibrate", "k_range_finish")
+MAIN = ("k_spmv_hot", "k_spmv_range", "k_spmv<")
 
 
 def is_step(name):
