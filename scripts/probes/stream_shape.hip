@@ -217,10 +217,15 @@ __global__ void __launch_bounds__(1024) k_stream(const int *__restrict__ col, co
         out[w * 64 + lane] = acc;
 }
 
+static int g_copies = 1;
+
 template <int DEPTH, bool CONTIG, int COLD, int PSTORE, int WORK>
-static int run(const char *name, const int *col, const double *val, const double *x, int xbytes, size_t ntiles, double *P,
+static int run(const char *name, const int *col0, const double *val0, const double *x, int xbytes, size_t ntiles, double *P,
                double *out, hipStream_t s)
 {
+    static int turn = 0;
+    const int *col = col0;
+    const double *val = val0;
     auto kern = k_stream<DEPTH, CONTIG, COLD, PSTORE, WORK>;
     const int lds = 160 * 1024;
     CK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -230,7 +235,10 @@ static int run(const char *name, const int *col, const double *val, const double
     hipLaunchKernelGGL(kern, dim3(256), dim3(1024), lds, s, col, val, x, xbytes, ntiles, P, out);
     CK(hipStreamSynchronize(s));
     float best = 1e30f;
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < 4 * g_copies; r++) {
+        turn = (turn + 1) % g_copies; // cold protocol: every launch streams another copy
+        col = col0 + (size_t)turn * ntiles * T;
+        val = val0 + (size_t)turn * ntiles * T;
         CK(hipEventRecord(a, s));
         hipLaunchKernelGGL(kern, dim3(256), dim3(1024), lds, s, col, val, x, xbytes, ntiles, P, out);
         CK(hipEventRecord(b, s));
@@ -248,24 +256,32 @@ static int run(const char *name, const int *col, const double *val, const double
 int main(int argc, char **argv)
 {
     const size_t nnz = argc > 1 ? (size_t)atoll(argv[1]) : ((size_t)1 << 28);
+    g_copies = argc > 2 ? atoi(argv[2]) : 1; // > 1: rotate over that many copies of the streams (cold-cache protocol)
+    const bool brief = argc > 3;
     const size_t ntiles = nnz / T;
     hipStream_t s;
     CK(hipStreamCreate(&s));
     int *col;
     double *val, *x, *P, *out;
     const int xbytes = 8 << 20;
-    CK(hipMalloc(&col, nnz * 4));
-    CK(hipMalloc(&val, nnz * 8));
+    CK(hipMalloc(&col, nnz * 4 * g_copies));
+    CK(hipMalloc(&val, nnz * 8 * g_copies));
     CK(hipMalloc(&x, xbytes));
     CK(hipMemset(x, 0, xbytes));
     CK(hipMalloc(&P, ntiles * 128 * 8));
     CK(hipMalloc(&out, (size_t)4096 * 64 * 8));
     for (int coldpct : {0, 34}) {
-        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, s, col, val, nnz, coldpct, xbytes / 8);
+        hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, s, col, val, nnz * g_copies, coldpct, xbytes / 8);
         CK(hipStreamSynchronize(s));
         printf("## %zu elements, %zu tiles of %d, cold gather lanes %d %% (x = 8 MB uniform)\n", nnz, ntiles, T, coldpct);
 #define RUN(D, C, CO, PS, W) \
     if (run<D, C, CO, PS, W>("depth " #D " contig " #C " cold " #CO " pstore-mode " #PS " work " #W, col, val, x, xbytes, ntiles, P, out, s)) return 1;
+        if (brief) { // small-matrix question: does one-tile-ahead prefetch help a 20-tile-per-wavefront kernel, cold?
+            if (coldpct == 0) {
+                RUN(1, true, 0, 0, 0) RUN(2, true, 0, 0, 0) RUN(1, true, 0, 1, 300) RUN(2, true, 0, 1, 300) RUN(3, true, 0, 1, 300)
+            }
+            continue;
+        }
         if (coldpct == 0) {
             RUN(1, true, 0, 0, 0) RUN(1, true, 0, 1, 0) RUN(1, true, 0, 2, 0) RUN(1, true, 0, 3, 0) RUN(1, true, 0, 4, 0)
             RUN(1, true, 0, 5, 0) RUN(1, true, 0, 6, 0)
