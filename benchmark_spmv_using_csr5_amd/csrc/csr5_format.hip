@@ -9,8 +9,9 @@
 //      one bisection of row_ptr per tile                             boundaries inside its pointer range; no search
 //   K2 generate_partition_pointer_s2  :43-95   block / tile,       (same kernel)     an empty row with pointer e marks
 //      loops over the tile's rows                                    tile (e-1)/T; no loop
-//   K4 generate_partition_descriptor_s1 :129-159 thread / row      (same kernel)     flag scatter, tiles < p-1 only
-//   K5 generate_partition_descriptor_s2 :161-267 warp / tile,      k_tile_desc       wave / tile: popcounts, DPP-free
+//   K4 generate_partition_descriptor_s1 :129-159 thread / row,     k_tile_desc       lane / sigma elements: the distinct row
+//      one atomicOr per row                                          pointers inside them, found in the tile's slice of row_ptr
+//   K5 generate_partition_descriptor_s2 :161-267 warp / tile,      (same kernel)     wave / tile: popcounts, DPP-free
 //      LDS scan + serial look-ahead loop                             shfl scan, ballot + ctz for scansum_offset
 //   K6 generate_partition_descriptor_s3 :269-300 1 block           rocprim device scan (k_offset_scan_small: 1 block, <= 16 k tiles)
 //   K7 generate_partition_descriptor_offset :362-523               k_desc_offset     wave / flagged tile
@@ -49,15 +50,15 @@ __device__ __forceinline__ void stamp_phase(uint32_t *__restrict__ counters, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1 + K2 + K4 fused, one thread per row r < m, reading row_ptr once (tile_ptr and tile_desc start zeroed; every
-// store is an atomicOr of disjoint bits, so the three parts need no order among themselves):
+// K1 + K2 fused, one thread per row r < m, reading row_ptr once (tile_ptr starts zeroed; every store is an atomicOr of
+// disjoint bits, so the parts need no order among themselves).  (Until round 3 the bit flags -- K4 -- were scattered from
+// here as well, one atomicOr per non-empty row: 0.8-1.0 ms of the 1.1 ms this pass took on R-MAT 24 and on its 40 M-row
+// slab child; k_tile_desc now derives a lane's flags from the tile's slice of row_ptr without atomics.)
 //  * K1: tile_ptr[t] = last row r in [0, m] with row_ptr[r] <= min(t*T, nnz).  For t*T < nnz that is the one
 //    NON-EMPTY row whose range [row_ptr[r], row_ptr[r+1]) holds t*T, so every row writes the boundaries inside its own
 //    range (none for most rows, thousands for a hub row: the wavefront shares those) and tile_ptr[p] = m.  The
 //    reference bisects row_ptr once per tile (format_cuda.h:21-41): p dependent 17-step chains, 7 us on a 171 k-row
 //    matrix where this pass costs nothing extra;
-//  * K4: bit flag of the row's first element e = row_ptr[r] (tiles 0..p-2 only; the last tile is
-//    processed from CSR and its descriptor stays zero, as in CSR5_avx2 format_avx2.h:98);
 //  * K2: an EMPTY row with e > 0 lies in the row range [tile_ptr[t], tile_ptr[t+1]) of exactly one
 //    tile, t = (e-1)/T  (tile_ptr[t] is the last row with pointer <= t*T, so r > tile_ptr[t] iff
 //    e > t*T, and r < tile_ptr[t+1] iff e <= (t+1)*T); leading empty rows (e == 0) precede every
@@ -91,13 +92,6 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_row_scan(Geometry g, const int32_
         for (int t = a + lane; t <= b; t += OMEGA)
             atomicOr(&tile_ptr[t], (uint32_t)row);
     }
-    const int tile = e / T;
-    if (live && tile < g.p - 1) {
-        const int fl = (e / g.sigma) % OMEGA;
-        const int gbit = e % g.sigma + g.bit_all;
-        const size_t loc = (size_t)tile * OMEGA * g.num_packet + (size_t)(gbit >> 5) * OMEGA + fl;
-        atomicOr(&tile_desc[loc], 1u << (31 - (gbit & 31)));
-    }
     // Empty rows come in runs with the same pointer (R-MAT: half of all rows), i.e. the same target tile:
     // only the first lane of a run marks it.
     const int target = (live && e == e1 && e > 0) ? (e - 1) / T : -1;
@@ -112,7 +106,8 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_row_scan(Geometry g, const int32_
 //   y_off = exclusive wave prefix of segn, minus one for lanes > 0 (index into y_local)
 //   ss    = number of directly following lanes without any flag (scansum_offset)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(FMT_BLOCK) k_tile_desc(Geometry g, const uint32_t *__restrict__ tile_ptr,
+__global__ void __launch_bounds__(FMT_BLOCK) k_tile_desc(Geometry g, const int32_t *__restrict__ row_ptr,
+                                                     const uint32_t *__restrict__ tile_ptr,
                                                      uint32_t *__restrict__ tile_desc,
                                                      int32_t *__restrict__ offset_ptr, uint32_t *__restrict__ counters)
 {
@@ -124,15 +119,65 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_desc(Geometry g, const uint3
     const uint32_t raw = tile_ptr[t];
     const uint32_t row_start = raw & ROW_MASK;
     const uint32_t row_stop = tile_ptr[t + 1] & ROW_MASK;
-    if (row_start == row_stop) // fast-track tile keeps only its raw flags (format_cuda.h:187-189)
-        return;
 
+    // K4 (format_cuda.h:129-160 scatters one bit per row): the flags of this lane's sigma elements [lo, lo + sigma) =
+    // the DISTINCT row pointers inside that range.  Rows that start in the tile lie in [row_start, row_stop]; the lane
+    // bisects that slice (a few dozen entries, shared by the wavefront in L1) for its first row and hops from one distinct
+    // pointer to the next (runs of empty rows share a pointer).  Tiles 0..p-2 only: the last tile is processed from CSR and
+    // its descriptor stays zero, as in CSR5_avx2 format_avx2.h:98.
+    uint32_t w0 = 0, w1 = 0;
+    {
+        const int lo = t * g.tile_elems + lane * g.sigma, hi = lo + g.sigma;
+        // the tile's slice of row_ptr, staged in LDS when it is short (the usual case: ~T / mean row length entries)
+        constexpr int SLICE = 512;
+        __shared__ int32_t slice_all[FMT_WAVES_PER_BLOCK][SLICE];
+        int32_t *mine = slice_all[threadIdx.x >> 6];
+        const int nrows = (int)(row_stop - row_start) + 1;
+        const bool staged = nrows <= SLICE;
+        if (staged) {
+            for (int i = lane; i < nrows; i += OMEGA)
+                mine[i] = row_ptr[row_start + i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        auto rp_at = [&](int r) -> int { return staged ? mine[r - (int)row_start] : row_ptr[r]; };
+        // first row in [row_start, row_stop] whose pointer is >= `key` (row_stop + 1 if none)
+        auto first_at_least = [&](int from, int key) {
+            int a = from, b = (int)row_stop + 1;
+            while (a < b) {
+                const int mid = (int)(((unsigned)a + (unsigned)b) >> 1);
+                if (rp_at(mid) < key)
+                    a = mid + 1;
+                else
+                    b = mid;
+            }
+            return a;
+        };
+        int r = first_at_least((int)row_start, lo);
+        while (r <= (int)row_stop) {
+            const int e = rp_at(r);
+            if (e >= hi)
+                break;
+            const int gbit = e - lo + g.bit_all;
+            if (gbit < 32)
+                w0 |= 1u << (31 - gbit);
+            else
+                w1 |= 1u << (63 - gbit);
+            r = first_at_least(r + 1, e + 1);
+        }
+    }
     uint32_t *d = tile_desc + (size_t)t * OMEGA * g.num_packet;
-    uint32_t w0 = d[lane];
+    if (g.num_packet > 1)
+        d[OMEGA + lane] = w1;
+    if (row_start == row_stop) { // fast-track tile keeps only its raw flags (format_cuda.h:187-189)
+        d[lane] = w0;
+        return;
+    }
+
     // all flags of the lane, MSB first (element i -> bit 31-i); sigma <= 32 so one word holds them
     uint32_t flags = w0 << g.bit_all;
     if (g.num_packet > 1)
-        flags |= d[OMEGA + lane] >> (32 - g.bit_all);
+        flags |= w1 >> (32 - g.bit_all);
 
     const int f0 = (int)(flags >> 31) | (lane == 0);
     const int stop = __popc(flags & 0x7FFFFFFFu);
@@ -555,7 +600,7 @@ hipError_t launch_tile_desc(const Geometry &g, const DeviceArrays &d, hipStream_
 {
     if (g.p <= 1)
         return hipSuccess;
-    hipLaunchKernelGGL(k_tile_desc, dim3(div_up(g.p - 1, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g,
+    hipLaunchKernelGGL(k_tile_desc, dim3(div_up(g.p - 1, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
                        d.tile_ptr, d.tile_desc, d.offset_ptr, d.counters);
     return hipGetLastError();
 }

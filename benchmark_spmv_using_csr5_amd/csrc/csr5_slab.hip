@@ -144,6 +144,15 @@ k_slab_scatter(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *
     // phase 3: stable destination of every element + its row
     const int rs = (int)(tile_ptr[t] & ROW_MASK);
     const int re = (int)(tile_ptr[t + 1] & ROW_MASK);
+    // the row of element j = number of row pointers in (rs, re] that are <= j: the tile's slice of row_ptr is searched in
+    // LDS (a bisection of global memory per element was six dependent loads; a tile spans ~T / mean row length rows)
+    constexpr int ROWCAP = 1024;
+    __shared__ int32_t srow[ROWCAP];
+    const bool rows_in_lds = re - rs <= ROWCAP;
+    if (rows_in_lds)
+        for (int i = tid; i < re - rs; i += SLAB_BLOCK)
+            srow[i] = row_ptr[rs + 1 + i];
+    __syncthreads();
     for (int ch = wave; ch < nchunks; ch += SLAB_BLOCK / OMEGA) {
         const int c = ch * OMEGA + lane;
         const bool valid = c < E;
@@ -161,7 +170,7 @@ k_slab_scatter(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *
         if (valid) {
             const size_t dst = (size_t)off[ch * S + k] + rank;
             const int j = (int)(base + c);
-            const int row = rs + upper_bound_i32(row_ptr + rs + 1, j, re - rs);
+            const int row = rs + (rows_in_lds ? upper_bound_i32(srow, j, re - rs) : upper_bound_i32(row_ptr + rs + 1, j, re - rs));
             col2[dst] = scol[c];
             val2[dst] = sval[c];
             key2[dst] = ((unsigned long long)k << 32) | (unsigned)row;
