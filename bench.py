@@ -335,7 +335,8 @@ def roofline_dict(prob, ev_ms_per_step, wall_ms_per_step, extra=None):
         "launch_us": round(ev_ms_per_step * 1e3, 3),
         "cache": ("working set far beyond the 256-MiB Infinity Cache: every step streams from HBM"
                   if prob.b_alg > 2 * INFINITY_CACHE_BYTES else
-                  "WARM: the working set stays in the 256-MiB Infinity Cache between back-to-back steps (see `cold`)"),
+                  "WARM: the working set stays in the 256-MiB Infinity Cache between back-to-back steps (this figure is "
+                  "replaced by the COLD protocol's unless --no-cold)"),
     }
     if extra:
         d.update(extra)

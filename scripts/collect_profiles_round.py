@@ -42,7 +42,9 @@ with open(os.path.join(dst, f"{ROUND}_summary.md"), "w") as f:
     f.write(f"# {ROUND}: rocprofv3 summaries (MI355X, `scripts/gpu_profiles_round.sh`)\n\n"
             f"`{ROUND}_<run>_kernel_stats.csv` = `rocprofv3 --kernel-trace --stats` of `python bench.py --no-cpu-baseline --no-sub-configs <args>`.\n"
             "Step time (rocprof) = sum over the step's kernels (tile kernel [+ tail / range-finish launch] [+ slab combine]) of average duration.\n"
-            "traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per step from separate `--pmc` passes (counters only).\n\n"
+            "traffic = (2*FETCH_SIZE + WRITE_SIZE) KiB per step from separate `--pmc` passes (counters only).\n"
+            "Small workloads run with `--no-cold` here (one protocol per trace: cache-warm back-to-back steps); their HIP-event time under the\n"
+            "profiler carries its per-dispatch overhead (6-40 us kernels: +2 ... +14 us), the kernel's own average duration does not.\n\n"
             "| run | sigma | slabs / hot | dominant kernel | its avg us | step us (rocprof, all kernels) | HIP-event us/step (bench, same run) | B_alg MB | traffic MB | traffic / B_alg | frac of 8 TB/s (step, rocprof) | L2 hit |\n"
             "|---|---|---|---|---|---|---|---|---|---|---|---|\n")
     for tag, cfg, roof, e, main in rows:
