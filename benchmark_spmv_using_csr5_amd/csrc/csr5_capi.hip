@@ -763,6 +763,10 @@ static int build_slabs_impl(csr5hip_handle h)
     HIP_TRY(slab_scan_tmp_bytes((size_t)S_alloc * g.p, &scan_bytes));
     HIP_TRY(slab_select_tmp_bytes(g.nnz, &sel_bytes));
     const size_t nb = (size_t)(g.n > 0 ? g.n : 1) * 4, hb = (size_t)S_alloc * slab_hot_buckets() * 4;
+    int bits_alloc = 0;
+    while ((1 << bits_alloc) < S_alloc)
+        bits_alloc++;
+    const size_t hotmap_bytes = slab_hotmap_bytes(g.n, S_alloc, bits_alloc, h->slab_shift);
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
@@ -770,7 +774,7 @@ static int build_slabs_impl(csr5hip_handle h)
         return at;
     };
     const size_t o_hist = take((size_t)S_alloc * g.p * 4), o_scan = take(scan_bytes), o_key = take((size_t)g.nnz * 8),
-                 o_count = take(16), o_sel = take(sel_bytes), o_cnt = take(nb), o_hotmap = take(nb), o_chist = take(hb),
+                 o_count = take(16), o_sel = take(sel_bytes), o_cnt = take(nb), o_hotmap = take(hotmap_bytes), o_chist = take(hb),
                  o_thr = take((size_t)S_alloc * 4);
     if (h->slab_mem_mib > 0) {
         // second copy of column_index / value + build temporaries + (upper bound) one partial sum per non-zero row piece
@@ -817,12 +821,12 @@ static int build_slabs_impl(csr5hip_handle h)
         HIP_TRY(h->b_slab_off.reserve(((size_t)S + 1) * 4));
         HIP_TRY(h->b_lead.reserve((size_t)S * HOT_RANGES_PER_SLAB * h->vsize())); // one leading partial per wavefront range
         HIP_TRY(hipMemsetAsync(ht.cnt, 0, nb, s));
-        HIP_TRY(hipMemsetAsync(ht.hotmap, 0xFF, nb, s));
+        HIP_TRY(hipMemsetAsync(ht.hotmap, 0xFF, slab_hotmap_bytes(g.n, S, bits_hot, h->slab_shift), s));
         HIP_TRY(hipMemsetAsync(ht.chist, 0, (size_t)S * slab_hot_buckets() * 4, s));
         HIP_TRY(hipMemsetAsync(ht.covered, 0, 8, s));
         HIP_TRY(hipMemsetAsync(h->b_hot_cols.ptr, 0, (size_t)S * hot_capacity * 4, s));
         HIP_TRY(slab_hot_select(g.n, g.nnz, S, bits_hot, h->slab_shift, hot_capacity, min_count, stride,
-                                (const int32_t *)h->d.col, (uint32_t *)ht.cnt, (int32_t *)ht.hotmap, (uint32_t *)ht.chist,
+                                (const int32_t *)h->d.col, (uint32_t *)ht.cnt, (uint16_t *)ht.hotmap, (uint32_t *)ht.chist,
                                 (uint32_t *)ht.thr, (int32_t *)h->b_hot_cols.ptr, (int32_t *)h->b_hot_count.ptr,
                                 (unsigned long long *)ht.covered, s));
         unsigned long long covered = 0;
@@ -883,8 +887,8 @@ static int build_slabs_impl(csr5hip_handle h)
             load[best] += first_tile[k + 1] - first_tile[k];
         }
         HIP_TRY(hipMemcpyAsync((int32_t *)h->b_hot_tile0.ptr + S + 1, order.data(), (size_t)S * 4, hipMemcpyHostToDevice, s));
-        HIP_TRY(slab_hot_encode(g.nnz, hot_T, hot_p, S, (const int32_t *)h->b_slab_off.ptr,
-                                (const int32_t *)h->b_hot_tile0.ptr, (const int32_t *)ht.hotmap, (int32_t *)h->b_col2.ptr, s));
+        HIP_TRY(slab_hot_encode(g.n, g.nnz, hot_T, hot_p, S, bits, h->slab_shift, (const int32_t *)h->b_slab_off.ptr,
+                                (const uint16_t *)ht.hotmap, (int32_t *)h->b_col2.ptr, s));
     }
     HIP_TRY(hipStreamSynchronize(s)); // (`order` and the temporaries are in use until here)
 

@@ -47,6 +47,20 @@ __device__ __forceinline__ uint32_t slab_of(uint32_t col, int shift, int bits)
     return out;
 }
 
+// Columns of one slab, renumbered densely: the slab is the xor of all `bits`-wide groups of (col >> shift), so given the slab
+// the LOWEST group is determined by the others -- dropping it is a bijection from the slab's columns onto [0, L),
+// L = slab_local_count(n).  The hot map is stored slab after slab in these local ids: one slab's slice (2 bytes per column,
+// 2 MB for R-MAT 24 at 16 slabs) stays in the L2 of the XCD that encodes that slab, where a map indexed by the global
+// column (67 MB) missed L2 on every look-up.
+__host__ __device__ inline uint32_t slab_local(uint32_t col, int shift, int bits)
+{
+    return ((col >> (shift + bits)) << shift) | (col & ((1u << shift) - 1u));
+}
+__host__ __device__ inline size_t slab_local_count(int n, int shift, int bits)
+{
+    return ((size_t)(((uint32_t)(n > 0 ? n - 1 : 0)) >> (shift + bits)) + 1) << shift;
+}
+
 __device__ __forceinline__ int upper_bound_i32(const int32_t *__restrict__ a, int key, int size)
 {
     int lo = 0, hi = size;
@@ -520,7 +534,7 @@ constexpr int HOT_ASSIGN_COLS = 16384;
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_hot_assign(int n, const uint32_t *__restrict__ cnt, int bits, int shift, const uint32_t *__restrict__ thr,
              int capacity, int min_count, int pass, int32_t *__restrict__ hot_count, int32_t *__restrict__ hot_cols,
-             int32_t *__restrict__ hotmap, unsigned long long *__restrict__ covered)
+             uint16_t *__restrict__ hotmap, size_t L, unsigned long long *__restrict__ covered)
 {
     __shared__ int want[SLAB_MAX], base[SLAB_MAX], given[SLAB_MAX];
     if (threadIdx.x < SLAB_MAX)
@@ -551,7 +565,7 @@ k_hot_assign(int n, const uint32_t *__restrict__ cnt, int bits, int shift, const
             const int slot = base[k] + atomicAdd(&given[k], 1);
             if (slot < capacity) {
                 hot_cols[(size_t)k * capacity + slot] = c;
-                hotmap[c] = slot;
+                hotmap[(size_t)k * L + slab_local((uint32_t)c, shift, bits)] = (uint16_t)slot;
                 got += v;
             }
         }
@@ -580,37 +594,36 @@ k_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacity, const uint3
         hot_count[k] = capacity;
 }
 
+// Rewrites the column words of the stacked matrix whose column has a slot in its slab's table to 0x80000000 | slot.
+// Workgroup b runs on XCD b % 8 (observed placement, used for locality only): it takes elements of the slabs k = xcd,
+// xcd + 8, ... one slab after the other, so the look-ups of an XCD stay inside one 2-MB slice of the map at a time.
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_hot_encode(int nnz, int T, int p, int S, const int32_t *__restrict__ slab_off, const int32_t *__restrict__ tile0,
-             const int32_t *__restrict__ hotmap, int32_t *__restrict__ col2)
+k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *__restrict__ slab_off,
+             const uint16_t *__restrict__ hotmap, size_t L, int32_t *__restrict__ col2)
 {
     __shared__ int32_t soff[SLAB_MAX + 1];
     if ((int)threadIdx.x <= S)
         soff[threadIdx.x] = slab_off[threadIdx.x];
     __syncthreads();
-    const size_t pos = (size_t)blockIdx.x * SLAB_BLOCK + threadIdx.x;
-    if (pos >= (size_t)nnz)
-        return;
-    const int t = (int)(pos / T);
-    if (t >= p - 1)
-        return; // the CSR tail is processed by the ordinary kernel: plain column words
-    auto slab_at = [&](long long q) { // largest k with slab_off[k] <= q
-        int lo = 0, hi = S;
-        while (lo + 1 < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((long long)soff[mid] <= q)
-                lo = mid;
-            else
-                hi = mid;
+    const int xcd = blockIdx.x % NUM_XCD, j = blockIdx.x / NUM_XCD, nj = gridDim.x / NUM_XCD;
+    const long long last = (long long)(p - 1) * T; // the CSR tail is processed from CSR: plain column words
+    for (int mine = xcd; mine < S; mine += NUM_XCD) {
+        const uint16_t *map = hotmap + (size_t)mine * L;
+        long long end = soff[mine + 1];
+        end = end < last ? end : last;
+        for (long long pos = (long long)soff[mine] + (long long)j * SLAB_BLOCK + threadIdx.x; pos < end;
+             pos += (long long)nj * SLAB_BLOCK) {
+            const long long t = pos / T;
+            // an element inside a tile owned by the PREVIOUS slab (a tile belongs to the slab of its first element) is
+            // gathered with that slab's table in LDS: it keeps its plain word
+            if (t * T < (long long)soff[mine])
+                continue;
+            const int32_t c = col2[pos];
+            const uint16_t h = map[slab_local((uint32_t)c, shift, bits)];
+            if (h != 0xFFFFu)
+                col2[pos] = (int32_t)(0x80000000u | (uint32_t)h);
         }
-        return lo;
-    };
-    const int mine = slab_at((long long)pos);
-    if (slab_at((long long)t * T) != mine)
-        return; // element of the NEXT slab inside a tile owned by the previous one: that tile holds another table
-    const int h = hotmap[(uint32_t)col2[pos]];
-    if (h >= 0)
-        col2[pos] = (int32_t)(0x80000000u | (uint32_t)h);
+    }
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
@@ -724,7 +737,7 @@ namespace csr5 {
 // can still change the slab count.  cnt, hotmap, chist, thr: caller-provided scratch (n, n, S*HOT_BUCKETS, S words; cnt
 // and chist zeroed, hotmap filled with 0xFF by the caller).
 hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capacity, int min_count, int sample_stride,
-                           const int32_t *col, uint32_t *cnt, int32_t *hotmap, uint32_t *chist, uint32_t *thr,
+                           const int32_t *col, uint32_t *cnt, uint16_t *hotmap, uint32_t *chist, uint32_t *thr,
                            int32_t *hot_cols, int32_t *hot_count, unsigned long long *covered, hipStream_t s)
 {
     long long blocks = ((long long)nnz / sample_stride + SLAB_BLOCK * 8 - 1) / (SLAB_BLOCK * 8);
@@ -739,7 +752,8 @@ hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capac
     hipLaunchKernelGGL(k_hot_threshold, dim3(S), dim3(OMEGA), 0, s, capacity, min_count, chist, thr);
     for (int pass = 0; pass < 2; pass++)
         hipLaunchKernelGGL(k_hot_assign, dim3((n + HOT_ASSIGN_COLS - 1) / HOT_ASSIGN_COLS), dim3(SLAB_BLOCK), 0, s, n, cnt, bits,
-                           shift, thr, capacity, min_count, pass, hot_count, hot_cols, hotmap, covered);
+                           shift, thr, capacity, min_count, pass, hot_count, hot_cols, hotmap, slab_local_count(n, shift, bits),
+                           covered);
     return hipGetLastError();
 }
 
@@ -753,13 +767,15 @@ hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacit
     return hipGetLastError();
 }
 
-hipError_t slab_hot_encode(int nnz, int T, int p, int S, const int32_t *slab_off, const int32_t *tile0,
-                           const int32_t *hotmap, int32_t *col2, hipStream_t s)
+hipError_t slab_hot_encode(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
+                           const uint16_t *hotmap, int32_t *col2, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_hot_encode, dim3((unsigned)(((size_t)nnz + SLAB_BLOCK - 1) / SLAB_BLOCK)), dim3(SLAB_BLOCK), 0, s,
-                       nnz, T, p, S, slab_off, tile0, hotmap, col2);
+    hipLaunchKernelGGL(k_hot_encode, dim3(NUM_XCD * 512), dim3(SLAB_BLOCK), 0, s, nnz, T, p, S, bits, shift, slab_off, hotmap,
+                       slab_local_count(n, shift, bits), col2);
     return hipGetLastError();
 }
+
+size_t slab_hotmap_bytes(int n, int S, int bits, int shift) { return (size_t)S * slab_local_count(n, shift, bits) * 2 + 256; }
 
 int slab_hot_buckets() { return HOT_BUCKETS; }
 
