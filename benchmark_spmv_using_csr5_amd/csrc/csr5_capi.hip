@@ -773,7 +773,7 @@ static int build_slabs_impl(csr5hip_handle h)
         off += (bytes + 255) & ~(size_t)255;
         return at;
     };
-    const size_t o_hist = take((size_t)S_alloc * g.p * 4), o_scan = take(scan_bytes), o_key = take((size_t)g.nnz * 8),
+    const size_t o_hist = take((size_t)S_alloc * g.p * 4), o_scan = take(scan_bytes), o_key = take((size_t)g.nnz * 4),
                  o_count = take(16), o_sel = take(sel_bytes), o_cnt = take(nb), o_hotmap = take(hotmap_bytes), o_chist = take(hb),
                  o_thr = take((size_t)S_alloc * 4);
     if (h->slab_mem_mib > 0) {
@@ -784,7 +784,7 @@ static int build_slabs_impl(csr5hip_handle h)
             return fail_hip(hipErrorOutOfMemory, "column slabs: CSR5HIP_OPT_SLAB_MEMORY_MIB");
     }
     HIP_TRY(h->b_slab_tmp.reserve(off));
-    struct TmpGuard { // very big temporaries (8 B per non-zero) do not outlive the build
+    struct TmpGuard { // very big temporaries (4 B per non-zero) do not outlive the build
         Buffer &b;
         size_t keep;
         ~TmpGuard()
@@ -821,12 +821,12 @@ static int build_slabs_impl(csr5hip_handle h)
         HIP_TRY(h->b_slab_off.reserve(((size_t)S + 1) * 4));
         HIP_TRY(h->b_lead.reserve((size_t)S * HOT_RANGES_PER_SLAB * h->vsize())); // one leading partial per wavefront range
         HIP_TRY(hipMemsetAsync(ht.cnt, 0, nb, s));
-        HIP_TRY(hipMemsetAsync(ht.hotmap, 0xFF, slab_hotmap_bytes(g.n, S, bits_hot, h->slab_shift), s));
+        HIP_TRY(hipMemsetAsync(ht.hotmap, 0, slab_hotmap_bytes(g.n, S, bits_hot, h->slab_shift), s));
         HIP_TRY(hipMemsetAsync(ht.chist, 0, (size_t)S * slab_hot_buckets() * 4, s));
         HIP_TRY(hipMemsetAsync(ht.covered, 0, 8, s));
         HIP_TRY(hipMemsetAsync(h->b_hot_cols.ptr, 0, (size_t)S * hot_capacity * 4, s));
         HIP_TRY(slab_hot_select(g.n, g.nnz, S, bits_hot, h->slab_shift, hot_capacity, min_count, stride,
-                                (const int32_t *)h->d.col, (uint32_t *)ht.cnt, (uint16_t *)ht.hotmap, (uint32_t *)ht.chist,
+                                (const int32_t *)h->d.col, (uint32_t *)ht.cnt, ht.hotmap, (uint32_t *)ht.chist,
                                 (uint32_t *)ht.thr, (int32_t *)h->b_hot_cols.ptr, (int32_t *)h->b_hot_count.ptr,
                                 (unsigned long long *)ht.covered, s));
         unsigned long long covered = 0;
@@ -846,18 +846,18 @@ static int build_slabs_impl(csr5hip_handle h)
     HIP_TRY(h->b_col2.reserve((size_t)g.nnz * 4));
     HIP_TRY(h->b_val2.reserve((size_t)g.nnz * h->vsize()));
     HIP_TRY(slab_partition(g, h->d, h->value_type, S, bits, h->slab_shift, (uint32_t *)t.hist, t.scan_tmp, scan_bytes,
-                           (int32_t *)h->b_col2.ptr, h->b_val2.ptr, (unsigned long long *)t.key, s));
-    HIP_TRY(slab_count_segments(g.nnz, (const unsigned long long *)t.key, t.sel_tmp, (unsigned int *)t.count, s));
+                           (int32_t *)h->b_col2.ptr, h->b_val2.ptr, (uint32_t *)t.key, s));
+    HIP_TRY(slab_count_segments(g.nnz, (const uint32_t *)t.key, t.sel_tmp, (unsigned int *)t.count, s));
     unsigned int m2 = 0;
     HIP_TRY(hipMemcpyAsync(&m2, t.count, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(h->b_row_ptr2.reserve(((size_t)m2 + 1) * 4));
-    HIP_TRY(slab_segments(g.nnz, (const unsigned long long *)t.key, t.sel_tmp, (int32_t *)h->b_row_ptr2.ptr, s));
+    HIP_TRY(slab_segments(g.nnz, (const uint32_t *)t.key, t.sel_tmp, (int32_t *)h->b_row_ptr2.ptr, s));
     HIP_TRY(h->b_rowidx.reserve((size_t)m2 + 1));
     HIP_TRY(h->b_base.reserve(slab_base_words(g.m, S) * 4));
     HIP_TRY(h->b_nonempty.reserve(((size_t)g.m / 32 + 16) * 4));
-    HIP_TRY(slab_tables(g.m, (int)m2, g.nnz, S, h->d.row_ptr, (int32_t *)h->b_row_ptr2.ptr, (const unsigned long long *)t.key,
-                        (unsigned char *)h->b_rowidx.ptr, (uint32_t *)h->b_base.ptr, (uint32_t *)h->b_nonempty.ptr, s));
+    HIP_TRY(slab_tables(g.m, (int)m2, g.nnz, S, g.p, h->d.row_ptr, (int32_t *)h->b_row_ptr2.ptr, (const uint32_t *)t.key,
+                        (const uint32_t *)t.hist, (unsigned char *)h->b_rowidx.ptr, (uint32_t *)h->b_base.ptr, (uint32_t *)h->b_nonempty.ptr, s));
     HIP_TRY(h->b_P.reserve(((size_t)m2 + 1) * h->vsize()));
     HIP_TRY(hipMemsetAsync(h->b_P.ptr, 0, ((size_t)m2 + 1) * h->vsize(), s));
 
@@ -888,7 +888,7 @@ static int build_slabs_impl(csr5hip_handle h)
         }
         HIP_TRY(hipMemcpyAsync((int32_t *)h->b_hot_tile0.ptr + S + 1, order.data(), (size_t)S * 4, hipMemcpyHostToDevice, s));
         HIP_TRY(slab_hot_encode(g.n, g.nnz, hot_T, hot_p, S, bits, h->slab_shift, (const int32_t *)h->b_slab_off.ptr,
-                                (const uint16_t *)ht.hotmap, (int32_t *)h->b_col2.ptr, s));
+                                ht.hotmap, (int32_t *)h->b_col2.ptr, s));
     }
     HIP_TRY(hipStreamSynchronize(s)); // (`order` and the temporaries are in use until here)
 

@@ -98,20 +98,20 @@ hipError_t slab_scan_tmp_bytes(size_t items, size_t *bytes);
 hipError_t slab_select_tmp_bytes(int nnz, size_t *bytes);
 hipError_t slab_partition(const Geometry &g, const DeviceArrays &d, int value_type, int S, int bits, int shift,
                           uint32_t *hist, void *scan_tmp, size_t scan_tmp_bytes, int32_t *col2, void *val2,
-                          unsigned long long *key2, hipStream_t s);
-hipError_t slab_count_segments(int nnz, const unsigned long long *key2, void *tmp, unsigned int *d_count, hipStream_t s);
-hipError_t slab_segments(int nnz, const unsigned long long *key2, const void *tmp, int32_t *row_ptr2, hipStream_t s);
+                          uint32_t *key2, hipStream_t s);
+hipError_t slab_count_segments(int nnz, const uint32_t *key2, void *tmp, unsigned int *d_count, hipStream_t s);
+hipError_t slab_segments(int nnz, const uint32_t *key2, const void *tmp, int32_t *row_ptr2, hipStream_t s);
 size_t slab_base_words(int m, int S);
-hipError_t slab_tables(int m, int m2, int nnz, int S, const int32_t *row_ptr, int32_t *row_ptr2, const unsigned long long *key2,
-                       unsigned char *rowidx, uint32_t *base, uint32_t *nonempty, hipStream_t s);
+hipError_t slab_tables(int m, int m2, int nnz, int S, int p, const int32_t *row_ptr, int32_t *row_ptr2, const uint32_t *key2,
+                       const uint32_t *chunk_start, unsigned char *rowidx, uint32_t *base, uint32_t *nonempty, hipStream_t s);
 hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capacity, int min_count, int sample_stride,
-                           const int32_t *col, uint32_t *cnt, uint16_t *hotmap, uint32_t *chist, uint32_t *thr,
+                           const int32_t *col, uint32_t *cnt, void *hotmap, uint32_t *chist, uint32_t *thr,
                            int32_t *hot_cols, int32_t *hot_count, unsigned long long *covered, hipStream_t s);
 hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacity, const uint32_t *chunk_start,
                            int32_t *hot_count, int32_t *tile0, int32_t *slab_off, hipStream_t s);
 hipError_t slab_hot_encode(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
-                           const uint16_t *hotmap, int32_t *col2, hipStream_t s);
-size_t slab_hotmap_bytes(int n, int S, int bits, int shift); // slab-major map of table slots, 2 bytes per (slab-local) column
+                           const void *hotmap, int32_t *col2, hipStream_t s);
+size_t slab_hotmap_bytes(int n, int S, int bits, int shift); // slab-major bitmap of the hot columns + group prefixes
 int slab_hot_buckets();
 hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int value_type, const uint32_t *base,
                                const unsigned char *rowidx, const uint32_t *nonempty, const void *P, int segments, void *y,

@@ -35,6 +35,7 @@ namespace csr5 {
 
 constexpr int SLAB_BLOCK = 256;
 constexpr int SLAB_MAX = 64;
+constexpr uint32_t SLAB_KEY_FIRST = 0x80000000u; // key bit: first element of a slab
 
 __device__ __forceinline__ uint32_t slab_of(uint32_t col, int shift, int bits)
 {
@@ -49,9 +50,11 @@ __device__ __forceinline__ uint32_t slab_of(uint32_t col, int shift, int bits)
 
 // Columns of one slab, renumbered densely: the slab is the xor of all `bits`-wide groups of (col >> shift), so given the slab
 // the LOWEST group is determined by the others -- dropping it is a bijection from the slab's columns onto [0, L),
-// L = slab_local_count(n).  The hot map is stored slab after slab in these local ids: one slab's slice (2 bytes per column,
-// 2 MB for R-MAT 24 at 16 slabs) stays in the L2 of the XCD that encodes that slab, where a map indexed by the global
-// column (67 MB) missed L2 on every look-up.
+// L = slab_local_count(n).  The hot map is stored slab after slab in these local ids, as a BITMAP (bit = the column owns a
+// table slot) plus the number of set bits in front of every 128-bit group: slots are handed out in column order, so the
+// slot of a hot column is that prefix + the set bits below it in its group.  One slab's slice is 18 bytes per 128 columns
+// (144 KB for R-MAT 24 at 16 slabs): k_hot_encode keeps it in LDS.  (A map of 2 bytes per column cost one L1 line fill
+// per non-zero: 1.7 ms on R-MAT 24.)
 __host__ __device__ inline uint32_t slab_local(uint32_t col, int shift, int bits)
 {
     return ((col >> (shift + bits)) << shift) | (col & ((1u << shift) - 1u));
@@ -59,6 +62,25 @@ __host__ __device__ inline uint32_t slab_local(uint32_t col, int shift, int bits
 __host__ __device__ inline size_t slab_local_count(int n, int shift, int bits)
 {
     return ((size_t)(((uint32_t)(n > 0 ? n - 1 : 0)) >> (shift + bits)) + 1) << shift;
+}
+// the column of slab k with local id `local` (inverse of slab_local on that slab)
+__device__ __forceinline__ uint32_t slab_column(uint32_t k, uint32_t local, int shift, int bits)
+{
+    const uint32_t hi = local >> shift, lo = local & ((1u << shift) - 1u);
+    const uint32_t low_group = k ^ slab_of(hi << shift, shift, bits); // xor of the groups above the lowest one
+    return (hi << (shift + bits)) | (low_group << shift) | lo;
+}
+// 128-bit groups of one slab's bitmap
+__host__ __device__ inline size_t slab_hot_groups(int n, int shift, int bits) { return (slab_local_count(n, shift, bits) + 127) / 128; }
+// set bits of a group below position `bit`, and whether `bit` itself is set
+__device__ __forceinline__ bool hot_lookup(const uint4 w, uint32_t bit, uint32_t &below)
+{
+    const unsigned long long lo = (unsigned long long)w.x | ((unsigned long long)w.y << 32);
+    const unsigned long long hi = (unsigned long long)w.z | ((unsigned long long)w.w << 32);
+    const unsigned long long word = bit < 64 ? lo : hi;
+    const uint32_t b = bit & 63;
+    below = (uint32_t)__popcll(word & ((1ull << b) - 1ull)) + (bit < 64 ? 0u : (uint32_t)__popcll(lo));
+    return (word >> b) & 1ull;
 }
 
 __device__ __forceinline__ int upper_bound_i32(const int32_t *__restrict__ a, int key, int size)
@@ -103,7 +125,7 @@ __global__ void __launch_bounds__(SLAB_BLOCK)
 k_slab_scatter(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ tile_ptr,
                const int32_t *__restrict__ col, const VT *__restrict__ val, int S, int bits, int shift,
                const uint32_t *__restrict__ chunk_start, int32_t *__restrict__ col2, VT *__restrict__ val2,
-               unsigned long long *__restrict__ key2)
+               uint32_t *__restrict__ key2)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int T = g.tile_elems;
@@ -162,10 +184,13 @@ k_slab_scatter(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *
     // LDS (a bisection of global memory per element was six dependent loads; a tile spans ~T / mean row length rows)
     constexpr int ROWCAP = 1024;
     __shared__ int32_t srow[ROWCAP];
+    __shared__ uint32_t slab_first[SLAB_MAX];
     const bool rows_in_lds = re - rs <= ROWCAP;
     if (rows_in_lds)
         for (int i = tid; i < re - rs; i += SLAB_BLOCK)
             srow[i] = row_ptr[rs + 1 + i];
+    if (tid < S)
+        slab_first[tid] = chunk_start[(size_t)tid * g.p]; // where slab tid begins in the child
     __syncthreads();
     for (int ch = wave; ch < nchunks; ch += SLAB_BLOCK / OMEGA) {
         const int c = ch * OMEGA + lane;
@@ -187,12 +212,22 @@ k_slab_scatter(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *
             const int row = rs + (rows_in_lds ? upper_bound_i32(srow, j, re - rs) : upper_bound_i32(row_ptr + rs + 1, j, re - rs));
             col2[dst] = scol[c];
             val2[dst] = sval[c];
-            key2[dst] = ((unsigned long long)k << 32) | (unsigned)row;
+            key2[dst] = (uint32_t)row | (dst == slab_first[k] ? SLAB_KEY_FIRST : 0u);
         }
     }
 }
 
-// Segment starts (positions j with key[j] != key[j-1]) -> row_ptr' in three small steps on a fixed partition of the keys
+// The key of a child element: its parent row, bit 31 set on the first element of every slab (one word per non-zero; the
+// slab itself is implied by the position).  A segment starts where the row changes or a slab begins.
+__device__ __forceinline__ bool segment_starts(const uint32_t *__restrict__ key, long long j)
+{
+    if (j == 0)
+        return true;
+    const uint32_t a = key[j], b = key[j - 1];
+    return (a & SLAB_KEY_FIRST) != 0 || ((a ^ b) & ~SLAB_KEY_FIRST) != 0;
+}
+
+// Segment starts -> row_ptr' in three small steps on a fixed partition of the keys
 // into <= SEG_BLOCKS chunks: per-chunk counts (no atomics), one-workgroup scan of the counts (also the total m'), then
 // every chunk re-reads its keys and writes its starts behind its offset (ballot ranks, no atomics).  rocprim::select on
 // a counting iterator did this in 4.8 ms on R-MAT 24 after a 3.0-ms counting pass; the two passes here read the keys
@@ -210,14 +245,14 @@ static int seg_blocks(int nnz)
 }
 
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_slab_count_segments(int nnz, const unsigned long long *__restrict__ key, unsigned int *__restrict__ block_count)
+k_slab_count_segments(int nnz, const uint32_t *__restrict__ key, unsigned int *__restrict__ block_count)
 {
     __shared__ unsigned part[SLAB_BLOCK / OMEGA];
     const long long chunk = seg_chunk(nnz, gridDim.x);
     const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < nnz ? lo + chunk : nnz;
     unsigned local = 0;
     for (long long j = lo + threadIdx.x; j < hi; j += SLAB_BLOCK)
-        local += j == 0 || key[j] != key[j - 1];
+        local += segment_starts(key, j);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         local += __shfl_xor(local, d, OMEGA);
@@ -270,7 +305,7 @@ __global__ void __launch_bounds__(1024) k_slab_scan_counts(int blocks, unsigned 
 }
 
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_slab_emit_segments(int nnz, const unsigned long long *__restrict__ key, const unsigned int *__restrict__ block_offset,
+k_slab_emit_segments(int nnz, const uint32_t *__restrict__ key, const unsigned int *__restrict__ block_offset,
                      int32_t *__restrict__ row_ptr2)
 {
     __shared__ unsigned wave_count[SLAB_BLOCK / OMEGA];
@@ -280,7 +315,7 @@ k_slab_emit_segments(int nnz, const unsigned long long *__restrict__ key, const 
     unsigned out = block_offset[blockIdx.x];
     for (long long j0 = lo; j0 < hi; j0 += SLAB_BLOCK) { // (chunk is a multiple of the workgroup size: uniform trip count)
         const long long j = j0 + threadIdx.x;
-        const bool start = j < hi && (j == 0 || key[j] != key[j - 1]);
+        const bool start = j < hi && segment_starts(key, j);
         const unsigned long long b = __ballot(start);
         if (lane == 0)
             wave_count[w] = (unsigned)__popcll(b);
@@ -302,7 +337,7 @@ constexpr int COMBINE_ROWS = 256;
 
 // one thread per segment s: its row inside the row block (one byte); thread 0 also closes row_ptr'
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_slab_rowidx(int m2, int nnz, const int32_t *__restrict__ row_ptr2, const unsigned long long *__restrict__ key,
+k_slab_rowidx(int m2, int nnz, const int32_t *__restrict__ row_ptr2, const uint32_t *__restrict__ key,
               unsigned char *__restrict__ rowidx, int32_t *__restrict__ row_ptr2_end)
 {
     const int s = blockIdx.x * SLAB_BLOCK + threadIdx.x;
@@ -310,25 +345,40 @@ k_slab_rowidx(int m2, int nnz, const int32_t *__restrict__ row_ptr2, const unsig
         *row_ptr2_end = nnz; // row_ptr'[m'] (the segment pass wrote the m' starts)
     if (s >= m2)
         return;
-    rowidx[s] = (unsigned char)((uint32_t)key[row_ptr2[s]] & (COMBINE_ROWS - 1));
+    rowidx[s] = (unsigned char)(key[row_ptr2[s]] & (COMBINE_ROWS - 1));
 }
 
 // base[b * S + k] = first segment whose (slab, row block) is >= (k, b): the segments are sorted by (slab, row), so the
 // partials of (block b, slab k) are P[base[b][k] .. base[b + 1][k]); entry b = nblk of slab k is the first segment of
-// slab k + 1.  One thread per entry, a binary search each (no atomics, no serial gap filling).
+// slab k + 1.  One thread per entry: the workgroup first finds the segment range of every slab (the first segment at or
+// after the slab's first element), then every thread bisects its slab's range by row (no atomics, no serial gap filling).
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_slab_base(int m2, int S, int nblk, const int32_t *__restrict__ row_ptr2, const unsigned long long *__restrict__ key,
-            uint32_t *__restrict__ base)
+k_slab_base(int m2, int nnz, int S, int nblk, const int32_t *__restrict__ row_ptr2, const uint32_t *__restrict__ key,
+            const uint32_t *__restrict__ chunk_start, int p, uint32_t *__restrict__ base)
 {
+    __shared__ int slab_seg[SLAB_MAX + 1];
+    if ((int)threadIdx.x <= S) {
+        const uint32_t first = (int)threadIdx.x < S ? chunk_start[(size_t)threadIdx.x * p] : (uint32_t)nnz;
+        int lo = 0, hi = m2;
+        while (lo < hi) {
+            const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+            if ((uint32_t)row_ptr2[mid] < first)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        slab_seg[threadIdx.x] = lo;
+    }
+    __syncthreads();
     const long long e = (long long)blockIdx.x * SLAB_BLOCK + threadIdx.x;
     if (e >= (long long)(nblk + 1) * S)
         return;
     const int b = (int)(e / S), k = (int)(e % S);
-    const unsigned long long want = ((unsigned long long)k << 32) | ((unsigned long long)b * COMBINE_ROWS);
-    int lo = 0, hi = m2; // first segment with key >= want (a block index of nblk is beyond every row of slab k)
+    const uint32_t want = (uint32_t)b * COMBINE_ROWS; // (a block index of nblk is beyond every row)
+    int lo = slab_seg[k], hi = slab_seg[k + 1];
     while (lo < hi) {
         const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
-        if (key[row_ptr2[mid]] < want)
+        if ((key[row_ptr2[mid]] & ~SLAB_KEY_FIRST) < want)
             lo = mid + 1;
         else
             hi = mid;
@@ -526,15 +576,15 @@ k_hot_threshold(int capacity, int min_count, const uint32_t *__restrict__ chist,
         thr[blockIdx.x] = (uint32_t)best;
 }
 
-// pass 0: every column with count >= thr gets a slot; pass 1: columns of the next lower count fill what is left.
+// pass 0: every column with count >= thr is marked hot; pass 1: columns of the next lower count fill what is left.
 // A workgroup walks HOT_ASSIGN_COLS columns twice: first it counts the slots it wants per slab (LDS), reserves them with
 // ONE global add per slab, then hands them out from LDS counters (196 k adds on 16 words -- one per chosen column -- took
 // 0.9 ms per pass on R-MAT 24).
 constexpr int HOT_ASSIGN_COLS = 16384;
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_hot_assign(int n, const uint32_t *__restrict__ cnt, int bits, int shift, const uint32_t *__restrict__ thr,
-             int capacity, int min_count, int pass, int32_t *__restrict__ hot_count, int32_t *__restrict__ hot_cols,
-             uint16_t *__restrict__ hotmap, size_t L, unsigned long long *__restrict__ covered)
+             int capacity, int min_count, int pass, int32_t *__restrict__ hot_count, uint32_t *__restrict__ hotbits,
+             size_t G, unsigned long long *__restrict__ covered)
 {
     __shared__ int want[SLAB_MAX], base[SLAB_MAX], given[SLAB_MAX];
     if (threadIdx.x < SLAB_MAX)
@@ -563,9 +613,9 @@ k_hot_assign(int n, const uint32_t *__restrict__ cnt, int bits, int shift, const
     for (int c = first + (int)threadIdx.x; c < last; c += SLAB_BLOCK)
         if (chosen(c, k, v)) {
             const int slot = base[k] + atomicAdd(&given[k], 1);
-            if (slot < capacity) {
-                hot_cols[(size_t)k * capacity + slot] = c;
-                hotmap[(size_t)k * L + slab_local((uint32_t)c, shift, bits)] = (uint16_t)slot;
+            if (slot < capacity) { // (the count decides WHETHER the column gets a slot; k_hot_rank decides which)
+                const uint32_t local = slab_local((uint32_t)c, shift, bits);
+                atomicOr(&hotbits[(size_t)k * G * 4 + (local >> 5)], 1u << (local & 31));
                 got += v;
             }
         }
@@ -594,13 +644,73 @@ k_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacity, const uint3
         hot_count[k] = capacity;
 }
 
-// Rewrites the column words of the stacked matrix whose column has a slot in its slab's table to 0x80000000 | slot.
-// Workgroup b runs on XCD b % 8 (observed placement, used for locality only): it takes elements of the slabs k = xcd,
-// xcd + 8, ... one slab after the other, so the look-ups of an XCD stay inside one 2-MB slice of the map at a time.
-__global__ void __launch_bounds__(SLAB_BLOCK)
-k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *__restrict__ slab_off,
-             const uint16_t *__restrict__ hotmap, size_t L, int32_t *__restrict__ col2)
+// One workgroup per slab: slots in column order.  pre[g] = slot of the first hot column of group g (slot 0 is reserved,
+// so the count starts at 1), hot_cols[slot] = column.
+constexpr int RANK_BLOCK = 1024;
+__global__ void __launch_bounds__(RANK_BLOCK)
+k_hot_rank(int bits, int shift, int capacity, size_t G, const uint4 *__restrict__ hotbits, uint16_t *__restrict__ pre,
+           int32_t *__restrict__ hot_cols)
 {
+    __shared__ uint32_t wave_total[RANK_BLOCK / OMEGA];
+    const uint32_t k = blockIdx.x;
+    const int lane = threadIdx.x & (OMEGA - 1), w = threadIdx.x / OMEGA;
+    uint32_t running = 1;
+    for (size_t g0 = 0; g0 < G; g0 += RANK_BLOCK) {
+        const size_t g = g0 + threadIdx.x;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (g < G)
+            v = hotbits[(size_t)k * G + g];
+        const uint32_t own = (uint32_t)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w));
+        uint32_t incl = own;
+#pragma unroll
+        for (int d = 1; d < OMEGA; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, OMEGA);
+            if (lane >= d)
+                incl += o;
+        }
+        if (lane == OMEGA - 1)
+            wave_total[w] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (int i = 0; i < RANK_BLOCK / OMEGA; i++) {
+            before += i < w ? wave_total[i] : 0u;
+            all += wave_total[i];
+        }
+        uint32_t slot = running + before + incl - own;
+        if (g < G) {
+            pre[(size_t)k * G + g] = (uint16_t)slot;
+            const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t m = word[i];
+                while (m) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1;
+                    if ((int)slot < capacity)
+                        hot_cols[(size_t)k * capacity + slot] = (int32_t)slab_column(k, (uint32_t)g * 128u + i * 32u + b, shift, bits);
+                    slot++;
+                }
+            }
+        }
+        running += all;
+        __syncthreads();
+    }
+}
+
+// Rewrites the column words of the stacked matrix whose column has a slot in its slab's table to 0x80000000 | slot.
+// Persistent: workgroup b runs on XCD b % 8 (observed placement, used for locality only) and takes the slabs k = xcd,
+// xcd + 8, ... one after the other; per slab it stages the slab's bitmap and group prefixes in LDS (IN_LDS; a slab with
+// more than ~1.1 M columns reads them from memory instead) and streams its share of the slab's column words, four per
+// lane and load.
+constexpr int ENCODE_BLOCK = 1024, ENCODE_WGS_PER_XCD = 32, ENCODE_UNROLL = 4;
+template <bool IN_LDS>
+__global__ void __launch_bounds__(ENCODE_BLOCK)
+k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *__restrict__ slab_off,
+             const uint4 *__restrict__ hotbits, const uint16_t *__restrict__ hotpre, size_t G, int32_t *__restrict__ col2)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint4 *lbits = reinterpret_cast<uint4 *>(smem);
+    uint16_t *lpre = reinterpret_cast<uint16_t *>(smem + G * sizeof(uint4));
     __shared__ int32_t soff[SLAB_MAX + 1];
     if ((int)threadIdx.x <= S)
         soff[threadIdx.x] = slab_off[threadIdx.x];
@@ -608,20 +718,56 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
     const int xcd = blockIdx.x % NUM_XCD, j = blockIdx.x / NUM_XCD, nj = gridDim.x / NUM_XCD;
     const long long last = (long long)(p - 1) * T; // the CSR tail is processed from CSR: plain column words
     for (int mine = xcd; mine < S; mine += NUM_XCD) {
-        const uint16_t *map = hotmap + (size_t)mine * L;
+        const uint4 *gb = hotbits + (size_t)mine * G;
+        const uint16_t *gp = hotpre + (size_t)mine * G;
+        if (IN_LDS) {
+            __syncthreads(); // (the previous slab's look-ups are done)
+            for (size_t g = threadIdx.x; g < G; g += ENCODE_BLOCK) {
+                lbits[g] = gb[g];
+                lpre[g] = gp[g];
+            }
+            __syncthreads();
+        }
+        auto encode = [&](int32_t c) -> int32_t {
+            const uint32_t local = slab_local((uint32_t)c, shift, bits);
+            const uint32_t g = local >> 7;
+            uint32_t below;
+            const bool hot = hot_lookup(IN_LDS ? lbits[g] : gb[g], local & 127u, below);
+            return hot ? (int32_t)(0x80000000u | ((uint32_t)(IN_LDS ? lpre[g] : gp[g]) + below)) : c;
+        };
+        // An element inside a tile owned by the PREVIOUS slab (a tile belongs to the slab of its first element) is gathered
+        // with that slab's table in LDS: it keeps its plain word.  So the slab's share starts at its first own tile.
+        const long long begin = ((long long)soff[mine] + T - 1) / T * T;
         long long end = soff[mine + 1];
         end = end < last ? end : last;
-        for (long long pos = (long long)soff[mine] + (long long)j * SLAB_BLOCK + threadIdx.x; pos < end;
-             pos += (long long)nj * SLAB_BLOCK) {
-            const long long t = pos / T;
-            // an element inside a tile owned by the PREVIOUS slab (a tile belongs to the slab of its first element) is
-            // gathered with that slab's table in LDS: it keeps its plain word
-            if (t * T < (long long)soff[mine])
-                continue;
-            const int32_t c = col2[pos];
-            const uint16_t h = map[slab_local((uint32_t)c, shift, bits)];
-            if (h != 0xFFFFu)
-                col2[pos] = (int32_t)(0x80000000u | (uint32_t)h);
+        if (begin >= end)
+            continue;
+        int4 *c4 = reinterpret_cast<int4 *>(col2 + begin); // (T is a multiple of 64: 16-byte aligned)
+        const long long quads = (end - begin) / 4;
+        for (long long q0 = (long long)j * ENCODE_BLOCK * ENCODE_UNROLL; q0 < quads;
+             q0 += (long long)nj * ENCODE_BLOCK * ENCODE_UNROLL) {
+            int4 v[ENCODE_UNROLL];
+#pragma unroll
+            for (int u = 0; u < ENCODE_UNROLL; u++) {
+                const long long q = q0 + u * ENCODE_BLOCK + threadIdx.x;
+                if (q < quads)
+                    v[u] = c4[q];
+            }
+#pragma unroll
+            for (int u = 0; u < ENCODE_UNROLL; u++) {
+                const long long q = q0 + u * ENCODE_BLOCK + threadIdx.x;
+                if (q < quads) {
+                    v[u].x = encode(v[u].x);
+                    v[u].y = encode(v[u].y);
+                    v[u].z = encode(v[u].z);
+                    v[u].w = encode(v[u].w);
+                    c4[q] = v[u];
+                }
+            }
+        }
+        if (j == 0 && (long long)threadIdx.x < end - begin - quads * 4) {
+            const long long pos = begin + quads * 4 + threadIdx.x;
+            col2[pos] = encode(col2[pos]);
         }
     }
 }
@@ -635,7 +781,7 @@ size_t slab_scatter_lds(const Geometry &g, int S, size_t vsize)
 
 hipError_t slab_partition(const Geometry &g, const DeviceArrays &d, int value_type, int S, int bits, int shift,
                           uint32_t *hist, void *scan_tmp, size_t scan_tmp_bytes, int32_t *col2, void *val2,
-                          unsigned long long *key2, hipStream_t s)
+                          uint32_t *key2, hipStream_t s)
 {
     hipLaunchKernelGGL(k_slab_hist, dim3(g.p), dim3(SLAB_BLOCK), 0, s, g, d.col, S, bits, shift, hist);
     hipError_t e = hipGetLastError();
@@ -668,7 +814,7 @@ hipError_t slab_select_tmp_bytes(int nnz, size_t *bytes)
 }
 
 // d_count <- m' (number of segments); `tmp` (slab_select_tmp_bytes) keeps the chunk offsets for slab_segments
-hipError_t slab_count_segments(int nnz, const unsigned long long *key2, void *tmp, unsigned int *d_count, hipStream_t s)
+hipError_t slab_count_segments(int nnz, const uint32_t *key2, void *tmp, unsigned int *d_count, hipStream_t s)
 {
     const int blocks = seg_blocks(nnz);
     hipLaunchKernelGGL(k_slab_count_segments, dim3(blocks), dim3(SLAB_BLOCK), 0, s, nnz, key2, (unsigned int *)tmp);
@@ -677,7 +823,7 @@ hipError_t slab_count_segments(int nnz, const unsigned long long *key2, void *tm
 }
 
 // row_ptr'[0 .. m') <- segment starts (after slab_count_segments on the same keys and tmp)
-hipError_t slab_segments(int nnz, const unsigned long long *key2, const void *tmp, int32_t *row_ptr2, hipStream_t s)
+hipError_t slab_segments(int nnz, const uint32_t *key2, const void *tmp, int32_t *row_ptr2, hipStream_t s)
 {
     hipLaunchKernelGGL(k_slab_emit_segments, dim3(seg_blocks(nnz)), dim3(SLAB_BLOCK), 0, s, nnz, key2,
                        (const unsigned int *)tmp, row_ptr2);
@@ -686,15 +832,15 @@ hipError_t slab_segments(int nnz, const unsigned long long *key2, const void *tm
 
 // tables of the combine: row byte per segment, run starts per (row block, slab), non-empty bit per parent row
 size_t slab_base_words(int m, int S) { return ((size_t)(m + COMBINE_ROWS - 1) / COMBINE_ROWS + 2) * (size_t)S; }
-hipError_t slab_tables(int m, int m2, int nnz, int S, const int32_t *row_ptr, int32_t *row_ptr2, const unsigned long long *key2,
-                       unsigned char *rowidx, uint32_t *base, uint32_t *nonempty, hipStream_t s)
+hipError_t slab_tables(int m, int m2, int nnz, int S, int p, const int32_t *row_ptr, int32_t *row_ptr2, const uint32_t *key2,
+                       const uint32_t *chunk_start, unsigned char *rowidx, uint32_t *base, uint32_t *nonempty, hipStream_t s)
 {
     const int nblk = (m + COMBINE_ROWS - 1) / COMBINE_ROWS;
     hipLaunchKernelGGL(k_slab_rowidx, dim3(((m2 > 0 ? m2 : 1) + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, s, m2, nnz,
                        row_ptr2, key2, rowidx, row_ptr2 + m2);
     const long long entries = (long long)(nblk + 1) * S;
-    hipLaunchKernelGGL(k_slab_base, dim3((unsigned)((entries + SLAB_BLOCK - 1) / SLAB_BLOCK)), dim3(SLAB_BLOCK), 0, s, m2, S, nblk,
-                       row_ptr2, key2, base);
+    hipLaunchKernelGGL(k_slab_base, dim3((unsigned)((entries + SLAB_BLOCK - 1) / SLAB_BLOCK)), dim3(SLAB_BLOCK), 0, s, m2, nnz, S,
+                       nblk, row_ptr2, key2, chunk_start, p, base);
     hipLaunchKernelGGL(k_slab_nonempty, dim3((m + 32 + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, s, m, row_ptr, nonempty);
     return hipGetLastError();
 }
@@ -734,12 +880,15 @@ namespace csr5 {
 
 // Selects the hot columns of every slab and fills hot_cols / hot_count; *covered = sampled non-zeros whose column got a
 // slot.  Needs only the column indices (any order: the parent's array), so it runs BEFORE the partition and its verdict
-// can still change the slab count.  cnt, hotmap, chist, thr: caller-provided scratch (n, n, S*HOT_BUCKETS, S words; cnt
-// and chist zeroed, hotmap filled with 0xFF by the caller).
+// can still change the slab count.  cnt, hotmap, chist, thr: caller-provided scratch (n words, slab_hotmap_bytes,
+// S*HOT_BUCKETS, S words; all zeroed by the caller except thr).
 hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capacity, int min_count, int sample_stride,
-                           const int32_t *col, uint32_t *cnt, uint16_t *hotmap, uint32_t *chist, uint32_t *thr,
+                           const int32_t *col, uint32_t *cnt, void *hotmap, uint32_t *chist, uint32_t *thr,
                            int32_t *hot_cols, int32_t *hot_count, unsigned long long *covered, hipStream_t s)
 {
+    const size_t G = slab_hot_groups(n, shift, bits);
+    uint4 *hotbits = (uint4 *)hotmap;
+    uint16_t *hotpre = (uint16_t *)(hotbits + (size_t)S * G);
     long long blocks = ((long long)nnz / sample_stride + SLAB_BLOCK * 8 - 1) / (SLAB_BLOCK * 8);
     blocks = blocks < 1 ? 1 : (blocks > 65536 ? 65536 : blocks);
     // slot 0 of every table is reserved (it holds +0.0, see k_spmv_hot): slots are handed out from 1
@@ -752,8 +901,8 @@ hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capac
     hipLaunchKernelGGL(k_hot_threshold, dim3(S), dim3(OMEGA), 0, s, capacity, min_count, chist, thr);
     for (int pass = 0; pass < 2; pass++)
         hipLaunchKernelGGL(k_hot_assign, dim3((n + HOT_ASSIGN_COLS - 1) / HOT_ASSIGN_COLS), dim3(SLAB_BLOCK), 0, s, n, cnt, bits,
-                           shift, thr, capacity, min_count, pass, hot_count, hot_cols, hotmap, slab_local_count(n, shift, bits),
-                           covered);
+                           shift, thr, capacity, min_count, pass, hot_count, (uint32_t *)hotbits, G, covered);
+    hipLaunchKernelGGL(k_hot_rank, dim3(S), dim3(RANK_BLOCK), 0, s, bits, shift, capacity, G, hotbits, hotpre, hot_cols);
     return hipGetLastError();
 }
 
@@ -768,14 +917,30 @@ hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacit
 }
 
 hipError_t slab_hot_encode(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
-                           const uint16_t *hotmap, int32_t *col2, hipStream_t s)
+                           const void *hotmap, int32_t *col2, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_hot_encode, dim3(NUM_XCD * 512), dim3(SLAB_BLOCK), 0, s, nnz, T, p, S, bits, shift, slab_off, hotmap,
-                       slab_local_count(n, shift, bits), col2);
+    const size_t G = slab_hot_groups(n, shift, bits);
+    const uint4 *hotbits = (const uint4 *)hotmap;
+    const uint16_t *hotpre = (const uint16_t *)(hotbits + (size_t)S * G);
+    const size_t lds = G * (sizeof(uint4) + sizeof(uint16_t));
+    const dim3 grid(NUM_XCD * ENCODE_WGS_PER_XCD), block(ENCODE_BLOCK);
+    if (lds <= 150 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hot_encode<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL(k_hot_encode<true>, grid, block, lds, s, nnz, T, p, S, bits, shift, slab_off, hotbits, hotpre, G, col2);
+    } else {
+        hipLaunchKernelGGL(k_hot_encode<false>, grid, block, 0, s, nnz, T, p, S, bits, shift, slab_off, hotbits, hotpre, G, col2);
+    }
     return hipGetLastError();
 }
 
-size_t slab_hotmap_bytes(int n, int S, int bits, int shift) { return (size_t)S * slab_local_count(n, shift, bits) * 2 + 256; }
+// slab-major bitmap of the hot columns (16 bytes per 128 slab-local columns) followed by the 2-byte group prefixes
+size_t slab_hotmap_bytes(int n, int S, int bits, int shift)
+{
+    return (size_t)S * slab_hot_groups(n, shift, bits) * (sizeof(uint4) + sizeof(uint16_t)) + 256;
+}
 
 int slab_hot_buckets() { return HOT_BUCKETS; }
 
