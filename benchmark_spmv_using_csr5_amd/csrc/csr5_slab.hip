@@ -120,6 +120,22 @@ k_slab_hist(Geometry g, const int32_t *__restrict__ col, int S, int bits, int sh
         hist[(size_t)threadIdx.x * g.p + t] = sh[threadIdx.x];
 }
 
+// lanes of the wavefront that hold the same slab as this lane (valid lanes only): one ballot per bit of the slab id
+__device__ __forceinline__ unsigned long long same_slab_lanes(int k, bool valid, int bits)
+{
+    unsigned long long same = __ballot(valid);
+    for (int b = 0; b < bits; b++) {
+        const bool on = (k >> b) & 1;
+        const unsigned long long bal = __ballot(on);
+        same &= on ? bal : ~bal;
+    }
+    return same;
+}
+
+// One workgroup per tile of the parent.  The tile is read once (coalesced, through the transpose map) into LDS in CSR
+// order, ranked per slab (stable), and written out SLAB AFTER SLAB: consecutive lanes write consecutive elements of one
+// slab's run, so a tile produces S contiguous runs per array.  (Writing straight from CSR order -- every 64-element chunk
+// scattering ~4 elements to each of 16 slabs -- issued 16 partial-line writes per instruction and array.)
 template <typename VT>
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_slab_scatter(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *__restrict__ tile_ptr,
@@ -132,7 +148,12 @@ k_slab_scatter(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *
     VT *sval = reinterpret_cast<VT *>(smem);
     int32_t *scol = reinterpret_cast<int32_t *>(smem + (size_t)T * sizeof(VT));
     uint32_t *off = reinterpret_cast<uint32_t *>(smem + (size_t)T * (sizeof(VT) + 4));
-    unsigned char *skey = reinterpret_cast<unsigned char *>(off + (size_t)(T / OMEGA) * S);
+    uint16_t *inv = reinterpret_cast<uint16_t *>(off + (size_t)(T / OMEGA) * S);
+    unsigned char *skey = reinterpret_cast<unsigned char *>(inv + T);
+    unsigned char *srank = skey + T;
+    constexpr int ROWCAP = 1024;
+    __shared__ int32_t srow[ROWCAP];
+    __shared__ uint32_t slab_first[SLAB_MAX], gstart[SLAB_MAX], lstart[SLAB_MAX + 1];
 
     const int t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & (OMEGA - 1), wave = tid >> 6;
@@ -147,84 +168,97 @@ k_slab_scatter(Geometry g, const int32_t *__restrict__ row_ptr, const uint32_t *
         sval[c] = val[base + q];
         skey[c] = (unsigned char)slab_of((uint32_t)ci, shift, bits);
     }
+    if (tid < S) {
+        slab_first[tid] = chunk_start[(size_t)tid * g.p]; // where slab tid begins in the child
+        gstart[tid] = chunk_start[(size_t)tid * g.p + t]; // where this tile's run of slab tid begins
+    }
+    // the row of element j = number of row pointers in (rs, re] that are <= j: the tile's slice of row_ptr is searched in
+    // LDS (a bisection of global memory per element was six dependent loads; a tile spans ~T / mean row length rows)
+    const int rs = (int)(tile_ptr[t] & ROW_MASK);
+    const int re = (int)(tile_ptr[t + 1] & ROW_MASK);
+    const bool rows_in_lds = re - rs <= ROWCAP;
+    if (rows_in_lds)
+        for (int i = tid; i < re - rs; i += SLAB_BLOCK)
+            srow[i] = row_ptr[rs + 1 + i];
     __syncthreads();
     const int nchunks = (E + OMEGA - 1) / OMEGA;
-    // phase 1: per 64-element chunk, how many elements go to each slab
+    // phase 1: per 64-element chunk, how many elements go to each slab, and every element's rank among them
     for (int ch = wave; ch < nchunks; ch += SLAB_BLOCK / OMEGA) {
         const int c = ch * OMEGA + lane;
         const bool valid = c < E;
-        const int k = valid ? skey[c] : -1;
+        const int k = valid ? skey[c] : 0;
         if (lane < S)
             off[ch * S + lane] = 0;
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            const int leader = __builtin_ctzll(todo);
-            const int kk = __builtin_amdgcn_readlane(k, leader);
-            const unsigned long long b = __ballot(valid && k == kk);
-            if (lane == leader)
-                off[ch * S + kk] = (uint32_t)__popcll(b);
-            todo &= ~b;
+        const unsigned long long same = same_slab_lanes(k, valid, bits);
+        if (valid) {
+            const int rank = __popcll(same & ((1ull << lane) - 1ull));
+            srank[c] = (unsigned char)rank;
+            if (rank == 0)
+                off[ch * S + k] = (uint32_t)__popcll(same);
         }
     }
     __syncthreads();
-    // phase 2: exclusive scan over the chunks for every slab, on top of the global start of (slab, tile)
+    // phase 2: exclusive scan over the chunks for every slab (positions inside the slab's run of this tile)
     if (tid < S) {
-        uint32_t run = chunk_start[(size_t)tid * g.p + t];
+        uint32_t run = 0;
         for (int ch = 0; ch < nchunks; ch++) {
             const uint32_t v = off[ch * S + tid];
             off[ch * S + tid] = run;
             run += v;
         }
+        lstart[tid + 1] = run;
     }
     __syncthreads();
-    // phase 3: stable destination of every element + its row
-    const int rs = (int)(tile_ptr[t] & ROW_MASK);
-    const int re = (int)(tile_ptr[t + 1] & ROW_MASK);
-    // the row of element j = number of row pointers in (rs, re] that are <= j: the tile's slice of row_ptr is searched in
-    // LDS (a bisection of global memory per element was six dependent loads; a tile spans ~T / mean row length rows)
-    constexpr int ROWCAP = 1024;
-    __shared__ int32_t srow[ROWCAP];
-    __shared__ uint32_t slab_first[SLAB_MAX];
-    const bool rows_in_lds = re - rs <= ROWCAP;
-    if (rows_in_lds)
-        for (int i = tid; i < re - rs; i += SLAB_BLOCK)
-            srow[i] = row_ptr[rs + 1 + i];
-    if (tid < S)
-        slab_first[tid] = chunk_start[(size_t)tid * g.p]; // where slab tid begins in the child
+    if (tid == 0) {
+        lstart[0] = 0;
+        for (int k = 0; k < S; k++)
+            lstart[k + 1] += lstart[k];
+    }
     __syncthreads();
-    for (int ch = wave; ch < nchunks; ch += SLAB_BLOCK / OMEGA) {
-        const int c = ch * OMEGA + lane;
-        const bool valid = c < E;
-        const int k = valid ? skey[c] : -1;
-        int rank = 0;
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            const int leader = __builtin_ctzll(todo);
-            const int kk = __builtin_amdgcn_readlane(k, leader);
-            const unsigned long long b = __ballot(valid && k == kk);
-            if (k == kk)
-                rank = __popcll(b & ((1ull << lane) - 1ull));
-            todo &= ~b;
-        }
-        if (valid) {
-            const size_t dst = (size_t)off[ch * S + k] + rank;
-            const int j = (int)(base + c);
-            const int row = rs + (rows_in_lds ? upper_bound_i32(srow, j, re - rs) : upper_bound_i32(row_ptr + rs + 1, j, re - rs));
-            col2[dst] = scol[c];
-            val2[dst] = sval[c];
-            key2[dst] = (uint32_t)row | (dst == slab_first[k] ? SLAB_KEY_FIRST : 0u);
-        }
+    // phase 3: position of every element in the slab-sorted tile
+    for (int c = tid; c < E; c += SLAB_BLOCK) {
+        const int k = skey[c];
+        inv[lstart[k] + off[(c >> 6) * S + k] + srank[c]] = (uint16_t)c;
+    }
+    __syncthreads();
+    // phase 4: write slab after slab
+    for (int o = tid; o < E; o += SLAB_BLOCK) {
+        const int c = inv[o];
+        const int k = skey[c];
+        const size_t dst = (size_t)gstart[k] + ((uint32_t)o - lstart[k]);
+        const int j = (int)(base + c);
+        const int row = rs + (rows_in_lds ? upper_bound_i32(srow, j, re - rs) : upper_bound_i32(row_ptr + rs + 1, j, re - rs));
+        col2[dst] = scol[c];
+        val2[dst] = sval[c];
+        key2[dst] = (uint32_t)row | (dst == slab_first[k] ? SLAB_KEY_FIRST : 0u);
     }
 }
 
 // The key of a child element: its parent row, bit 31 set on the first element of every slab (one word per non-zero; the
 // slab itself is implied by the position).  A segment starts where the row changes or a slab begins.
-__device__ __forceinline__ bool segment_starts(const uint32_t *__restrict__ key, long long j)
+__device__ __forceinline__ bool key_starts(uint32_t a, uint32_t before)
 {
-    if (j == 0)
-        return true;
-    const uint32_t a = key[j], b = key[j - 1];
-    return (a & SLAB_KEY_FIRST) != 0 || ((a ^ b) & ~SLAB_KEY_FIRST) != 0;
+    return (a & SLAB_KEY_FIRST) != 0 || ((a ^ before) & ~SLAB_KEY_FIRST) != 0;
+}
+// bit i = a segment starts at j + i, for the four keys at j (a multiple of 4), limited to positions below hi
+__device__ __forceinline__ unsigned segment_starts4(const uint32_t *__restrict__ key, long long j, long long hi)
+{
+    if (j >= hi)
+        return 0u;
+    const uint32_t before = j > 0 ? key[j - 1] : 0u;
+    if (j + 4 <= hi) {
+        const uint4 k = *reinterpret_cast<const uint4 *>(key + j);
+        return (j == 0 || key_starts(k.x, before) ? 1u : 0u) | (key_starts(k.y, k.x) ? 2u : 0u) | (key_starts(k.z, k.y) ? 4u : 0u) |
+               (key_starts(k.w, k.z) ? 8u : 0u);
+    }
+    unsigned f = 0;
+    uint32_t prev = before;
+    for (int i = 0; j + i < hi; i++) {
+        const uint32_t k = key[j + i];
+        f |= (j + i == 0 || key_starts(k, prev) ? 1u : 0u) << i;
+        prev = k;
+    }
+    return f;
 }
 
 // Segment starts -> row_ptr' in three small steps on a fixed partition of the keys
@@ -233,10 +267,11 @@ __device__ __forceinline__ bool segment_starts(const uint32_t *__restrict__ key,
 // a counting iterator did this in 4.8 ms on R-MAT 24 after a 3.0-ms counting pass; the two passes here read the keys
 // twice at stream speed.
 constexpr int SEG_BLOCKS = 2048;
+constexpr int SEG_STEP = SLAB_BLOCK * 4; // keys per workgroup and step: four consecutive ones per thread (one 16-byte load)
 __host__ __device__ inline long long seg_chunk(int nnz, int blocks)
 {
     long long c = ((long long)nnz + blocks - 1) / blocks;
-    return (c + SLAB_BLOCK - 1) / SLAB_BLOCK * SLAB_BLOCK;
+    return (c + SEG_STEP - 1) / SEG_STEP * SEG_STEP;
 }
 static int seg_blocks(int nnz)
 {
@@ -251,8 +286,8 @@ k_slab_count_segments(int nnz, const uint32_t *__restrict__ key, unsigned int *_
     const long long chunk = seg_chunk(nnz, gridDim.x);
     const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < nnz ? lo + chunk : nnz;
     unsigned local = 0;
-    for (long long j = lo + threadIdx.x; j < hi; j += SLAB_BLOCK)
-        local += segment_starts(key, j);
+    for (long long j = lo + (long long)threadIdx.x * 4; j < hi; j += SEG_STEP)
+        local += (unsigned)__popc(segment_starts4(key, j, hi));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         local += __shfl_xor(local, d, OMEGA);
@@ -313,20 +348,30 @@ k_slab_emit_segments(int nnz, const uint32_t *__restrict__ key, const unsigned i
     const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < nnz ? lo + chunk : nnz;
     const int lane = threadIdx.x & (OMEGA - 1), w = threadIdx.x / OMEGA;
     unsigned out = block_offset[blockIdx.x];
-    for (long long j0 = lo; j0 < hi; j0 += SLAB_BLOCK) { // (chunk is a multiple of the workgroup size: uniform trip count)
-        const long long j = j0 + threadIdx.x;
-        const bool start = j < hi && segment_starts(key, j);
-        const unsigned long long b = __ballot(start);
-        if (lane == 0)
-            wave_count[w] = (unsigned)__popcll(b);
+    for (long long j0 = lo; j0 < hi; j0 += SEG_STEP) { // (chunk is a multiple of the step: uniform trip count)
+        const long long j = j0 + (long long)threadIdx.x * 4;
+        const unsigned f = segment_starts4(key, j, hi);
+        const unsigned own = (unsigned)__popc(f);
+        unsigned incl = own;
+#pragma unroll
+        for (int d = 1; d < OMEGA; d <<= 1) {
+            const unsigned o = __shfl_up(incl, d, OMEGA);
+            if (lane >= d)
+                incl += o;
+        }
+        if (lane == OMEGA - 1)
+            wave_count[w] = incl;
         __syncthreads();
         unsigned before = 0, all = 0;
         for (int k = 0; k < SLAB_BLOCK / OMEGA; k++) {
             before += k < w ? wave_count[k] : 0u;
             all += wave_count[k];
         }
-        if (start)
-            row_ptr2[out + before + (unsigned)__popcll(b & ((1ull << lane) - 1ull))] = (int32_t)j;
+        unsigned at = out + before + incl - own;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            if (f & (1u << i))
+                row_ptr2[at++] = (int32_t)(j + i);
         out += all;
         __syncthreads();
     }
@@ -776,7 +821,7 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
 size_t slab_scatter_lds(const Geometry &g, int S, size_t vsize)
 {
     const size_t T = (size_t)g.tile_elems;
-    return T * (vsize + 4) + (T / OMEGA) * (size_t)S * 4 + T;
+    return T * (vsize + 4) + (T / OMEGA) * (size_t)S * 4 + T * 2 + T + T; // values, columns, chunk counts, inverse, slab, rank
 }
 
 hipError_t slab_partition(const Geometry &g, const DeviceArrays &d, int value_type, int S, int bits, int shift,
