@@ -852,12 +852,12 @@ static int build_slabs_impl(csr5hip_handle h)
     HIP_TRY(hipMemcpyAsync(&m2, t.count, 4, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     HIP_TRY(h->b_row_ptr2.reserve(((size_t)m2 + 1) * 4));
-    HIP_TRY(slab_segments(g.nnz, (const uint32_t *)t.key, t.sel_tmp, (int32_t *)h->b_row_ptr2.ptr, s));
     HIP_TRY(h->b_rowidx.reserve((size_t)m2 + 1));
+    HIP_TRY(slab_segments(g.nnz, (const uint32_t *)t.key, t.sel_tmp, (int32_t *)h->b_row_ptr2.ptr, (unsigned char *)h->b_rowidx.ptr, s));
     HIP_TRY(h->b_base.reserve(slab_base_words(g.m, S) * 4));
     HIP_TRY(h->b_nonempty.reserve(((size_t)g.m / 32 + 16) * 4));
     HIP_TRY(slab_tables(g.m, (int)m2, g.nnz, S, g.p, h->d.row_ptr, (int32_t *)h->b_row_ptr2.ptr, (const uint32_t *)t.key,
-                        (const uint32_t *)t.hist, (unsigned char *)h->b_rowidx.ptr, (uint32_t *)h->b_base.ptr, (uint32_t *)h->b_nonempty.ptr, s));
+                        (const uint32_t *)t.hist, (uint32_t *)h->b_base.ptr, (uint32_t *)h->b_nonempty.ptr, s));
     HIP_TRY(h->b_P.reserve(((size_t)m2 + 1) * h->vsize()));
     HIP_TRY(hipMemsetAsync(h->b_P.ptr, 0, ((size_t)m2 + 1) * h->vsize(), s));
 

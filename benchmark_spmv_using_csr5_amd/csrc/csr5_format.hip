@@ -92,11 +92,19 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_row_scan(Geometry g, const int32_
         for (int t = a + lane; t <= b; t += OMEGA)
             atomicOr(&tile_ptr[t], (uint32_t)row);
     }
-    // Empty rows come in runs with the same pointer (R-MAT: half of all rows), i.e. the same target tile:
-    // only the first lane of a run marks it.
+    // Empty rows come in runs with the same pointer (R-MAT: half of all rows) and several runs fall into one tile: only
+    // the first lane of the wavefront that names a tile marks it (the targets rise with the row, so that is the lane whose
+    // target exceeds the running maximum; one atomic per RUN was 4 M atomics = 0.28 ms of this pass on R-MAT 24).
     const int target = (live && e == e1 && e > 0) ? (e - 1) / T : -1;
-    const int before = __shfl_up(target, 1, OMEGA);
-    if (target >= 0 && (lane == 0 || before != target))
+    int seen = target;
+#pragma unroll
+    for (int d = 1; d < OMEGA; d <<= 1) {
+        const int o = __shfl_up(seen, d, OMEGA);
+        if (lane >= d)
+            seen = o > seen ? o : seen;
+    }
+    const int before = __shfl_up(seen, 1, OMEGA);
+    if (target >= 0 && (lane == 0 || target > before))
         atomicOr(&tile_ptr[target], 0x80000000u);
 }
 
@@ -458,27 +466,34 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
             const int o = __shfl_xor(best, d, OMEGA);
             best = o > best ? o : best;
         }
-        const int lo = __builtin_amdgcn_readlane(my_lo, OMEGA - 1 - (__builtin_amdgcn_readfirstlane(best) % OMEGA));
-        int inside = 0;
-        for (int i = 0; i < g.sigma; i++)
-            inside += (unsigned)(c[i * OMEGA] - lo) < (unsigned)XWIN_ELEMS;
-        inside = wave_sum_i32(inside);
-        // How many distinct 128-byte lines of x do the in-window lanes of ONE gather instruction (the 64 samples)
-        // touch?  That is what the window replaces: a gather spread over 30+ lines costs 60+ clk in the vector-memory
-        // path, one that sits on a handful of lines is cheap and the staging would cost more than it saves.
-        const bool in_win = (unsigned)(sample - lo) < (unsigned)XWIN_ELEMS;
-        const int line = sample >> line_shift;
-        bool first = in_win;
+        const int best_all = __builtin_amdgcn_readfirstlane(best);
+        const int lo = __builtin_amdgcn_readlane(my_lo, OMEGA - 1 - (best_all % OMEGA));
+        // The 64 samples are every sigma-th element of the tile.  A window that holds fewer than a quarter of the samples
+        // it would need cannot cover XWIN_MIN_COVER_PCT % of the tile: such tiles (every tile of a matrix with scattered
+        // columns) are left without reading their other column words -- 1 GB and 0.3 ms of this pass on R-MAT 24.
+        if ((best_all / OMEGA) * 400 >= OMEGA * XWIN_MIN_COVER_PCT) {
+            int inside = 0;
+            for (int i = 0; i < g.sigma; i++)
+                inside += (unsigned)(c[i * OMEGA] - lo) < (unsigned)XWIN_ELEMS;
+            inside = wave_sum_i32(inside);
+            if (inside * 100 >= g.tile_elems * XWIN_MIN_COVER_PCT) {
+                // How many distinct 128-byte lines of x do the in-window lanes of ONE gather instruction (the 64 samples)
+                // touch?  That is what the window replaces: a gather spread over 30+ lines costs 60+ clk in the
+                // vector-memory path, one that sits on a handful of lines is cheap and the staging would cost more than
+                // it saves.
+                const bool in_win = (unsigned)(sample - lo) < (unsigned)XWIN_ELEMS;
+                const int line = sample >> line_shift;
+                bool first = in_win;
 #pragma unroll
-        for (int j = 0; j < OMEGA - 1; j++) {
-            const int other = __builtin_amdgcn_readlane(line, j);
-            const bool other_in = (__builtin_amdgcn_readlane((int)in_win, j) != 0);
-            first = first && !(j < lane && other_in && other == line);
-        }
-        const int lines = __popcll(__ballot(first));
-        if (inside * 100 >= g.tile_elems * XWIN_MIN_COVER_PCT) {
-            window = (unsigned)lo + 1u;
-            stats = (unsigned)inside | ((unsigned)lines << 16);
+                for (int j = 0; j < OMEGA - 1; j++) {
+                    const int other = __builtin_amdgcn_readlane(line, j);
+                    const bool other_in = (__builtin_amdgcn_readlane((int)in_win, j) != 0);
+                    first = first && !(j < lane && other_in && other == line);
+                }
+                const int lines = __popcll(__ballot(first));
+                window = (unsigned)lo + 1u;
+                stats = (unsigned)inside | ((unsigned)lines << 16);
+            }
         }
     }
     if (lane == 0) {

@@ -100,10 +100,10 @@ hipError_t slab_partition(const Geometry &g, const DeviceArrays &d, int value_ty
                           uint32_t *hist, void *scan_tmp, size_t scan_tmp_bytes, int32_t *col2, void *val2,
                           uint32_t *key2, hipStream_t s);
 hipError_t slab_count_segments(int nnz, const uint32_t *key2, void *tmp, unsigned int *d_count, hipStream_t s);
-hipError_t slab_segments(int nnz, const uint32_t *key2, const void *tmp, int32_t *row_ptr2, hipStream_t s);
+hipError_t slab_segments(int nnz, const uint32_t *key2, const void *tmp, int32_t *row_ptr2, unsigned char *rowidx, hipStream_t s);
 size_t slab_base_words(int m, int S);
 hipError_t slab_tables(int m, int m2, int nnz, int S, int p, const int32_t *row_ptr, int32_t *row_ptr2, const uint32_t *key2,
-                       const uint32_t *chunk_start, unsigned char *rowidx, uint32_t *base, uint32_t *nonempty, hipStream_t s);
+                       const uint32_t *chunk_start, uint32_t *base, uint32_t *nonempty, hipStream_t s);
 hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capacity, int min_count, int sample_stride,
                            const int32_t *col, uint32_t *cnt, void *hotmap, uint32_t *chist, uint32_t *thr,
                            int32_t *hot_cols, int32_t *hot_count, unsigned long long *covered, hipStream_t s);

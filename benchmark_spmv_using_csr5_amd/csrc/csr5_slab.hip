@@ -21,10 +21,10 @@
 //   k_slab_hist     workgroup / tile: slab histogram of the tile                       -> hist[slab][tile]
 //   exclusive scan  (rocprim) over hist in slab-major order = start of every (slab, tile) chunk in A'
 //   k_slab_scatter  workgroup / tile: stable rank of every element inside its slab (wave ballots + LDS chunk table),
-//                   scatter of column, value and the 64-bit key (slab << 32 | row)
+//                   scatter of column, value and the 32-bit key (row, bit 31 = first element of a slab)
 //   segment starts  = positions where the key changes: counted per chunk, scanned, then written into row_ptr' by
 //                   ballot rank (k_slab_count_segments, k_slab_scan_counts, k_slab_emit_segments)
-//   k_slab_rowidx   thread / segment: row of the segment inside its 256-row block
+//                   (the emit pass also writes the row of every segment inside its 256-row block, one byte)
 //   k_slab_base     thread / (row block, slab): first segment of the run (binary search on the sorted segment keys)
 //   k_slab_nonempty thread / row: one bit per row of the parent
 #include "csr5_internal.h"
@@ -103,21 +103,53 @@ __device__ __forceinline__ bool tile_is_transposed(const Geometry &g, const uint
     return t < g.p - 1 && tile_ptr[t] != tile_ptr[t + 1];
 }
 
+// One wavefront per tile, HIST_TILES consecutive tiles per workgroup.  Lane k keeps the count of slab k in a register:
+// per 64-element chunk one ballot per bit of the slab id, and every lane intersects the ballots that spell its own
+// number (64 LDS atomics on 16 words per chunk serialised; so did the 16 strided words per tile of the result -- a
+// workgroup now writes HIST_TILES consecutive words per slab).
+constexpr int HIST_TILES = 16;
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_slab_hist(Geometry g, const int32_t *__restrict__ col, int S, int bits, int shift, uint32_t *__restrict__ hist)
 {
-    __shared__ uint32_t sh[SLAB_MAX];
-    const int t = blockIdx.x;
-    const size_t base = (size_t)t * g.tile_elems;
-    const int E = (int)((size_t)g.nnz - base < (size_t)g.tile_elems ? (size_t)g.nnz - base : (size_t)g.tile_elems);
-    if (threadIdx.x < SLAB_MAX)
-        sh[threadIdx.x] = 0;
+    __shared__ uint32_t sh[SLAB_MAX][HIST_TILES];
+    const int lane = threadIdx.x & (OMEGA - 1), wave = threadIdx.x >> 6;
+    const int t0 = blockIdx.x * HIST_TILES;
+    for (int i = wave; i < HIST_TILES; i += SLAB_BLOCK / OMEGA) {
+        const int t = t0 + i;
+        uint32_t mine = 0;
+        if (t < g.p) {
+            const size_t base = (size_t)t * g.tile_elems;
+            const int E = (int)((size_t)g.nnz - base < (size_t)g.tile_elems ? (size_t)g.nnz - base : (size_t)g.tile_elems);
+            constexpr int AHEAD = 4; // chunks requested together
+            for (int q0 = 0; q0 < E; q0 += AHEAD * OMEGA) {
+                int32_t c[AHEAD];
+#pragma unroll
+                for (int u = 0; u < AHEAD; u++) {
+                    const int q = q0 + u * OMEGA + lane;
+                    c[u] = col[base + (q < E ? q : E - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < AHEAD; u++) {
+                    const bool valid = q0 + u * OMEGA + lane < E;
+                    const uint32_t k = slab_of((uint32_t)c[u], shift, bits);
+                    unsigned long long sel = __ballot(valid);
+                    for (int b = 0; b < bits; b++) {
+                        const unsigned long long bal = __ballot((k >> b) & 1u);
+                        sel &= (lane >> b) & 1 ? bal : ~bal;
+                    }
+                    mine += (uint32_t)__popcll(sel);
+                }
+            }
+        }
+        if (lane < S)
+            sh[lane][i] = mine;
+    }
     __syncthreads();
-    for (int q = threadIdx.x; q < E; q += SLAB_BLOCK)
-        atomicAdd(&sh[slab_of((uint32_t)col[base + q], shift, bits)], 1u);
-    __syncthreads();
-    if ((int)threadIdx.x < S)
-        hist[(size_t)threadIdx.x * g.p + t] = sh[threadIdx.x];
+    for (int e = threadIdx.x; e < S * HIST_TILES; e += SLAB_BLOCK) {
+        const int k = e / HIST_TILES, i = e % HIST_TILES;
+        if (t0 + i < g.p)
+            hist[(size_t)k * g.p + t0 + i] = sh[k][i];
+    }
 }
 
 // lanes of the wavefront that hold the same slab as this lane (valid lanes only): one ballot per bit of the slab id
@@ -240,26 +272,28 @@ __device__ __forceinline__ bool key_starts(uint32_t a, uint32_t before)
 {
     return (a & SLAB_KEY_FIRST) != 0 || ((a ^ before) & ~SLAB_KEY_FIRST) != 0;
 }
-// bit i = a segment starts at j + i, for the four keys at j (a multiple of 4), limited to positions below hi
-__device__ __forceinline__ unsigned segment_starts4(const uint32_t *__restrict__ key, long long j, long long hi)
+// bit i = a segment starts at j + i, for the four keys at j (a multiple of 4), limited to positions below hi; k[] = the keys
+__device__ __forceinline__ unsigned segment_starts4(const uint32_t *__restrict__ key, long long j, long long hi, uint32_t k[4])
 {
     if (j >= hi)
         return 0u;
     const uint32_t before = j > 0 ? key[j - 1] : 0u;
     if (j + 4 <= hi) {
-        const uint4 k = *reinterpret_cast<const uint4 *>(key + j);
-        return (j == 0 || key_starts(k.x, before) ? 1u : 0u) | (key_starts(k.y, k.x) ? 2u : 0u) | (key_starts(k.z, k.y) ? 4u : 0u) |
-               (key_starts(k.w, k.z) ? 8u : 0u);
+        const uint4 v = *reinterpret_cast<const uint4 *>(key + j);
+        k[0] = v.x, k[1] = v.y, k[2] = v.z, k[3] = v.w;
+    } else {
+        for (int i = 0; i < 4; i++)
+            k[i] = j + i < hi ? key[j + i] : 0u;
     }
-    unsigned f = 0;
-    uint32_t prev = before;
-    for (int i = 0; j + i < hi; i++) {
-        const uint32_t k = key[j + i];
-        f |= (j + i == 0 || key_starts(k, prev) ? 1u : 0u) << i;
-        prev = k;
-    }
+    unsigned f = j == 0 || key_starts(k[0], before) ? 1u : 0u;
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+        f |= (j + i < hi && key_starts(k[i], k[i - 1]) ? 1u : 0u) << i;
     return f;
 }
+
+// Row blocks of the combine (COMBINE_ROWS rows per block = one wavefront of k_slab_combine).
+constexpr int COMBINE_ROWS = 256;
 
 // Segment starts -> row_ptr' in three small steps on a fixed partition of the keys
 // into <= SEG_BLOCKS chunks: per-chunk counts (no atomics), one-workgroup scan of the counts (also the total m'), then
@@ -286,8 +320,10 @@ k_slab_count_segments(int nnz, const uint32_t *__restrict__ key, unsigned int *_
     const long long chunk = seg_chunk(nnz, gridDim.x);
     const long long lo = (long long)blockIdx.x * chunk, hi = lo + chunk < nnz ? lo + chunk : nnz;
     unsigned local = 0;
-    for (long long j = lo + (long long)threadIdx.x * 4; j < hi; j += SEG_STEP)
-        local += (unsigned)__popc(segment_starts4(key, j, hi));
+    for (long long j = lo + (long long)threadIdx.x * 4; j < hi; j += SEG_STEP) {
+        uint32_t k[4];
+        local += (unsigned)__popc(segment_starts4(key, j, hi, k));
+    }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         local += __shfl_xor(local, d, OMEGA);
@@ -341,7 +377,7 @@ __global__ void __launch_bounds__(1024) k_slab_scan_counts(int blocks, unsigned 
 
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_slab_emit_segments(int nnz, const uint32_t *__restrict__ key, const unsigned int *__restrict__ block_offset,
-                     int32_t *__restrict__ row_ptr2)
+                     int32_t *__restrict__ row_ptr2, unsigned char *__restrict__ rowidx)
 {
     __shared__ unsigned wave_count[SLAB_BLOCK / OMEGA];
     const long long chunk = seg_chunk(nnz, gridDim.x);
@@ -350,7 +386,8 @@ k_slab_emit_segments(int nnz, const uint32_t *__restrict__ key, const unsigned i
     unsigned out = block_offset[blockIdx.x];
     for (long long j0 = lo; j0 < hi; j0 += SEG_STEP) { // (chunk is a multiple of the step: uniform trip count)
         const long long j = j0 + (long long)threadIdx.x * 4;
-        const unsigned f = segment_starts4(key, j, hi);
+        uint32_t k4[4];
+        const unsigned f = segment_starts4(key, j, hi, k4);
         const unsigned own = (unsigned)__popc(f);
         unsigned incl = own;
 #pragma unroll
@@ -370,27 +407,13 @@ k_slab_emit_segments(int nnz, const uint32_t *__restrict__ key, const unsigned i
         unsigned at = out + before + incl - own;
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            if (f & (1u << i))
-                row_ptr2[at++] = (int32_t)(j + i);
+            if (f & (1u << i)) {
+                row_ptr2[at] = (int32_t)(j + i);
+                rowidx[at++] = (unsigned char)(k4[i] & (COMBINE_ROWS - 1)); // the segment's row inside its row block
+            }
         out += all;
         __syncthreads();
     }
-}
-
-// Row-block tables of the combine (COMBINE_ROWS rows per block = one wavefront of k_slab_combine).
-constexpr int COMBINE_ROWS = 256;
-
-// one thread per segment s: its row inside the row block (one byte); thread 0 also closes row_ptr'
-__global__ void __launch_bounds__(SLAB_BLOCK)
-k_slab_rowidx(int m2, int nnz, const int32_t *__restrict__ row_ptr2, const uint32_t *__restrict__ key,
-              unsigned char *__restrict__ rowidx, int32_t *__restrict__ row_ptr2_end)
-{
-    const int s = blockIdx.x * SLAB_BLOCK + threadIdx.x;
-    if (s == 0)
-        *row_ptr2_end = nnz; // row_ptr'[m'] (the segment pass wrote the m' starts)
-    if (s >= m2)
-        return;
-    rowidx[s] = (unsigned char)(key[row_ptr2[s]] & (COMBINE_ROWS - 1));
 }
 
 // base[b * S + k] = first segment whose (slab, row block) is >= (k, b): the segments are sorted by (slab, row), so the
@@ -399,9 +422,11 @@ k_slab_rowidx(int m2, int nnz, const int32_t *__restrict__ row_ptr2, const uint3
 // after the slab's first element), then every thread bisects its slab's range by row (no atomics, no serial gap filling).
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_slab_base(int m2, int nnz, int S, int nblk, const int32_t *__restrict__ row_ptr2, const uint32_t *__restrict__ key,
-            const uint32_t *__restrict__ chunk_start, int p, uint32_t *__restrict__ base)
+            const uint32_t *__restrict__ chunk_start, int p, uint32_t *__restrict__ base, int32_t *__restrict__ row_ptr2_end)
 {
     __shared__ int slab_seg[SLAB_MAX + 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        *row_ptr2_end = nnz; // row_ptr'[m'] (the segment pass wrote the m' starts)
     if ((int)threadIdx.x <= S) {
         const uint32_t first = (int)threadIdx.x < S ? chunk_start[(size_t)threadIdx.x * p] : (uint32_t)nnz;
         int lo = 0, hi = m2;
@@ -828,7 +853,7 @@ hipError_t slab_partition(const Geometry &g, const DeviceArrays &d, int value_ty
                           uint32_t *hist, void *scan_tmp, size_t scan_tmp_bytes, int32_t *col2, void *val2,
                           uint32_t *key2, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_slab_hist, dim3(g.p), dim3(SLAB_BLOCK), 0, s, g, d.col, S, bits, shift, hist);
+    hipLaunchKernelGGL(k_slab_hist, dim3((g.p + HIST_TILES - 1) / HIST_TILES), dim3(SLAB_BLOCK), 0, s, g, d.col, S, bits, shift, hist);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
@@ -868,24 +893,22 @@ hipError_t slab_count_segments(int nnz, const uint32_t *key2, void *tmp, unsigne
 }
 
 // row_ptr'[0 .. m') <- segment starts (after slab_count_segments on the same keys and tmp)
-hipError_t slab_segments(int nnz, const uint32_t *key2, const void *tmp, int32_t *row_ptr2, hipStream_t s)
+hipError_t slab_segments(int nnz, const uint32_t *key2, const void *tmp, int32_t *row_ptr2, unsigned char *rowidx, hipStream_t s)
 {
     hipLaunchKernelGGL(k_slab_emit_segments, dim3(seg_blocks(nnz)), dim3(SLAB_BLOCK), 0, s, nnz, key2,
-                       (const unsigned int *)tmp, row_ptr2);
+                       (const unsigned int *)tmp, row_ptr2, rowidx);
     return hipGetLastError();
 }
 
 // tables of the combine: row byte per segment, run starts per (row block, slab), non-empty bit per parent row
 size_t slab_base_words(int m, int S) { return ((size_t)(m + COMBINE_ROWS - 1) / COMBINE_ROWS + 2) * (size_t)S; }
 hipError_t slab_tables(int m, int m2, int nnz, int S, int p, const int32_t *row_ptr, int32_t *row_ptr2, const uint32_t *key2,
-                       const uint32_t *chunk_start, unsigned char *rowidx, uint32_t *base, uint32_t *nonempty, hipStream_t s)
+                       const uint32_t *chunk_start, uint32_t *base, uint32_t *nonempty, hipStream_t s)
 {
     const int nblk = (m + COMBINE_ROWS - 1) / COMBINE_ROWS;
-    hipLaunchKernelGGL(k_slab_rowidx, dim3(((m2 > 0 ? m2 : 1) + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, s, m2, nnz,
-                       row_ptr2, key2, rowidx, row_ptr2 + m2);
     const long long entries = (long long)(nblk + 1) * S;
     hipLaunchKernelGGL(k_slab_base, dim3((unsigned)((entries + SLAB_BLOCK - 1) / SLAB_BLOCK)), dim3(SLAB_BLOCK), 0, s, m2, nnz, S,
-                       nblk, row_ptr2, key2, chunk_start, p, base);
+                       nblk, row_ptr2, key2, chunk_start, p, base, row_ptr2 + m2);
     hipLaunchKernelGGL(k_slab_nonempty, dim3((m + 32 + SLAB_BLOCK - 1) / SLAB_BLOCK), dim3(SLAB_BLOCK), 0, s, m, row_ptr, nonempty);
     return hipGetLastError();
 }
