@@ -775,7 +775,7 @@ static int build_slabs_impl(csr5hip_handle h)
     };
     const size_t o_hist = take((size_t)S_alloc * g.p * 4), o_scan = take(scan_bytes), o_key = take((size_t)g.nnz * 4),
                  o_count = take(16), o_sel = take(sel_bytes), o_cnt = take(nb), o_hotmap = take(hotmap_bytes), o_chist = take(hb),
-                 o_thr = take((size_t)S_alloc * 4);
+                 o_thr = take((size_t)S_alloc * 8);
     if (h->slab_mem_mib > 0) {
         // second copy of column_index / value + build temporaries + (upper bound) one partial sum per non-zero row piece
         const unsigned long long need = (unsigned long long)g.nnz * (4 + h->vsize()) + off +
@@ -811,7 +811,7 @@ static int build_slabs_impl(csr5hip_handle h)
         // Column use counts come from a sample of the non-zeros (one 64-element chunk in `stride`): ~4 M samples are
         // plenty to rank columns, and a full count serialises on the very columns it is looking for.
         stride = (int)(g.nnz / (4LL * 1024 * 1024));
-        stride = stride < 1 ? 1 : (stride > 32 ? 32 : stride);
+        stride = stride < 1 ? 1 : (stride > 64 ? 64 : stride); // (R-MAT 24: 1/64 ranks as well as 1/32, 1/128 costs 1.5 % of the SpMV)
         // a slot is staged by each of the ~32 workgroups of the slab's XCD in every SpMV: it must be used more often
         int min_count = 48 / stride;
         min_count = min_count < 2 ? 2 : min_count;

@@ -37,6 +37,8 @@ constexpr int SLAB_BLOCK = 256;
 constexpr int SLAB_MAX = 64;
 constexpr uint32_t SLAB_KEY_FIRST = 0x80000000u; // key bit: first element of a slab
 
+// slab of a column = xor of all `bits`-wide groups of (col >> shift).  (A fold by halves -- five uniform steps instead of a
+// loop whose length depends on the column -- was slower: most columns need two or three rounds.)
 __device__ __forceinline__ uint32_t slab_of(uint32_t col, int shift, int bits)
 {
     uint32_t v = col >> shift, out = 0;
@@ -103,24 +105,29 @@ __device__ __forceinline__ bool tile_is_transposed(const Geometry &g, const uint
     return t < g.p - 1 && tile_ptr[t] != tile_ptr[t + 1];
 }
 
-// One wavefront per tile, HIST_TILES consecutive tiles per workgroup.  Lane k keeps the count of slab k in a register:
-// per 64-element chunk one ballot per bit of the slab id, and every lane intersects the ballots that spell its own
-// number (64 LDS atomics on 16 words per chunk serialised; so did the 16 strided words per tile of the result -- a
-// workgroup now writes HIST_TILES consecutive words per slab).
-constexpr int HIST_TILES = 16;
+// One wavefront per tile, HIST_TILES consecutive tiles per workgroup.  Every LANE counts its own elements in LDS counters
+// of its own ([slab][lane], padded to 65 lanes so that the column sums below do not collide on one bank): one ds_add per
+// element and no cross-lane work; lane k then adds up row k.  (64 LDS atomics on 16 shared words per chunk serialised;
+// counting by ballots -- one per bit of the slab id, intersected per lane -- was bound by its ~45 vector instructions per
+// chunk.)  A workgroup writes HIST_TILES consecutive words per slab (16 strided words per tile were 4 M partial lines).
+constexpr int HIST_TILES = 16, HIST_PAD = OMEGA + 1;
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_slab_hist(Geometry g, const int32_t *__restrict__ col, int S, int bits, int shift, uint32_t *__restrict__ hist)
 {
+    extern __shared__ uint32_t hist_lds[];
     __shared__ uint32_t sh[SLAB_MAX][HIST_TILES];
     const int lane = threadIdx.x & (OMEGA - 1), wave = threadIdx.x >> 6;
+    uint32_t *mine = hist_lds + (size_t)wave * S * HIST_PAD;
     const int t0 = blockIdx.x * HIST_TILES;
     for (int i = wave; i < HIST_TILES; i += SLAB_BLOCK / OMEGA) {
         const int t = t0 + i;
-        uint32_t mine = 0;
+        uint32_t total = 0;
         if (t < g.p) {
+            for (int k = 0; k < S; k++)
+                mine[k * HIST_PAD + lane] = 0;
             const size_t base = (size_t)t * g.tile_elems;
             const int E = (int)((size_t)g.nnz - base < (size_t)g.tile_elems ? (size_t)g.nnz - base : (size_t)g.tile_elems);
-            constexpr int AHEAD = 4; // chunks requested together
+            constexpr int AHEAD = 8; // chunks requested together
             for (int q0 = 0; q0 < E; q0 += AHEAD * OMEGA) {
                 int32_t c[AHEAD];
 #pragma unroll
@@ -129,20 +136,17 @@ k_slab_hist(Geometry g, const int32_t *__restrict__ col, int S, int bits, int sh
                     c[u] = col[base + (q < E ? q : E - 1)];
                 }
 #pragma unroll
-                for (int u = 0; u < AHEAD; u++) {
-                    const bool valid = q0 + u * OMEGA + lane < E;
-                    const uint32_t k = slab_of((uint32_t)c[u], shift, bits);
-                    unsigned long long sel = __ballot(valid);
-                    for (int b = 0; b < bits; b++) {
-                        const unsigned long long bal = __ballot((k >> b) & 1u);
-                        sel &= (lane >> b) & 1 ? bal : ~bal;
-                    }
-                    mine += (uint32_t)__popcll(sel);
-                }
+                for (int u = 0; u < AHEAD; u++)
+                    if (q0 + u * OMEGA + lane < E)
+                        atomicAdd(&mine[slab_of((uint32_t)c[u], shift, bits) * HIST_PAD + lane], 1u);
             }
+            // (one wavefront: its LDS operations are executed in order)
+            if (lane < S)
+                for (int j = 0; j < OMEGA; j++)
+                    total += mine[lane * HIST_PAD + j];
         }
         if (lane < S)
-            sh[lane][i] = mine;
+            sh[lane][i] = total;
     }
     __syncthreads();
     for (int e = threadIdx.x; e < S * HIST_TILES; e += SLAB_BLOCK) {
@@ -560,19 +564,50 @@ constexpr int HOT_BUCKETS = 2048;
 
 // Use counts of the columns from a SAMPLE of the non-zeros: one 64-element chunk out of every `stride` (the reads stay
 // coalesced).  The table only needs to know which columns are popular, and a popular column is exactly what makes a
-// full count slow: R-MAT 24 sends 370 k increments to one address (27 ms for the whole pass; 1/16 sample: < 2 ms).
-__global__ void __launch_bounds__(SLAB_BLOCK)
+// count slow: increments of ONE word are served one after the other, ~73 ns each (R-MAT 24 sends 370 k of them to its top
+// column: 27 ms for a full count, and still 0.83 ms = 11.5 k x 73 ns for the 1/32 sample).  So a workgroup first merges
+// its samples in a small direct-mapped table in LDS -- a column that finds its slot free or its own adds there, any
+// other goes to memory at once -- and flushes every used slot with one add: the top column then costs one add per
+// workgroup.  (Rows of unpopular columns fill the table too; a popular one shows up early enough to find its slot.)
+constexpr int COUNT_SLOTS = 16384, COUNT_BLOCK = 1024, COUNT_WGS = 256, COUNT_AHEAD = 4;
+__global__ void __launch_bounds__(COUNT_BLOCK)
 k_col_count(int nnz, int stride, const int32_t *__restrict__ col, uint32_t *__restrict__ cnt)
 {
+    extern __shared__ uint32_t count_lds[];
+    uint32_t *key = count_lds, *hits = count_lds + COUNT_SLOTS;
+    for (int i = threadIdx.x; i < COUNT_SLOTS; i += COUNT_BLOCK) {
+        key[i] = 0xFFFFFFFFu;
+        hits[i] = 0;
+    }
+    __syncthreads();
     const size_t chunks = ((size_t)nnz + OMEGA - 1) / OMEGA;
     const size_t sampled = (chunks + stride - 1) / stride;
     const int lane = threadIdx.x & (OMEGA - 1);
-    for (size_t w = ((size_t)blockIdx.x * SLAB_BLOCK + threadIdx.x) / OMEGA; w < sampled;
-         w += (size_t)gridDim.x * (SLAB_BLOCK / OMEGA)) {
-        const size_t i = w * stride * OMEGA + lane;
-        if (i < (size_t)nnz)
-            atomicAdd(&cnt[(uint32_t)col[i]], 1u);
+    const size_t step = (size_t)gridDim.x * (COUNT_BLOCK / OMEGA);
+    for (size_t w0 = ((size_t)blockIdx.x * COUNT_BLOCK + threadIdx.x) / OMEGA; w0 < sampled; w0 += step * COUNT_AHEAD) {
+        uint32_t c[COUNT_AHEAD];
+#pragma unroll
+        for (int u = 0; u < COUNT_AHEAD; u++) {
+            const size_t w = w0 + u * step;
+            const size_t i = w * stride * OMEGA + lane;
+            c[u] = w < sampled && i < (size_t)nnz ? (uint32_t)col[i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int u = 0; u < COUNT_AHEAD; u++) {
+            if (c[u] == 0xFFFFFFFFu)
+                continue;
+            const uint32_t slot = (c[u] * 2654435761u) >> 18; // 14 bits
+            const uint32_t owner = atomicCAS(&key[slot], 0xFFFFFFFFu, c[u]);
+            if (owner == 0xFFFFFFFFu || owner == c[u])
+                atomicAdd(&hits[slot], 1u);
+            else
+                atomicAdd(&cnt[c[u]], 1u);
+        }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < COUNT_SLOTS; i += COUNT_BLOCK)
+        if (hits[i])
+            atomicAdd(&cnt[key[i]], hits[i]);
 }
 
 // Histogram of the use counts per slab.  Most columns have SMALL counts (on a matrix without popular columns all of
@@ -642,19 +677,36 @@ k_hot_threshold(int capacity, int min_count, const uint32_t *__restrict__ chist,
         const int o = __shfl_xor(best, d, OMEGA);
         best = o < best ? o : best;
     }
-    if (lane == 0)
+    // room = slots left for the columns of the next lower count: capacity - 1 - suffix(best)
+    unsigned long long at_best = 0; // suffix(best), held by the lane that owns bucket `best` (0 for best = HOT_BUCKETS)
+    {
+        unsigned long long run = incl - own;
+#pragma unroll
+        for (int i = PER - 1; i >= 0; i--) {
+            run += v[i];
+            if (lane * PER + i == best)
+                at_best = run;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        at_best += __shfl_xor(at_best, d, OMEGA);
+    if (lane == 0) {
         thr[blockIdx.x] = (uint32_t)best;
+        thr[gridDim.x + blockIdx.x] = (uint32_t)((unsigned long long)(capacity - 1) - at_best);
+    }
 }
 
-// pass 0: every column with count >= thr is marked hot; pass 1: columns of the next lower count fill what is left.
-// A workgroup walks HOT_ASSIGN_COLS columns twice: first it counts the slots it wants per slab (LDS), reserves them with
-// ONE global add per slab, then hands them out from LDS counters (196 k adds on 16 words -- one per chosen column -- took
-// 0.9 ms per pass on R-MAT 24).
+// Every column with count >= thr is marked hot; columns of the next lower count fill the room that is left (thr[S + k],
+// from k_hot_threshold), first come first served.  A workgroup walks HOT_ASSIGN_COLS columns twice: first it counts the
+// second-class columns it wants per slab (LDS), reserves them with ONE global add per slab, then hands them out from LDS
+// counters (196 k adds on 16 words -- one per chosen column -- took 0.9 ms on R-MAT 24).  The bitmap only says WHETHER a
+// column gets a slot; k_hot_rank numbers them.
 constexpr int HOT_ASSIGN_COLS = 16384;
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_hot_assign(int n, const uint32_t *__restrict__ cnt, int bits, int shift, const uint32_t *__restrict__ thr,
-             int capacity, int min_count, int pass, int32_t *__restrict__ hot_count, uint32_t *__restrict__ hotbits,
-             size_t G, unsigned long long *__restrict__ covered)
+k_hot_assign(int n, int S, const uint32_t *__restrict__ cnt, int bits, int shift, const uint32_t *__restrict__ thr,
+             int min_count, int32_t *__restrict__ fill, uint32_t *__restrict__ hotbits, size_t G,
+             unsigned long long *__restrict__ covered)
 {
     __shared__ int want[SLAB_MAX], base[SLAB_MAX], given[SLAB_MAX];
     if (threadIdx.x < SLAB_MAX)
@@ -662,32 +714,39 @@ k_hot_assign(int n, const uint32_t *__restrict__ cnt, int bits, int shift, const
     __syncthreads();
     const int first = blockIdx.x * HOT_ASSIGN_COLS;
     const int last = first + HOT_ASSIGN_COLS < n ? first + HOT_ASSIGN_COLS : n;
-    auto chosen = [&](int c, uint32_t &k, uint32_t &v) -> bool {
+    // 0 = not chosen, 1 = first class (count >= thr), 2 = second class (count == thr - 1)
+    auto chosen = [&](int c, uint32_t &k, uint32_t &v) -> int {
         v = cnt[c];
         if (!v)
-            return false;
+            return 0;
         k = slab_of((uint32_t)c, shift, bits);
         const uint32_t bucket = v < HOT_BUCKETS - 1 ? v : HOT_BUCKETS - 1;
         const uint32_t b = thr[k];
-        return pass == 0 ? bucket >= b : (bucket + 1 == b && (int)bucket >= min_count);
+        return bucket >= b ? 1 : (bucket + 1 == b && (int)bucket >= min_count ? 2 : 0);
+    };
+    auto mark = [&](int c, uint32_t k) {
+        const uint32_t local = slab_local((uint32_t)c, shift, bits);
+        atomicOr(&hotbits[(size_t)k * G * 4 + (local >> 5)], 1u << (local & 31));
     };
     uint32_t k = 0, v = 0;
-    for (int c = first + (int)threadIdx.x; c < last; c += SLAB_BLOCK)
-        if (chosen(c, k, v))
+    unsigned long long got = 0;
+    for (int c = first + (int)threadIdx.x; c < last; c += SLAB_BLOCK) {
+        const int cls = chosen(c, k, v);
+        if (cls == 1) {
+            mark(c, k);
+            got += v;
+        } else if (cls == 2) {
             atomicAdd(&want[k], 1);
+        }
+    }
     __syncthreads();
     if (threadIdx.x < SLAB_MAX && want[threadIdx.x])
-        base[threadIdx.x] = atomicAdd(&hot_count[threadIdx.x], want[threadIdx.x]);
+        base[threadIdx.x] = atomicAdd(&fill[threadIdx.x], want[threadIdx.x]);
     __syncthreads();
-    unsigned long long got = 0;
     for (int c = first + (int)threadIdx.x; c < last; c += SLAB_BLOCK)
-        if (chosen(c, k, v)) {
-            const int slot = base[k] + atomicAdd(&given[k], 1);
-            if (slot < capacity) { // (the count decides WHETHER the column gets a slot; k_hot_rank decides which)
-                const uint32_t local = slab_local((uint32_t)c, shift, bits);
-                atomicOr(&hotbits[(size_t)k * G * 4 + (local >> 5)], 1u << (local & 31));
-                got += v;
-            }
+        if (chosen(c, k, v) == 2 && want[k] && base[k] + atomicAdd(&given[k], 1) < (int)thr[S + k]) {
+            mark(c, k);
+            got += v;
         }
     // sampled non-zeros that found a slot: one increment per wavefront
 #pragma unroll
@@ -714,23 +773,21 @@ k_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacity, const uint3
         hot_count[k] = capacity;
 }
 
-// One workgroup per slab: slots in column order.  pre[g] = slot of the first hot column of group g (slot 0 is reserved,
-// so the count starts at 1), hot_cols[slot] = column.
+// Slots in column order: pre[g] = slot of the first hot column of group g (slot 0 is reserved, so the count starts at 1),
+// hot_cols[slot] = column, hot_count[k] = slots in use.  Workgroup (k, j) numbers the groups [j, j + 1) * RANK_BLOCK of
+// slab k; it first counts the set bits in front of them itself (at most 128 KB of bitmap) instead of waiting for the
+// workgroups before it.
 constexpr int RANK_BLOCK = 1024;
 __global__ void __launch_bounds__(RANK_BLOCK)
 k_hot_rank(int bits, int shift, int capacity, size_t G, const uint4 *__restrict__ hotbits, uint16_t *__restrict__ pre,
-           int32_t *__restrict__ hot_cols)
+           int32_t *__restrict__ hot_cols, int32_t *__restrict__ hot_count)
 {
     __shared__ uint32_t wave_total[RANK_BLOCK / OMEGA];
     const uint32_t k = blockIdx.x;
+    const size_t g0 = (size_t)blockIdx.y * RANK_BLOCK;
     const int lane = threadIdx.x & (OMEGA - 1), w = threadIdx.x / OMEGA;
-    uint32_t running = 1;
-    for (size_t g0 = 0; g0 < G; g0 += RANK_BLOCK) {
-        const size_t g = g0 + threadIdx.x;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (g < G)
-            v = hotbits[(size_t)k * G + g];
-        const uint32_t own = (uint32_t)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w));
+    auto bits_of = [](const uint4 v) { return (uint32_t)(__popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w)); };
+    auto block_scan = [&](uint32_t own, uint32_t &before, uint32_t &all) { // exclusive position of `own`, and the total
         uint32_t incl = own;
 #pragma unroll
         for (int d = 1; d < OMEGA; d <<= 1) {
@@ -738,33 +795,47 @@ k_hot_rank(int bits, int shift, int capacity, size_t G, const uint4 *__restrict_
             if (lane >= d)
                 incl += o;
         }
+        __syncthreads(); // (wave_total is reused)
         if (lane == OMEGA - 1)
             wave_total[w] = incl;
         __syncthreads();
-        uint32_t before = 0, all = 0;
+        before = incl - own;
+        all = 0;
         for (int i = 0; i < RANK_BLOCK / OMEGA; i++) {
             before += i < w ? wave_total[i] : 0u;
             all += wave_total[i];
         }
-        uint32_t slot = running + before + incl - own;
-        if (g < G) {
-            pre[(size_t)k * G + g] = (uint16_t)slot;
-            const uint32_t word[4] = {v.x, v.y, v.z, v.w};
+    };
+    uint32_t front = 0;
+    for (size_t g = threadIdx.x; g < g0; g += RANK_BLOCK)
+        front += bits_of(hotbits[(size_t)k * G + g]);
+    uint32_t unused, running;
+    block_scan(front, unused, running);
+    running += 1; // slot 0 is reserved
+    const size_t g = g0 + threadIdx.x;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (g < G)
+        v = hotbits[(size_t)k * G + g];
+    uint32_t before, all;
+    block_scan(bits_of(v), before, all);
+    uint32_t slot = running + before;
+    if (g < G) {
+        pre[(size_t)k * G + g] = (uint16_t)slot;
+        const uint32_t word[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint32_t m = word[i];
-                while (m) {
-                    const uint32_t b = (uint32_t)__builtin_ctz(m);
-                    m &= m - 1;
-                    if ((int)slot < capacity)
-                        hot_cols[(size_t)k * capacity + slot] = (int32_t)slab_column(k, (uint32_t)g * 128u + i * 32u + b, shift, bits);
-                    slot++;
-                }
+        for (int i = 0; i < 4; i++) {
+            uint32_t m = word[i];
+            while (m) {
+                const uint32_t b = (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
+                if ((int)slot < capacity)
+                    hot_cols[(size_t)k * capacity + slot] = (int32_t)slab_column(k, (uint32_t)g * 128u + i * 32u + b, shift, bits);
+                slot++;
             }
         }
-        running += all;
-        __syncthreads();
     }
+    if (blockIdx.y == gridDim.y - 1 && threadIdx.x == 0)
+        hot_count[k] = (int32_t)(running + all);
 }
 
 // Rewrites the column words of the stacked matrix whose column has a slot in its slab's table to 0x80000000 | slot.
@@ -853,8 +924,14 @@ hipError_t slab_partition(const Geometry &g, const DeviceArrays &d, int value_ty
                           uint32_t *hist, void *scan_tmp, size_t scan_tmp_bytes, int32_t *col2, void *val2,
                           uint32_t *key2, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_slab_hist, dim3((g.p + HIST_TILES - 1) / HIST_TILES), dim3(SLAB_BLOCK), 0, s, g, d.col, S, bits, shift, hist);
-    hipError_t e = hipGetLastError();
+    const size_t hist_lds = (size_t)(SLAB_BLOCK / OMEGA) * S * HIST_PAD * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_slab_hist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)hist_lds);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(k_slab_hist, dim3((g.p + HIST_TILES - 1) / HIST_TILES), dim3(SLAB_BLOCK), hist_lds, s, g, d.col, S, bits, shift,
+                       hist);
+    e = hipGetLastError();
     if (e != hipSuccess)
         return e;
     e = rocprim::exclusive_scan(scan_tmp, scan_tmp_bytes, hist, hist, 0u, (size_t)S * g.p, rocprim::plus<uint32_t>(), s);
@@ -949,7 +1026,7 @@ namespace csr5 {
 // Selects the hot columns of every slab and fills hot_cols / hot_count; *covered = sampled non-zeros whose column got a
 // slot.  Needs only the column indices (any order: the parent's array), so it runs BEFORE the partition and its verdict
 // can still change the slab count.  cnt, hotmap, chist, thr: caller-provided scratch (n words, slab_hotmap_bytes,
-// S*HOT_BUCKETS, S words; all zeroed by the caller except thr).
+// S*HOT_BUCKETS, 2 S words; all zeroed by the caller except thr).
 hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capacity, int min_count, int sample_stride,
                            const int32_t *col, uint32_t *cnt, void *hotmap, uint32_t *chist, uint32_t *thr,
                            int32_t *hot_cols, int32_t *hot_count, unsigned long long *covered, hipStream_t s)
@@ -957,20 +1034,26 @@ hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capac
     const size_t G = slab_hot_groups(n, shift, bits);
     uint4 *hotbits = (uint4 *)hotmap;
     uint16_t *hotpre = (uint16_t *)(hotbits + (size_t)S * G);
-    long long blocks = ((long long)nnz / sample_stride + SLAB_BLOCK * 8 - 1) / (SLAB_BLOCK * 8);
-    blocks = blocks < 1 ? 1 : (blocks > 65536 ? 65536 : blocks);
-    // slot 0 of every table is reserved (it holds +0.0, see k_spmv_hot): slots are handed out from 1
-    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)hot_count, 1, (size_t)S, s);
+    long long blocks = ((long long)nnz / sample_stride + COUNT_BLOCK * 8 - 1) / (COUNT_BLOCK * 8);
+    blocks = blocks < 1 ? 1 : (blocks > COUNT_WGS ? COUNT_WGS : blocks);
+    const size_t count_lds = (size_t)COUNT_SLOTS * 8;
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(k_col_count), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)count_lds);
+    if (ea != hipSuccess)
+        return ea;
+    // hot_count doubles as the fill counter of the second-class columns until k_hot_rank writes the slot counts
+    // (slot 0 of every table is reserved -- it holds +0.0, see k_spmv_range -- so those start at 1)
+    hipError_t e = hipMemsetAsync(hot_count, 0, (size_t)S * 4, s);
     if (e != hipSuccess)
         return e;
-    hipLaunchKernelGGL(k_col_count, dim3((unsigned)blocks), dim3(SLAB_BLOCK), 0, s, nnz, sample_stride, col, cnt);
+    hipLaunchKernelGGL(k_col_count, dim3((unsigned)blocks), dim3(COUNT_BLOCK), count_lds, s, nnz, sample_stride, col, cnt);
     hipLaunchKernelGGL(k_hot_hist, dim3((n + HOT_HIST_COLS - 1) / HOT_HIST_COLS), dim3(SLAB_BLOCK), 0, s, n, cnt, S, bits, shift,
                        chist);
     hipLaunchKernelGGL(k_hot_threshold, dim3(S), dim3(OMEGA), 0, s, capacity, min_count, chist, thr);
-    for (int pass = 0; pass < 2; pass++)
-        hipLaunchKernelGGL(k_hot_assign, dim3((n + HOT_ASSIGN_COLS - 1) / HOT_ASSIGN_COLS), dim3(SLAB_BLOCK), 0, s, n, cnt, bits,
-                           shift, thr, capacity, min_count, pass, hot_count, (uint32_t *)hotbits, G, covered);
-    hipLaunchKernelGGL(k_hot_rank, dim3(S), dim3(RANK_BLOCK), 0, s, bits, shift, capacity, G, hotbits, hotpre, hot_cols);
+    hipLaunchKernelGGL(k_hot_assign, dim3((n + HOT_ASSIGN_COLS - 1) / HOT_ASSIGN_COLS), dim3(SLAB_BLOCK), 0, s, n, S, cnt, bits, shift,
+                       thr, min_count, hot_count, (uint32_t *)hotbits, G, covered);
+    hipLaunchKernelGGL(k_hot_rank, dim3(S, (unsigned)((G + RANK_BLOCK - 1) / RANK_BLOCK)), dim3(RANK_BLOCK), 0, s, bits, shift,
+                       capacity, G, hotbits, hotpre, hot_cols, hot_count);
     return hipGetLastError();
 }
 
