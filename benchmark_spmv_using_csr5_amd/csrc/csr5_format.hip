@@ -261,36 +261,55 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_desc_offset(Geometry g, const int
 // r2c: element (lane l, step i) moves from l*sigma+i to i*omega+l; !r2c is the inverse.
 // LDS rows are padded by one element so both passes are bank-conflict free.
 // ---------------------------------------------------------------------------------------------
+__host__ __device__ inline int transpose_pitch(int sigma) { return OMEGA + (OMEGA / sigma > 0 ? OMEGA / sigma : 1); }
+
 template <typename VT>
 __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint32_t *__restrict__ tile_ptr,
                                                      int32_t *__restrict__ col, VT *__restrict__ val,
-                                                     int r2c, uint32_t *__restrict__ counters)
+                                                     int r2c, int tiles_per_block, uint32_t *__restrict__ counters)
 {
     stamp_phase(counters, 2);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int t = blockIdx.x;
-    // fast-track tiles are not transposed; the test is on the RAW words (format_cuda.h:540)
-    if (tile_ptr[t] == tile_ptr[t + 1])
-        return;
+    // A workgroup moves `tiles_per_block` consecutive tiles: the bytes a compute unit has in flight are what bounds this
+    // pass, and eight resident workgroups with one 6-KB tile each (sigma = 8, the slab child) kept it at 6 TB/s.
+    const int t0 = blockIdx.x * tiles_per_block;
     const int T = g.tile_elems;
     const int sigma = g.sigma;
+    // row pitch of the staging area: 64 consecutive CSR ranks are sigma steps x 64/sigma lanes, so a pitch of
+    // 64 + 64/sigma spreads them over all banks (two per bank, the minimum); 65 put them on sigma + 64/sigma - 1 banks
+    const int pitch = transpose_pitch(sigma);
+    const size_t per_tile = (size_t)sigma * pitch;
     VT *sv = reinterpret_cast<VT *>(smem);
-    int32_t *sc = reinterpret_cast<int32_t *>(smem + (size_t)sigma * (OMEGA + 1) * sizeof(VT));
-    const size_t base = (size_t)t * T;
-    for (int idx = threadIdx.x; idx < T; idx += FMT_BLOCK) {
+    int32_t *sc = reinterpret_cast<int32_t *>(smem + per_tile * tiles_per_block * sizeof(VT));
+    __shared__ int moved[16]; // (tiles_per_block <= 16)
+    if ((int)threadIdx.x < tiles_per_block) {
+        const int t = t0 + (int)threadIdx.x;
+        // fast-track tiles are not transposed; the test is on the RAW words (format_cuda.h:540)
+        moved[threadIdx.x] = t < g.p - 1 && tile_ptr[t] != tile_ptr[t + 1];
+    }
+    __syncthreads();
+    const size_t base = (size_t)t0 * T;
+    const int total = tiles_per_block * T;
+    for (int e = threadIdx.x; e < total; e += FMT_BLOCK) {
+        const int tt = e / T, idx = e - tt * T;
+        if (!moved[tt])
+            continue;
         int i, l;
         if (r2c) { i = idx % sigma; l = idx / sigma; }
         else     { l = idx & (OMEGA - 1); i = idx >> 6; }
-        sc[i * (OMEGA + 1) + l] = col[base + idx];
-        sv[i * (OMEGA + 1) + l] = val[base + idx];
+        sc[tt * per_tile + i * pitch + l] = col[base + e];
+        sv[tt * per_tile + i * pitch + l] = val[base + e];
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < T; idx += FMT_BLOCK) {
+    for (int e = threadIdx.x; e < total; e += FMT_BLOCK) {
+        const int tt = e / T, idx = e - tt * T;
+        if (!moved[tt])
+            continue;
         int i, l;
         if (r2c) { l = idx & (OMEGA - 1); i = idx >> 6; }
         else     { i = idx % sigma; l = idx / sigma; }
-        col[base + idx] = sc[i * (OMEGA + 1) + l];
-        val[base + idx] = sv[i * (OMEGA + 1) + l];
+        col[base + e] = sc[tt * per_tile + i * pitch + l];
+        val[base + e] = sv[tt * per_tile + i * pitch + l];
     }
 }
 
@@ -685,13 +704,17 @@ hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_
     if (g.p <= 1)
         return hipSuccess;
     const size_t vsz = value_type == CSR5HIP_F64 ? 8 : 4;
-    const size_t lds = (size_t)g.sigma * (OMEGA + 1) * (vsz + 4);
+    // ~12 KB of tile data per workgroup (one tile at sigma = 16 fp64, two at sigma = 8, ...)
+    int tpb = (int)(12288 / ((size_t)g.tile_elems * (vsz + 4)));
+    tpb = tpb < 1 ? 1 : (tpb > 16 ? 16 : tpb);
+    const size_t lds = (size_t)tpb * g.sigma * transpose_pitch(g.sigma) * (vsz + 4);
+    const dim3 grid((unsigned)((g.p - 1 + tpb - 1) / tpb));
     if (value_type == CSR5HIP_F64)
-        hipLaunchKernelGGL(k_transpose<double>, dim3(g.p - 1), dim3(FMT_BLOCK), lds, s, g, d.tile_ptr,
-                           d.col, (double *)d.val, r2c ? 1 : 0, r2c ? d.counters : nullptr);
+        hipLaunchKernelGGL(k_transpose<double>, grid, dim3(FMT_BLOCK), lds, s, g, d.tile_ptr, d.col, (double *)d.val, r2c ? 1 : 0, tpb,
+                           r2c ? d.counters : nullptr);
     else
-        hipLaunchKernelGGL(k_transpose<float>, dim3(g.p - 1), dim3(FMT_BLOCK), lds, s, g, d.tile_ptr,
-                           d.col, (float *)d.val, r2c ? 1 : 0, r2c ? d.counters : nullptr);
+        hipLaunchKernelGGL(k_transpose<float>, grid, dim3(FMT_BLOCK), lds, s, g, d.tile_ptr, d.col, (float *)d.val, r2c ? 1 : 0, tpb,
+                           r2c ? d.counters : nullptr);
     return hipGetLastError();
 }
 
