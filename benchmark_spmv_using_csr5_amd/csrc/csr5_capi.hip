@@ -136,8 +136,10 @@ struct csr5hip_handle_s {
     // LDS hot table of the slab child (k_spmv_hot): chosen at conversion, see csr5_slab.hip
     int hot_request = 1;      // CSR5HIP_OPT_SLAB_HOT: 0 off, 1 auto, 2 force
     bool hot_enabled = false; // (child) column words are hot-encoded: spmv must use the persistent hot kernel
+    bool hot_packed = false;  // (child) ... as packed codes next to the plain column words: only the values are transposed
     int hot_cover_pct = 0;    // (parent) share of the non-zeros whose column got a table slot
     Buffer b_hot_cols, b_hot_count, b_hot_tile0, b_slab_off, b_lead;
+    Buffer b_col_lo, b_col_hi; // packed column codes of a hot child (3 bytes per non-zero)
 
     // csr5hip_spmv_rotate: one graph over several handles (cold-cache measurement protocol)
     hipGraphExec_t rotate_exec = nullptr;
@@ -586,7 +588,10 @@ int csr5hip_as_csr5(csr5hip_handle h)
         if (rc != CSR5HIP_SUCCESS)
             return rc;
         // step 3: in-place tile transpose of column_index and value, then the kernel-side tables
-        HIP_TRY(launch_transpose(g, h->d, h->value_type, true, s));
+        if (h->is_child && h->hot_packed)
+            HIP_TRY(launch_transpose_values(g, h->d, h->value_type, s)); // (the column codes are read in CSR order)
+        else
+            HIP_TRY(launch_transpose(g, h->d, h->value_type, true, s));
         // From here on the caller's arrays are in tile order while the handle still says CSR: a failure must
         // put them back (a retry would transpose them a second time).
         auto finish = [&]() -> int {
@@ -625,7 +630,7 @@ static void release_slabs(csr5hip_handle h)
         csr5hip_free(h->slab_child);
         h->slab_child = nullptr;
     }
-    for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty, &h->b_hot_cols,
+    for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty, &h->b_col_lo, &h->b_col_hi, &h->b_hot_cols,
                       &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_slab_tmp})
         b->release();
     h->slab_S = 0;
@@ -734,6 +739,7 @@ static int build_slabs_impl(csr5hip_handle h)
     bool hot = h->hot_request != 0 && S % NUM_XCD == 0 && h->opt.mode == 1 && hot_sigma >= 4 && hot_p >= 2 &&
                (long long)g.n * (long long)h->vsize() <= 0x7FFFFFFFLL;
     int hot_capacity = 0;
+    bool hot_packed = false;
     if (hot) {
         int dev = 0, lds_max = 0;
         HIP_TRY(hipGetDevice(&dev));
@@ -887,8 +893,15 @@ static int build_slabs_impl(csr5hip_handle h)
             load[best] += first_tile[k + 1] - first_tile[k];
         }
         HIP_TRY(hipMemcpyAsync((int32_t *)h->b_hot_tile0.ptr + S + 1, order.data(), (size_t)S * 4, hipMemcpyHostToDevice, s));
+        // 3-byte column codes next to the plain words when a lane's codes are whole dwords and a slab-local id fits 23 bits
+        hot_packed = hot_sigma % 4 == 0 && slab_local_columns(g.n, bits, h->slab_shift) <= ((size_t)1 << 23);
+        if (hot_packed) {
+            HIP_TRY(h->b_col_lo.reserve((size_t)g.nnz * 2 + 64));
+            HIP_TRY(h->b_col_hi.reserve((size_t)g.nnz + 64));
+        }
         HIP_TRY(slab_hot_encode(g.n, g.nnz, hot_T, hot_p, S, bits, h->slab_shift, (const int32_t *)h->b_slab_off.ptr,
-                                ht.hotmap, (int32_t *)h->b_col2.ptr, s));
+                                ht.hotmap, (int32_t *)h->b_col2.ptr, hot_packed ? (uint16_t *)h->b_col_lo.ptr : nullptr,
+                                hot_packed ? (uint8_t *)h->b_col_hi.ptr : nullptr, s));
     }
     HIP_TRY(hipStreamSynchronize(s)); // (`order` and the temporaries are in use until here)
 
@@ -907,6 +920,12 @@ static int build_slabs_impl(csr5hip_handle h)
     c->ldsy_request = h->ldsy_request;
     c->nt_request = h->nt_request;
     c->hot_enabled = hot;
+    c->hot_packed = hot && hot_packed;
+    c->d.col_lo = c->hot_packed ? (const uint16_t *)h->b_col_lo.ptr : nullptr;
+    c->d.col_hi = c->hot_packed ? (const uint8_t *)h->b_col_hi.ptr : nullptr;
+    c->d.slab_off = (const int32_t *)h->b_slab_off.ptr;
+    c->d.slab_shift = h->slab_shift;
+    c->d.slab_bits = bits;
     c->d.hot_cols = (const int32_t *)h->b_hot_cols.ptr;
     c->d.hot_count = (const int32_t *)h->b_hot_count.ptr;
     c->d.hot_tile0 = (const int32_t *)h->b_hot_tile0.ptr;
@@ -1403,7 +1422,8 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_fallback = h->slab_fallback ? 1 : 0;
     long long bytes = (long long)h->b_arena.cap;
     for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
-                            &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_slab_tmp})
+                            &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_slab_tmp, &h->b_col_lo,
+                            &h->b_col_hi})
         bytes += (long long)b->cap;
     if (h->slab_child)
         bytes += (long long)h->slab_child->b_arena.cap;

@@ -266,8 +266,10 @@ __host__ __device__ inline int transpose_pitch(int sigma) { return OMEGA + (OMEG
 template <typename VT>
 __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint32_t *__restrict__ tile_ptr,
                                                      int32_t *__restrict__ col, VT *__restrict__ val,
-                                                     int r2c, int tiles_per_block, uint32_t *__restrict__ counters)
+                                                     int r2c, int tiles_per_block, int values_all,
+                                                     uint32_t *__restrict__ counters)
 {
+    // values_all: a hot slab child with packed column codes -- only the values move, and EVERY tile 0 .. p-2 does
     stamp_phase(counters, 2);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // A workgroup moves `tiles_per_block` consecutive tiles: the bytes a compute unit has in flight are what bounds this
@@ -285,7 +287,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint3
     if ((int)threadIdx.x < tiles_per_block) {
         const int t = t0 + (int)threadIdx.x;
         // fast-track tiles are not transposed; the test is on the RAW words (format_cuda.h:540)
-        moved[threadIdx.x] = t < g.p - 1 && tile_ptr[t] != tile_ptr[t + 1];
+        moved[threadIdx.x] = t < g.p - 1 && (values_all || tile_ptr[t] != tile_ptr[t + 1]);
     }
     __syncthreads();
     const size_t base = (size_t)t0 * T;
@@ -297,7 +299,8 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint3
         int i, l;
         if (r2c) { i = idx % sigma; l = idx / sigma; }
         else     { l = idx & (OMEGA - 1); i = idx >> 6; }
-        sc[tt * per_tile + i * pitch + l] = col[base + e];
+        if (!values_all)
+            sc[tt * per_tile + i * pitch + l] = col[base + e];
         sv[tt * per_tile + i * pitch + l] = val[base + e];
     }
     __syncthreads();
@@ -308,7 +311,8 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint3
         int i, l;
         if (r2c) { l = idx & (OMEGA - 1); i = idx >> 6; }
         else     { i = idx % sigma; l = idx / sigma; }
-        col[base + e] = sc[tt * per_tile + i * pitch + l];
+        if (!values_all)
+            col[base + e] = sc[tt * per_tile + i * pitch + l];
         val[base + e] = sv[tt * per_tile + i * pitch + l];
     }
 }
@@ -698,8 +702,7 @@ hipError_t launch_desc_offset(const Geometry &g, const DeviceArrays &d, hipStrea
     return hipGetLastError();
 }
 
-hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c,
-                            hipStream_t s)
+static hipError_t transpose_launch(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c, bool values_all, hipStream_t s)
 {
     if (g.p <= 1)
         return hipSuccess;
@@ -711,11 +714,21 @@ hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_
     const dim3 grid((unsigned)((g.p - 1 + tpb - 1) / tpb));
     if (value_type == CSR5HIP_F64)
         hipLaunchKernelGGL(k_transpose<double>, grid, dim3(FMT_BLOCK), lds, s, g, d.tile_ptr, d.col, (double *)d.val, r2c ? 1 : 0, tpb,
-                           r2c ? d.counters : nullptr);
+                           values_all ? 1 : 0, r2c ? d.counters : nullptr);
     else
         hipLaunchKernelGGL(k_transpose<float>, grid, dim3(FMT_BLOCK), lds, s, g, d.tile_ptr, d.col, (float *)d.val, r2c ? 1 : 0, tpb,
-                           r2c ? d.counters : nullptr);
+                           values_all ? 1 : 0, r2c ? d.counters : nullptr);
     return hipGetLastError();
+}
+
+hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c, hipStream_t s)
+{
+    return transpose_launch(g, d, value_type, r2c, false, s);
+}
+
+hipError_t launch_transpose_values(const Geometry &g, const DeviceArrays &d, int value_type, hipStream_t s)
+{
+    return transpose_launch(g, d, value_type, true, true, s);
 }
 
 // export_only: the matrix is a column-slab child served by the range kernel (csr5_hot.hip), which uses neither carry meta nor

@@ -12,6 +12,7 @@
 //     stores of a wavefront are sequential over its whole range.
 // Round 2's form (tiles dealt round robin, per-tile 32-byte header, short-spill re-reads, arrival protocol) is gone.
 #include "csr5_internal.h"
+#include "csr5_slabmap.h"
 #include "csr5_wave.h"
 
 #include <type_traits>
@@ -20,26 +21,55 @@ namespace csr5 {
 
 constexpr int HOT_BLOCK = 1024;
 
-template <typename VT, int SIGMA>
+// PACKED: the child's column words come as 3-byte codes (k_hot_encode PACK) in CSR order -- lane l's sigma codes are
+// consecutive: 2 sigma bytes of col_lo, sigma bytes of col_hi -- and are decoded into c[] when they have arrived.
+template <typename VT, int SIGMA, bool PACKED>
 struct TileRegs {
     int32_t c[SIGMA];
+    uint32_t plo[PACKED ? SIGMA / 2 : 1], phi[PACKED ? SIGMA / 4 : 1];
     VT v[SIGMA];
     uint32_t w0, tp0, tp1;
 };
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// N consecutive dwords (p 4 N-byte aligned ... at least as far as the widest piece used) with the widest loads
+template <int N, bool NT>
+__device__ __forceinline__ void load_dwords(uint32_t *dst, const uint32_t *p)
+{
+    if constexpr (N >= 4) {
+        const u32x4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p)) : *reinterpret_cast<const u32x4 *>(p);
+        dst[0] = v.x, dst[1] = v.y, dst[2] = v.z, dst[3] = v.w;
+        load_dwords<N - 4, NT>(dst + 4, p + 4);
+    } else if constexpr (N >= 2) {
+        const u32x2 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x2 *>(p)) : *reinterpret_cast<const u32x2 *>(p);
+        dst[0] = v.x, dst[1] = v.y;
+        load_dwords<N - 2, NT>(dst + 2, p + 2);
+    } else if constexpr (N == 1) {
+        dst[0] = NT ? __builtin_nontemporal_load(p) : *p;
+    }
+}
+
 // every load of tile t: column words first (the gathers wait for them only), then the descriptor word, the tile_ptr
 // pair (vector loads of wave-uniform words: they return in order with the rest) and the values
-template <typename VT, int SIGMA, bool NT>
-__device__ __forceinline__ void range_load(TileRegs<VT, SIGMA> &r, const int32_t *__restrict__ col,
+template <typename VT, int SIGMA, bool NT, bool PACKED>
+__device__ __forceinline__ void range_load(TileRegs<VT, SIGMA, PACKED> &r, const int32_t *__restrict__ col,
+                                           const uint16_t *__restrict__ col_lo, const uint8_t *__restrict__ col_hi,
                                            const VT *__restrict__ val, const uint32_t *__restrict__ tile_desc,
                                            const uint32_t *__restrict__ tile_ptr, int t, int lane, int vz)
 {
     constexpr int T = OMEGA * SIGMA;
-    const int32_t *ct = col + (size_t)t * T + lane;
     const VT *vt = val + (size_t)t * T + lane;
+    if constexpr (PACKED) {
+        const size_t first = (size_t)t * T + (size_t)lane * SIGMA;
+        load_dwords<SIGMA / 2, NT>(r.plo, reinterpret_cast<const uint32_t *>(col_lo + first));
+        load_dwords<SIGMA / 4, NT>(r.phi, reinterpret_cast<const uint32_t *>(col_hi + first));
+    } else {
+        const int32_t *ct = col + (size_t)t * T + lane;
 #pragma unroll
-    for (int i = 0; i < SIGMA; i++)
-        r.c[i] = NT ? __builtin_nontemporal_load(ct + i * OMEGA) : ct[i * OMEGA];
+        for (int i = 0; i < SIGMA; i++)
+            r.c[i] = NT ? __builtin_nontemporal_load(ct + i * OMEGA) : ct[i * OMEGA];
+    }
     r.w0 = tile_desc[(size_t)t * OMEGA + lane];
     r.tp0 = tile_ptr[t + vz];
     r.tp1 = tile_ptr[t + 1 + vz];
@@ -56,7 +86,7 @@ struct OpenRow {
     bool is_lead; // the row was already open when the range began: the partial goes to lead[range], not to P
 };
 
-template <typename VT, int SIGMA, bool NT, int DEPTH>
+template <typename VT, int SIGMA, bool NT, int DEPTH, bool PACKED>
 __global__ void __launch_bounds__(HOT_BLOCK)
 k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__ val, const VT *__restrict__ x,
              const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc, VT *__restrict__ P,
@@ -139,17 +169,53 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
             return __builtin_bit_cast(word_t, hot[cw < 0 ? (unsigned)cw & 0x7FFFFFFFu : 0u]);
         };
 
+        // PACKED: the 3-byte codes of tile t -> column words (bit 31 | slot, or the column itself).  A slab-local id is
+        // turned back into the column with the slab of the element: this slab's, except behind the slab's end inside its
+        // last tile (the elements there belong to the following slab(s)).  A quarter fewer column bytes and two wide loads
+        // instead of eight for ~25 vector instructions per element.  Their NUMBER is free (profiles/r03_probes.txt), their
+        // latency is not -- this code sits between the arrival of the codes and the issue of the tile's gathers: with the
+        // data-dependent loop of slab_of in it the packed kernel was 2 % slower than the unpacked one, straight-line it is
+        // 1.3 % faster.
+        const long long own_end = PACKED ? (long long)hp.slab_off[k + 1] : 0;
+        auto decode = [&](TileRegs<VT, SIGMA, PACKED> &tr, int t) {
+            if constexpr (PACKED) {
+                constexpr int T = OMEGA * SIGMA;
+                const long long first = (long long)t * T;
+                uint32_t code[SIGMA];
+#pragma unroll
+                for (int i = 0; i < SIGMA; i++)
+                    code[i] = ((tr.plo[i / 2] >> (16 * (i & 1))) & 0xFFFFu) | (((tr.phi[i / 4] >> (8 * (i & 3))) & 0xFFu) << 16);
+                if (first + T <= own_end) { // (wave-uniform) straight-line: this code sits in front of the tile's gathers
+#pragma unroll
+                    for (int i = 0; i < SIGMA; i++)
+                        tr.c[i] = (code[i] & 0x800000u) ? (int32_t)(0x80000000u | (code[i] & 0x7FFFFFu))
+                                                        : (int32_t)slab_column_straight((uint32_t)k, code[i], hp.shift, hp.bits);
+                } else { // the slab ends inside this tile (one tile per slab)
+#pragma unroll
+                    for (int i = 0; i < SIGMA; i++) {
+                        const long long pos = first + (long long)lane * SIGMA + i;
+                        uint32_t slab = (uint32_t)k;
+                        for (int j = k + 1; j < hp.slabs; j++)
+                            slab = pos >= (long long)hp.slab_off[j] ? (uint32_t)j : slab;
+                        tr.c[i] = (code[i] & 0x800000u) ? (int32_t)(0x80000000u | (code[i] & 0x7FFFFFu))
+                                                        : (int32_t)slab_column(slab, code[i], hp.shift, hp.bits);
+                    }
+                }
+            }
+        };
+
         // ---- one tile whose loads (streams in `tr`, cold gathers in `xg`) are in flight or done -------------------------
-        auto compute = [&](const TileRegs<VT, SIGMA> &tr, const word_t (&xg)[SIGMA]) {
+        auto compute = [&](const TileRegs<VT, SIGMA, PACKED> &tr, const word_t (&xg)[SIGMA]) {
             VT mx[SIGMA];
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
                 mx[i] = __builtin_bit_cast(VT, (word_t)(xg[i] | table_word(tr.c[i])));
             const uint32_t tp0 = __builtin_amdgcn_readfirstlane(tr.tp0), tp1 = __builtin_amdgcn_readfirstlane(tr.tp1);
+            const uint32_t w0 = tr.w0;
             const int rs = (int)(tp0 & ROW_MASK);
             // decode before any data-dependent branch (loads consumed only inside a branch get sunk into it)
-            const uint32_t flags = tr.w0 << bit_all; // element i -> bit 31-i
-            int y_off = (int)(tr.w0 >> (32 - bit_y));
+            const uint32_t flags = w0 << bit_all; // element i -> bit 31-i
+            int y_off = (int)(w0 >> (32 - bit_y));
             const bool f0 = (flags >> 31) | (lane == 0);
             const bool present = f0 | ((flags & 0x7FFFFFFFu) != 0);
             if (open.row < 0)
@@ -263,12 +329,16 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
             open.is_lead = false;
         };
 
+        auto load = [&](TileRegs<VT, SIGMA, PACKED> &tr, int t) {
+            range_load<VT, SIGMA, NT, PACKED>(tr, col, hp.col_lo, hp.col_hi, val, tile_desc, tile_ptr, t, lane, vz);
+        };
         if constexpr (DEPTH == 1) {
             for (int t = tb; t < te; t++) {
-                TileRegs<VT, SIGMA> a;
+                TileRegs<VT, SIGMA, PACKED> a;
                 word_t xa[SIGMA];
-                range_load<VT, SIGMA, NT>(a, col, val, tile_desc, tile_ptr, t, lane, vz);
+                load(a, t);
                 __builtin_amdgcn_sched_barrier(0);
+                decode(a, t);
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++)
                     xa[i] = cold_word(a.c[i]);
@@ -281,30 +351,33 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
             // `break` in the middle of the pair loop leaves the compiler a path on which the second set's loads are
             // still pending at the loop head, and it then drains the whole queue (s_waitcnt vmcnt(0)) in front of
             // every pair's gathers.
-            TileRegs<VT, SIGMA> a, b;
+            TileRegs<VT, SIGMA, PACKED> a, b;
             word_t xa[SIGMA];
-            range_load<VT, SIGMA, NT>(a, col, val, tile_desc, tile_ptr, tb, lane, vz);
+            load(a, tb);
             int t = tb;
             for (; t + 1 < te; t += 2) {
                 __builtin_amdgcn_sched_barrier(0);
+                decode(a, t);
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++)
                     xa[i] = cold_word(a.c[i]);
                 __builtin_amdgcn_sched_barrier(0);
-                range_load<VT, SIGMA, NT>(b, col, val, tile_desc, tile_ptr, t + 1, lane, vz);
+                load(b, t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(a, xa);
                 __builtin_amdgcn_sched_barrier(0);
+                decode(b, t + 1);
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++)
                     xa[i] = cold_word(b.c[i]);
                 __builtin_amdgcn_sched_barrier(0);
-                range_load<VT, SIGMA, NT>(a, col, val, tile_desc, tile_ptr, t + 2 < te ? t + 2 : t + 1, lane, vz);
+                load(a, t + 2 < te ? t + 2 : t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(b, xa);
             }
             if (t < te) {
                 __builtin_amdgcn_sched_barrier(0);
+                decode(a, t);
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++)
                     xa[i] = cold_word(a.c[i]);
@@ -417,13 +490,14 @@ k_range_finish(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *_
 }
 
 // ---- dispatch ----------------------------------------------------------------------------------------------------------
-template <typename VT, int SIGMA, bool NT>
+template <typename VT, int SIGMA, bool NT, bool PACKED>
 static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const void *x, void *y, hipStream_t s)
 {
-    HotParams hp{d.hot_slabs, d.hot_slabs / NUM_XCD, d.hot_capacity, d.hot_cols, d.hot_count, d.hot_tile0};
+    HotParams hp{d.hot_slabs, d.hot_slabs / NUM_XCD, d.hot_capacity, d.hot_cols, d.hot_count, d.hot_tile0,
+                 d.col_lo,    d.col_hi,               d.slab_off,     d.slab_shift, d.slab_bits};
     const size_t lds = (size_t)d.hot_capacity * sizeof(VT) + (size_t)HOT_WAVES * HOT_WAVE_LDS;
     constexpr int DEPTH = CSR5_HOT_DEPTH;
-    auto kern = k_spmv_range<VT, SIGMA, NT, DEPTH>;
+    auto kern = k_spmv_range<VT, SIGMA, NT, DEPTH, PACKED>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess)
         return e;
@@ -441,6 +515,19 @@ static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const v
     return hipGetLastError();
 }
 
+// packed column codes exist only for child sigmas that are multiples of four (whole dwords of col_lo / col_hi per lane)
+template <typename VT, int S>
+static hipError_t launch_range_packed(const Geometry &g, const DeviceArrays &d, const void *x, void *y, bool nt, hipStream_t s)
+{
+    if constexpr (S % 4 == 0) {
+        if (d.col_lo)
+            return nt ? launch_range<VT, S, true, true>(g, d, x, y, s) : launch_range<VT, S, false, true>(g, d, x, y, s);
+    }
+    if (d.col_lo)
+        return hipErrorInvalidValue;
+    return nt ? launch_range<VT, S, true, false>(g, d, x, y, s) : launch_range<VT, S, false, false>(g, d, x, y, s);
+}
+
 template <typename VT>
 static hipError_t launch_range_sigma(const Geometry &g, const DeviceArrays &d, const void *x, void *y, bool nt, hipStream_t s)
 {
@@ -448,7 +535,7 @@ static hipError_t launch_range_sigma(const Geometry &g, const DeviceArrays &d, c
 #define CSR5_HOT_CASE(S)                                                                                               \
     case S:                                                                                                            \
         if constexpr ((size_t)OMEGA * S * sizeof(VT) <= (size_t)HOT_WAVE_LDS)                                          \
-            return nt ? launch_range<VT, S, true>(g, d, x, y, s) : launch_range<VT, S, false>(g, d, x, y, s);         \
+            return launch_range_packed<VT, S>(g, d, x, y, nt, s);                                                     \
         else                                                                                                           \
             return hipErrorInvalidValue;
         CSR5_HOT_CASE(4) CSR5_HOT_CASE(5) CSR5_HOT_CASE(6) CSR5_HOT_CASE(7) CSR5_HOT_CASE(8) CSR5_HOT_CASE(9)

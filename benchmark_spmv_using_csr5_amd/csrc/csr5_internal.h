@@ -76,6 +76,12 @@ struct DeviceArrays {
     const int32_t *hot_tile0;  // [hot_slabs + 1] first tile of every slab, then [hot_slabs] the slabs each XCD walks
     int hot_slabs, hot_capacity;
     void *range_lead;          // [hot_slabs * HOT_RANGES_PER_SLAB] of vT: leading partial of every wavefront range (csr5_hot.hip)
+    // packed column codes of a hot child (k_hot_encode PACK): 3 bytes per non-zero in the child's CSR order; nullptr = the
+    // column words themselves are hot-encoded (col)
+    const uint16_t *col_lo;
+    const uint8_t *col_hi;
+    const int32_t *slab_off;   // [hot_slabs + 1] first child element of every slab
+    int slab_shift, slab_bits; // the column -> slab map (csr5_slab.hip slab_of)
 };
 
 // ---- conversion (csr5_format.hip) ----
@@ -86,6 +92,9 @@ hipError_t launch_offset_scan(const Geometry &g, const DeviceArrays &d, void *tm
 hipError_t launch_desc_offset(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c,
                             hipStream_t s);
+// a hot child with packed column codes: values only, EVERY tile 0 .. p-2 (the range kernel's fast track sums a one-row tile
+// in any order, and the packed codes are read in CSR order)
+hipError_t launch_transpose_values(const Geometry &g, const DeviceArrays &d, int value_type, hipStream_t s);
 hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int value_size, uint32_t *host_words, bool export_only,
                               hipStream_t s);
 hipError_t launch_warmup(hipStream_t s);
@@ -110,7 +119,8 @@ hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capac
 hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacity, const uint32_t *chunk_start,
                            int32_t *hot_count, int32_t *tile0, int32_t *slab_off, hipStream_t s);
 hipError_t slab_hot_encode(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
-                           const void *hotmap, int32_t *col2, hipStream_t s);
+                           const void *hotmap, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, hipStream_t s);
+size_t slab_local_columns(int n, int bits, int shift); // columns of one slab (slab-local ids 0 .. this - 1)
 size_t slab_hotmap_bytes(int n, int S, int bits, int shift); // slab-major bitmap of the hot columns + group prefixes
 int slab_hot_buckets();
 hipError_t launch_slab_combine(int m, int tail_start, int zero_empty, int S, int value_type, const uint32_t *base,
@@ -142,6 +152,11 @@ struct HotParams {
     const int32_t *count;            // [slabs] slots in use
     const int32_t *tile0;            // [slabs + 1] first tile owned by each slab (tile0[S] = p - 1); behind it [slabs]: the slabs of
                                      // XCD 0 (one per round), of XCD 1, ... (dealt by size at conversion)
+    // packed column codes (DeviceArrays::col_lo ...), used by the PACKED kernel variant only
+    const uint16_t *col_lo;
+    const uint8_t *col_hi;
+    const int32_t *slab_off;
+    int shift, bits;
 };
 // child sigma of a hot slab structure: small enough for the y-compaction region (measured: the hot kernel is flat in
 // sigma between 8 and 16, R-MAT 22 320 / 324 / 329 us at 8 / 12 / 16)

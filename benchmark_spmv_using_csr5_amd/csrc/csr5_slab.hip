@@ -28,6 +28,7 @@
 //   k_slab_base     thread / (row block, slab): first segment of the run (binary search on the sorted segment keys)
 //   k_slab_nonempty thread / row: one bit per row of the parent
 #include "csr5_internal.h"
+#include "csr5_slabmap.h"
 
 #include <rocprim/device/device_scan.hpp>
 
@@ -37,41 +38,6 @@ constexpr int SLAB_BLOCK = 256;
 constexpr int SLAB_MAX = 64;
 constexpr uint32_t SLAB_KEY_FIRST = 0x80000000u; // key bit: first element of a slab
 
-// slab of a column = xor of all `bits`-wide groups of (col >> shift).  (A fold by halves -- five uniform steps instead of a
-// loop whose length depends on the column -- was slower: most columns need two or three rounds.)
-__device__ __forceinline__ uint32_t slab_of(uint32_t col, int shift, int bits)
-{
-    uint32_t v = col >> shift, out = 0;
-    const uint32_t mask = (1u << bits) - 1u;
-    while (v) {
-        out ^= v & mask;
-        v >>= bits;
-    }
-    return out;
-}
-
-// Columns of one slab, renumbered densely: the slab is the xor of all `bits`-wide groups of (col >> shift), so given the slab
-// the LOWEST group is determined by the others -- dropping it is a bijection from the slab's columns onto [0, L),
-// L = slab_local_count(n).  The hot map is stored slab after slab in these local ids, as a BITMAP (bit = the column owns a
-// table slot) plus the number of set bits in front of every 128-bit group: slots are handed out in column order, so the
-// slot of a hot column is that prefix + the set bits below it in its group.  One slab's slice is 18 bytes per 128 columns
-// (144 KB for R-MAT 24 at 16 slabs): k_hot_encode keeps it in LDS.  (A map of 2 bytes per column cost one L1 line fill
-// per non-zero: 1.7 ms on R-MAT 24.)
-__host__ __device__ inline uint32_t slab_local(uint32_t col, int shift, int bits)
-{
-    return ((col >> (shift + bits)) << shift) | (col & ((1u << shift) - 1u));
-}
-__host__ __device__ inline size_t slab_local_count(int n, int shift, int bits)
-{
-    return ((size_t)(((uint32_t)(n > 0 ? n - 1 : 0)) >> (shift + bits)) + 1) << shift;
-}
-// the column of slab k with local id `local` (inverse of slab_local on that slab)
-__device__ __forceinline__ uint32_t slab_column(uint32_t k, uint32_t local, int shift, int bits)
-{
-    const uint32_t hi = local >> shift, lo = local & ((1u << shift) - 1u);
-    const uint32_t low_group = k ^ slab_of(hi << shift, shift, bits); // xor of the groups above the lowest one
-    return (hi << (shift + bits)) | (low_group << shift) | lo;
-}
 // 128-bit groups of one slab's bitmap
 __host__ __device__ inline size_t slab_hot_groups(int n, int shift, int bits) { return (slab_local_count(n, shift, bits) + 127) / 128; }
 // set bits of a group below position `bit`, and whether `bit` itself is set
@@ -844,10 +810,17 @@ k_hot_rank(int bits, int shift, int capacity, size_t G, const uint4 *__restrict_
 // more than ~1.1 M columns reads them from memory instead) and streams its share of the slab's column words, four per
 // lane and load.
 constexpr int ENCODE_BLOCK = 1024, ENCODE_WGS_PER_XCD = 32, ENCODE_UNROLL = 4;
-template <bool IN_LDS>
+// PACK: instead of rewriting col2, every column word of the tiles 0 .. p-2 is written as a 24-bit code -- low 16 bits to
+// col_lo, high 8 bits to col_hi, both in the child's CSR order, which is already the order lane l of k_spmv_range wants
+// (its sigma elements are consecutive there): bit 23 = table slot in bits 0..13, else the slab-LOCAL column id (< 2^23).
+// 3 bytes per non-zero instead of 4 in the SpMV's streams; col2 stays plain (the CSR tail tile reads it).  Elements behind
+// the slab's end inside its last tile belong to the next slab: they are coded as plain local ids of THEIR slab (the SpMV
+// kernel knows where a slab ends).
+template <bool IN_LDS, bool PACK>
 __global__ void __launch_bounds__(ENCODE_BLOCK)
 k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *__restrict__ slab_off,
-             const uint4 *__restrict__ hotbits, const uint16_t *__restrict__ hotpre, size_t G, int32_t *__restrict__ col2)
+             const uint4 *__restrict__ hotbits, const uint16_t *__restrict__ hotpre, size_t G, int32_t *__restrict__ col2,
+             uint16_t *__restrict__ col_lo, uint8_t *__restrict__ col_hi)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *lbits = reinterpret_cast<uint4 *>(smem);
@@ -869,21 +842,33 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
             }
             __syncthreads();
         }
-        auto encode = [&](int32_t c) -> int32_t {
-            const uint32_t local = slab_local((uint32_t)c, shift, bits);
+        const long long own_end = soff[mine + 1];
+        // (the element's slot in its slab's table, or -1)
+        auto slot_of = [&](uint32_t local) -> int {
             const uint32_t g = local >> 7;
             uint32_t below;
             const bool hot = hot_lookup(IN_LDS ? lbits[g] : gb[g], local & 127u, below);
-            return hot ? (int32_t)(0x80000000u | ((uint32_t)(IN_LDS ? lpre[g] : gp[g]) + below)) : c;
+            return hot ? (int)((uint32_t)(IN_LDS ? lpre[g] : gp[g]) + below) : -1;
+        };
+        auto encode = [&](int32_t c, long long pos) -> int32_t {
+            const uint32_t local = slab_local((uint32_t)c, shift, bits);
+            if (PACK) {
+                const int slot = pos < own_end ? slot_of(local) : -1;
+                return slot >= 0 ? (int32_t)(0x800000u | (uint32_t)slot) : (int32_t)local;
+            }
+            const int slot = slot_of(local);
+            return slot >= 0 ? (int32_t)(0x80000000u | (uint32_t)slot) : c;
         };
         // An element inside a tile owned by the PREVIOUS slab (a tile belongs to the slab of its first element) is gathered
         // with that slab's table in LDS: it keeps its plain word.  So the slab's share starts at its first own tile.
         const long long begin = ((long long)soff[mine] + T - 1) / T * T;
-        long long end = soff[mine + 1];
+        long long end = PACK ? (own_end + T - 1) / T * T : own_end; // PACK: the whole last tile, foreign elements included
         end = end < last ? end : last;
         if (begin >= end)
             continue;
         int4 *c4 = reinterpret_cast<int4 *>(col2 + begin); // (T is a multiple of 64: 16-byte aligned)
+        uint2 *lo4 = reinterpret_cast<uint2 *>(col_lo + begin);
+        uint32_t *hi4 = reinterpret_cast<uint32_t *>(col_hi + begin);
         const long long quads = (end - begin) / 4;
         for (long long q0 = (long long)j * ENCODE_BLOCK * ENCODE_UNROLL; q0 < quads;
              q0 += (long long)nj * ENCODE_BLOCK * ENCODE_UNROLL) {
@@ -898,17 +883,25 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
             for (int u = 0; u < ENCODE_UNROLL; u++) {
                 const long long q = q0 + u * ENCODE_BLOCK + threadIdx.x;
                 if (q < quads) {
-                    v[u].x = encode(v[u].x);
-                    v[u].y = encode(v[u].y);
-                    v[u].z = encode(v[u].z);
-                    v[u].w = encode(v[u].w);
-                    c4[q] = v[u];
+                    const long long pos = begin + q * 4;
+                    v[u].x = encode(v[u].x, pos);
+                    v[u].y = encode(v[u].y, pos + 1);
+                    v[u].z = encode(v[u].z, pos + 2);
+                    v[u].w = encode(v[u].w, pos + 3);
+                    if (PACK) {
+                        const uint32_t a = (uint32_t)v[u].x, b = (uint32_t)v[u].y, c = (uint32_t)v[u].z, d = (uint32_t)v[u].w;
+                        lo4[q] = make_uint2((a & 0xFFFFu) | (b << 16), (c & 0xFFFFu) | (d << 16));
+                        hi4[q] = ((a >> 16) & 0xFFu) | (((b >> 16) & 0xFFu) << 8) | (((c >> 16) & 0xFFu) << 16) | ((d >> 16) << 24);
+                    } else {
+                        c4[q] = v[u];
+                    }
                 }
             }
         }
-        if (j == 0 && (long long)threadIdx.x < end - begin - quads * 4) {
+        // (PACK: begin and end are multiples of the tile size, nothing is left over)
+        if (!PACK && j == 0 && (long long)threadIdx.x < end - begin - quads * 4) {
             const long long pos = begin + quads * 4 + threadIdx.x;
-            col2[pos] = encode(col2[pos]);
+            col2[pos] = encode(col2[pos], pos);
         }
     }
 }
@@ -1067,25 +1060,33 @@ hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacit
     return hipGetLastError();
 }
 
+// col_lo != nullptr: packed 3-byte codes into col_lo / col_hi (col2 is only read); else col2 is rewritten in place
 hipError_t slab_hot_encode(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
-                           const void *hotmap, int32_t *col2, hipStream_t s)
+                           const void *hotmap, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, hipStream_t s)
 {
     const size_t G = slab_hot_groups(n, shift, bits);
     const uint4 *hotbits = (const uint4 *)hotmap;
     const uint16_t *hotpre = (const uint16_t *)(hotbits + (size_t)S * G);
     const size_t lds = G * (sizeof(uint4) + sizeof(uint16_t));
     const dim3 grid(NUM_XCD * ENCODE_WGS_PER_XCD), block(ENCODE_BLOCK);
-    if (lds <= 150 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_hot_encode<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-        hipLaunchKernelGGL(k_hot_encode<true>, grid, block, lds, s, nnz, T, p, S, bits, shift, slab_off, hotbits, hotpre, G, col2);
-    } else {
-        hipLaunchKernelGGL(k_hot_encode<false>, grid, block, 0, s, nnz, T, p, S, bits, shift, slab_off, hotbits, hotpre, G, col2);
-    }
-    return hipGetLastError();
+    const bool in_lds = lds <= 150 * 1024, pack = col_lo != nullptr;
+    auto launch = [&](auto kern) -> hipError_t {
+        if (in_lds) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)lds);
+            if (e != hipSuccess)
+                return e;
+        }
+        hipLaunchKernelGGL(kern, grid, block, in_lds ? lds : 0, s, nnz, T, p, S, bits, shift, slab_off, hotbits, hotpre, G, col2,
+                           col_lo, col_hi);
+        return hipGetLastError();
+    };
+    if (in_lds)
+        return pack ? launch(k_hot_encode<true, true>) : launch(k_hot_encode<true, false>);
+    return pack ? launch(k_hot_encode<false, true>) : launch(k_hot_encode<false, false>);
 }
+
+size_t slab_local_columns(int n, int bits, int shift) { return slab_local_count(n, shift, bits); }
 
 // slab-major bitmap of the hot columns (16 bytes per 128 slab-local columns) followed by the 2-byte group prefixes
 size_t slab_hotmap_bytes(int n, int S, int bits, int shift)
