@@ -783,8 +783,9 @@ static int build_slabs_impl(csr5hip_handle h)
                  o_count = take(16), o_sel = take(sel_bytes), o_cnt = take(nb), o_hotmap = take(hotmap_bytes), o_chist = take(hb),
                  o_thr = take((size_t)S_alloc * 8);
     if (h->slab_mem_mib > 0) {
-        // second copy of column_index / value + build temporaries + (upper bound) one partial sum per non-zero row piece
-        const unsigned long long need = (unsigned long long)g.nnz * (4 + h->vsize()) + off +
+        // second copy of column_index / value (+ 3-byte column codes with a hot table) + build temporaries + (upper bound)
+        // one partial sum per non-zero row piece
+        const unsigned long long need = (unsigned long long)g.nnz * (4 + h->vsize() + (hot ? 3 : 0)) + off +
                                         (unsigned long long)g.m * (h->vsize() + 5);
         if (need > (unsigned long long)h->slab_mem_mib << 20)
             return fail_hip(hipErrorOutOfMemory, "column slabs: CSR5HIP_OPT_SLAB_MEMORY_MIB");
