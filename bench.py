@@ -103,6 +103,10 @@ def parse_args():
     ap.add_argument("--slabs", default="auto", help="column slabs: auto (default), 0 = off, 2..64 = that many")
     ap.add_argument("--slab-shift", type=int, default=None)
     ap.add_argument("--slab-hot", default="auto", choices=["auto", "off", "force"], help="LDS hot table of the slab kernel")
+    ap.add_argument("--x-snapshot", type=int, default=1, choices=[0, 1],
+                    help="hot-table slab kernel: 1 (default) = its permuted copy of x is taken once per setX, as the reference CLI's "
+                         "protocol allows (setX once, NUM_RUN spmv calls on the same x: CSR5_cuda/main.cu:63-99); 0 = by every "
+                         "spmv (the library default: x is read live)")
     ap.add_argument("--zero-empty", type=int, default=0, choices=[0, 1],
                     help="1 = rows without non-zeros are written as 0 (CSR5HIP_OPT_ZERO_EMPTY_ROWS; the coupled-iteration setting)")
     ap.add_argument("--scaling", default=None, choices=[None, "weak", "strong"],
@@ -229,6 +233,9 @@ class Problem:
         if args.slab_shift is not None:
             _ck(A.setSlabShift(args.slab_shift), "setSlabShift")
         _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
+        rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 1)))
+        if rc != 0 and not os.environ.get("CSR5HIP_LIB"):  # (an older library build under A/B test does not know the option)
+            _ck(rc, "setXSnapshot")
         if getattr(args, "zero_empty", 0):
             _ck(A.setZeroEmptyRows(1), "setZeroEmptyRows")
         A.warmup()
@@ -352,6 +359,9 @@ def config_dict(prob, args, ingest_ms=None):
         "column_slabs": info.column_slabs, "slab_shift": info.slab_shift, "slab_segments": info.slab_segments,
         "slab_sigma": info.slab_sigma, "slab_build_ms": round(info.t_slab_ms, 3),
         "slab_hot_table": bool(info.slab_hot), "slab_hot_cover_pct": info.slab_hot_cover_pct,
+        "x_permuted_copy": bool(info.slab_x_permuted), "x_cold_entries": info.slab_cold_entries,
+        "x_snapshot": ("once per setX (CSR5HIP_OPT_X_SNAPSHOT = 1; reference CLI protocol: setX once, then the timed spmv loop)"
+                       if info.x_snapshot else "every spmv (library default)") if info.slab_x_permuted else None,
         "values": "rand()%10 integers (reference CLI data, exact in fp)" if args.values == "int" else "uniform(-1,1)",
         "ingest_ms": ingest_ms,
         "csr_to_csr5_ms": round(prob.convert_ms, 3),

@@ -140,6 +140,11 @@ struct csr5hip_handle_s {
     int hot_cover_pct = 0;    // (parent) share of the non-zeros whose column got a table slot
     Buffer b_hot_cols, b_hot_count, b_hot_tile0, b_slab_off, b_lead;
     Buffer b_col_lo, b_col_hi; // packed column codes of a hot child (3 bytes per non-zero)
+    // permuted copy of x behind the packed codes (csr5_hot.hip k_x_permute): table images + frequency-ordered cold regions
+    Buffer b_cold_base, b_cold_cols, b_xperm;
+    int x_snapshot = 0;    // CSR5HIP_OPT_X_SNAPSHOT: 0 = the copy is refreshed by every spmv(), 1 = by setX only
+    bool xperm_valid = false; // (snapshot mode) the copy holds the current x
+    int cold_total = 0;       // entries of the cold region
 
     // csr5hip_spmv_rotate: one graph over several handles (cold-cache measurement protocol)
     hipGraphExec_t rotate_exec = nullptr;
@@ -282,6 +287,7 @@ int csr5hip_set_x(csr5hip_handle h, const void *d_x)
     if (!h)
         return CSR5HIP_INVALID_ARGUMENT;
     h->x = d_x;
+    h->xperm_valid = false; // (snapshot mode: the next spmv() takes a new copy)
     h->drop_graphs();
     return CSR5HIP_SUCCESS;
 }
@@ -387,6 +393,12 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         break;
     case CSR5HIP_OPT_ZERO_EMPTY_ROWS:
         h->zero_empty = value ? 1 : 0;
+        break;
+    case CSR5HIP_OPT_X_SNAPSHOT:
+        if (value != 0 && value != 1)
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->x_snapshot = value;
+        h->xperm_valid = false;
         break;
     case CSR5HIP_OPT_SLAB_MEMORY_MIB:
         if (value < 0)
@@ -631,7 +643,8 @@ static void release_slabs(csr5hip_handle h)
         h->slab_child = nullptr;
     }
     for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty, &h->b_col_lo, &h->b_col_hi, &h->b_hot_cols,
-                      &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_slab_tmp})
+                      &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_slab_tmp, &h->b_cold_base, &h->b_cold_cols,
+                      &h->b_xperm})
         b->release();
     h->slab_S = 0;
     h->slab_m2 = 0;
@@ -782,6 +795,17 @@ static int build_slabs_impl(csr5hip_handle h)
     const size_t o_hist = take((size_t)S_alloc * g.p * 4), o_scan = take(scan_bytes), o_key = take((size_t)g.nnz * 4),
                  o_count = take(16), o_sel = take(sel_bytes), o_cnt = take(nb), o_hotmap = take(hotmap_bytes), o_chist = take(hb),
                  o_thr = take((size_t)S_alloc * 8);
+    // ranking of the cold columns behind the packed codes (slab_hot_pack): counts / ranks, sort keys in and out, sources
+    size_t cold_words = 0, cold_sort_bytes = 0;
+    int bits_first = 0;
+    while ((1 << bits_first) < S)
+        bits_first++;
+    if (hot) {
+        cold_words = slab_cold_words(g.n, S, bits_first, h->slab_shift);
+        HIP_TRY(slab_cold_sort_tmp_bytes(cold_words, bits_first + 10, &cold_sort_bytes));
+    }
+    const size_t o_cnt2 = take(cold_words * 4), o_keys = take(cold_words * 4), o_keys2 = take(cold_words * 4),
+                 o_src = take(cold_words * 4), o_sort = take(cold_sort_bytes);
     if (h->slab_mem_mib > 0) {
         // second copy of column_index / value (+ 3-byte column codes with a hot table) + build temporaries + (upper bound)
         // one partial sum per non-zero row piece
@@ -896,13 +920,28 @@ static int build_slabs_impl(csr5hip_handle h)
         HIP_TRY(hipMemcpyAsync((int32_t *)h->b_hot_tile0.ptr + S + 1, order.data(), (size_t)S * 4, hipMemcpyHostToDevice, s));
         // 3-byte column codes next to the plain words when a lane's codes are whole dwords and a slab-local id fits 23 bits
         hot_packed = hot_sigma % 4 == 0 && slab_local_columns(g.n, bits, h->slab_shift) <= ((size_t)1 << 23);
+        int32_t cold_total = 0;
         if (hot_packed) {
             HIP_TRY(h->b_col_lo.reserve((size_t)g.nnz * 2 + 64));
             HIP_TRY(h->b_col_hi.reserve((size_t)g.nnz + 64));
+            // the cold region holds at most one entry per column of every slab, and no more than there are non-zeros
+            const size_t cold_cap = std::min(cold_words, (size_t)g.nnz);
+            HIP_TRY(h->b_cold_base.reserve(((size_t)S + 1) * 4));
+            HIP_TRY(h->b_cold_cols.reserve((cold_cap + 1) * 4));
+            HIP_TRY(h->b_xperm.reserve(((size_t)S * hot_capacity + cold_cap + 1) * h->vsize()));
+            HIP_TRY(hipMemsetAsync(tb + o_cnt2, 0, cold_words * 4, s));
+            HIP_TRY(slab_hot_pack(g.n, g.nnz, hot_T, hot_p, S, bits, h->slab_shift, (const int32_t *)h->b_slab_off.ptr, ht.hotmap,
+                                  (int32_t *)h->b_col2.ptr, (uint16_t *)h->b_col_lo.ptr, (uint8_t *)h->b_col_hi.ptr,
+                                  (uint32_t *)(tb + o_cnt2), (uint32_t *)(tb + o_keys), (uint32_t *)(tb + o_keys2),
+                                  (uint32_t *)(tb + o_src), tb + o_sort, cold_sort_bytes, (int32_t *)h->b_cold_base.ptr,
+                                  (int32_t *)h->b_cold_cols.ptr, s));
+            HIP_TRY(hipMemcpyAsync(&cold_total, (int32_t *)h->b_cold_base.ptr + S, 4, hipMemcpyDeviceToHost, s));
+        } else {
+            HIP_TRY(slab_hot_rewrite(g.n, g.nnz, hot_T, hot_p, S, bits, h->slab_shift, (const int32_t *)h->b_slab_off.ptr,
+                                     ht.hotmap, (int32_t *)h->b_col2.ptr, s));
         }
-        HIP_TRY(slab_hot_encode(g.n, g.nnz, hot_T, hot_p, S, bits, h->slab_shift, (const int32_t *)h->b_slab_off.ptr,
-                                ht.hotmap, (int32_t *)h->b_col2.ptr, hot_packed ? (uint16_t *)h->b_col_lo.ptr : nullptr,
-                                hot_packed ? (uint8_t *)h->b_col_hi.ptr : nullptr, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        h->cold_total = cold_total;
     }
     HIP_TRY(hipStreamSynchronize(s)); // (`order` and the temporaries are in use until here)
 
@@ -927,6 +966,11 @@ static int build_slabs_impl(csr5hip_handle h)
     c->d.slab_off = (const int32_t *)h->b_slab_off.ptr;
     c->d.slab_shift = h->slab_shift;
     c->d.slab_bits = bits;
+    c->d.xperm = c->hot_packed ? h->b_xperm.ptr : nullptr;
+    c->d.cold_base = c->hot_packed ? (const int32_t *)h->b_cold_base.ptr : nullptr;
+    c->d.cold_cols = c->hot_packed ? (const int32_t *)h->b_cold_cols.ptr : nullptr;
+    c->d.cold_total = c->hot_packed ? h->cold_total : 0;
+    h->xperm_valid = false;
     c->d.hot_cols = (const int32_t *)h->b_hot_cols.ptr;
     c->d.hot_count = (const int32_t *)h->b_hot_count.ptr;
     c->d.hot_tile0 = (const int32_t *)h->b_hot_tile0.ptr;
@@ -947,13 +991,33 @@ static int build_slabs_impl(csr5hip_handle h)
     return CSR5HIP_SUCCESS;
 }
 
+// CSR5HIP_OPT_X_SNAPSHOT: the permuted copy of x is taken once per setX -- here, on stream s, in front of the first SpMV
+// (or graph capture) that needs it
+static hipError_t ensure_x_snapshot(csr5hip_handle h, hipStream_t s)
+{
+    if (!h->x_snapshot || h->xperm_valid || h->slab_S <= 0 || !h->slab_child->hot_packed)
+        return hipSuccess;
+    hipError_t e = launch_x_permute(h->slab_child->d, h->value_type, h->x, s);
+    if (e == hipSuccess)
+        h->xperm_valid = true;
+    return e;
+}
+
 // one SpMV on stream s: the tile kernel on the matrix itself, or -- with column slabs -- on the stacked matrix
 // followed by the combine kernel
 static hipError_t enqueue_spmv(csr5hip_handle h, void *d_y, hipStream_t s)
 {
     if (h->slab_S > 0) {
         csr5hip_handle c = h->slab_child;
-        hipError_t e = launch_spmv(c->g, c->d, c->value_type, h->x, h->b_P.ptr, c->opt, s);
+        hipError_t e = hipSuccess;
+        if (c->hot_packed && !(h->x_snapshot && h->xperm_valid)) {
+            // the packed codes index the permuted copy of x: taken by every spmv() (x is read live, as the reference reads
+            // it), or -- CSR5HIP_OPT_X_SNAPSHOT -- once per setX
+            e = launch_x_permute(c->d, c->value_type, h->x, s);
+            if (e != hipSuccess)
+                return e;
+        }
+        e = launch_spmv(c->g, c->d, c->value_type, h->x, h->b_P.ptr, c->opt, s);
         if (e != hipSuccess)
             return e;
         return launch_slab_combine(h->g.m, h->g.tail_start, h->zero_empty, h->slab_S, h->value_type,
@@ -1210,6 +1274,7 @@ int csr5hip_spmv(csr5hip_handle h, double alpha, void *d_y)
         return CSR5HIP_UNKOWN_FORMAT;
     if (!h->x)
         return CSR5HIP_INVALID_ARGUMENT;
+    HIP_TRY(ensure_x_snapshot(h, h->stream));
     HIP_TRY(enqueue_spmv(h, d_y, h->stream));
     return CSR5HIP_SUCCESS;
 }
@@ -1226,6 +1291,7 @@ int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count)
         return CSR5HIP_INVALID_ARGUMENT;
     if (count == 0)
         return CSR5HIP_SUCCESS;
+    HIP_TRY(ensure_x_snapshot(h, h->stream));
     GraphKey key{d_y, count, h->opt.mode};
     auto it = h->graphs.find(key);
     if (it == h->graphs.end()) {
@@ -1277,6 +1343,8 @@ int csr5hip_spmv_rotate(csr5hip_handle *hs, void **d_ys, int k, double alpha, in
     if (count == 0)
         return CSR5HIP_SUCCESS;
     csr5hip_handle h0 = hs[0];
+    for (int i = 0; i < k; i++)
+        HIP_TRY(ensure_x_snapshot(hs[i], h0->stream));
     std::vector<void *> key;
     key.push_back((void *)(intptr_t)count);
     for (int i = 0; i < k; i++) {
@@ -1421,10 +1489,13 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_hot = h->slab_S > 0 && h->slab_child->hot_enabled ? 1 : 0;
     info->slab_hot_cover_pct = h->hot_cover_pct;
     info->slab_fallback = h->slab_fallback ? 1 : 0;
+    info->slab_x_permuted = h->slab_S > 0 && h->slab_child->hot_packed ? 1 : 0;
+    info->slab_cold_entries = info->slab_x_permuted ? h->cold_total : 0;
+    info->x_snapshot = h->x_snapshot;
     long long bytes = (long long)h->b_arena.cap;
     for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
                             &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_slab_tmp, &h->b_col_lo,
-                            &h->b_col_hi})
+                            &h->b_col_hi, &h->b_cold_base, &h->b_cold_cols, &h->b_xperm})
         bytes += (long long)b->cap;
     if (h->slab_child)
         bytes += (long long)h->slab_child->b_arena.cap;

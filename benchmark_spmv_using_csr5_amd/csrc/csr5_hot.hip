@@ -51,12 +51,12 @@ __device__ __forceinline__ void load_dwords(uint32_t *dst, const uint32_t *p)
 }
 
 // every load of tile t: column words first (the gathers wait for them only), then the descriptor word, the tile_ptr
-// pair (vector loads of wave-uniform words: they return in order with the rest) and the values
+// pair (scalar) and the values
 template <typename VT, int SIGMA, bool NT, bool PACKED>
 __device__ __forceinline__ void range_load(TileRegs<VT, SIGMA, PACKED> &r, const int32_t *__restrict__ col,
                                            const uint16_t *__restrict__ col_lo, const uint8_t *__restrict__ col_hi,
                                            const VT *__restrict__ val, const uint32_t *__restrict__ tile_desc,
-                                           const uint32_t *__restrict__ tile_ptr, int t, int lane, int vz)
+                                           const uint32_t *__restrict__ tile_ptr, int t, int lane)
 {
     constexpr int T = OMEGA * SIGMA;
     const VT *vt = val + (size_t)t * T + lane;
@@ -71,8 +71,13 @@ __device__ __forceinline__ void range_load(TileRegs<VT, SIGMA, PACKED> &r, const
             r.c[i] = NT ? __builtin_nontemporal_load(ct + i * OMEGA) : ct[i * OMEGA];
     }
     r.w0 = tile_desc[(size_t)t * OMEGA + lane];
-    r.tp0 = tile_ptr[t + vz];
-    r.tp1 = tile_ptr[t + 1 + vz];
+    {
+        // the tile_ptr pair is wave-uniform: through the scalar cache (constant address space -> s_load_dwordx2, requested
+        // one tile ahead like the streams), which keeps it off the vector memory path -- the unit this kernel saturates
+        const auto *tpc = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)tile_ptr;
+        r.tp0 = tpc[t];
+        r.tp1 = tpc[t + 1];
+    }
 #pragma unroll
     for (int i = 0; i < SIGMA; i++)
         r.v[i] = NT ? __builtin_nontemporal_load(vt + i * OMEGA) : vt[i * OMEGA];
@@ -102,34 +107,56 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
     const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, nwg = gridDim.x / NUM_XCD;
     const int lane = threadIdx.x & (OMEGA - 1), wave = threadIdx.x >> 6;
     VT *seg = reinterpret_cast<VT *>(smem + (size_t)hp.capacity * sizeof(VT) + (size_t)wave * HOT_WAVE_LDS);
-    const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(x), (short)0, g.n * (int)sizeof(VT), 0x00020000);
-    int vz; // opaque per-lane zero: keeps the wave-uniform tile_ptr words on the vector memory path (in-order return)
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    // Cold gathers.  PACKED: from the cold region of the permuted copy of x (hp.xp: [slabs][capacity] table images, then
+    // every slab's cold columns in descending order of use -- k_x_permute), so that the part of x a slab gathers from is
+    // dense and its popular prefix stays in the XCD's L2; otherwise from x itself.
+    const VT *xcold = PACKED ? static_cast<const VT *>(hp.xp) + (size_t)hp.slabs * hp.capacity : x;
+    const int xcold_bytes = PACKED ? hp.cold_total * (int)sizeof(VT) : g.n * (int)sizeof(VT);
+    const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(xcold), (short)0, xcold_bytes, 0x00020000);
 
     for (int r = 0; r < hp.rounds; r++) {
         const int k = hp.tile0[hp.slabs + 1 + xcd * hp.rounds + r];
         const int nhot = hp.count[k];
-        const int32_t *hc = hp.cols + (size_t)k * hp.capacity;
         __syncthreads(); // every wavefront is done with the previous slab's table
-        // Refill in batches of 16 slots per thread: all column words first (coalesced), then all gathers, then the
-        // LDS writes -- two memory round trips per batch instead of two dependent ones per slot.
-        for (int j0 = 0; j0 < nhot; j0 += HOT_BLOCK * 16) {
-            int32_t cw[16];
-            VT xw[16];
+        if constexpr (PACKED) {
+            // the slab's table image is one contiguous run of the permuted copy: a coalesced copy
+            const VT *img = static_cast<const VT *>(hp.xp) + (size_t)k * hp.capacity;
+            for (int j0 = 0; j0 < nhot; j0 += HOT_BLOCK * 8) {
+                VT xw[8];
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
-                cw[q] = hc[j < nhot ? j : 0]; // (unconditional load at a clamped index: a select on the LOADED value compiles to
-                                              //  sixteen branches with a full wait each)
+                for (int q = 0; q < 8; q++) {
+                    const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
+                    xw[q] = img[j < nhot ? j : 0];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
+                    if (j < nhot)
+                        hot[j] = j ? xw[q] : (VT)0; // slot 0 = +0.0: what the cold lanes read
+                }
             }
+        } else {
+            const int32_t *hc = hp.cols + (size_t)k * hp.capacity;
+            // Refill in batches of 16 slots per thread: all column words first (coalesced), then all gathers, then the
+            // LDS writes -- two memory round trips per batch instead of two dependent ones per slot.
+            for (int j0 = 0; j0 < nhot; j0 += HOT_BLOCK * 16) {
+                int32_t cw[16];
+                VT xw[16];
 #pragma unroll
-            for (int q = 0; q < 16; q++)
-                xw[q] = x[(uint32_t)cw[q]];
+                for (int q = 0; q < 16; q++) {
+                    const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
+                    cw[q] = hc[j < nhot ? j : 0]; // (unconditional load at a clamped index: a select on the LOADED value compiles to
+                                                  //  sixteen branches with a full wait each)
+                }
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
-                if (j < nhot)
-                    hot[j] = j ? xw[q] : (VT)0; // slot 0 = +0.0: what the cold lanes read
+                for (int q = 0; q < 16; q++)
+                    xw[q] = x[(uint32_t)cw[q]];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
+                    if (j < nhot)
+                        hot[j] = j ? xw[q] : (VT)0; // slot 0 = +0.0: what the cold lanes read
+                }
             }
         }
         __syncthreads();
@@ -169,14 +196,12 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
             return __builtin_bit_cast(word_t, hot[cw < 0 ? (unsigned)cw & 0x7FFFFFFFu : 0u]);
         };
 
-        // PACKED: the 3-byte codes of tile t -> column words (bit 31 | slot, or the column itself).  A slab-local id is
-        // turned back into the column with the slab of the element: this slab's, except behind the slab's end inside its
-        // last tile (the elements there belong to the following slab(s)).  A quarter fewer column bytes and two wide loads
-        // instead of eight for ~25 vector instructions per element.  Their NUMBER is free (profiles/r03_probes.txt), their
-        // latency is not -- this code sits between the arrival of the codes and the issue of the tile's gathers: with the
-        // data-dependent loop of slab_of in it the packed kernel was 2 % slower than the unpacked one, straight-line it is
-        // 1.3 % faster.
+        // PACKED: the 3-byte codes of tile t -> gather words (bit 31 | slot, or the index into the cold region of the
+        // permuted copy: start of the element's slab + its column's rank there).  The element's slab is this slab, except
+        // behind the slab's end inside its last tile (the elements there belong to the following slab(s)).  A quarter fewer
+        // column bytes and two wide loads instead of eight; the decode is a shift, an or and an add per element.
         const long long own_end = PACKED ? (long long)hp.slab_off[k + 1] : 0;
+        const int32_t own_base = PACKED ? hp.cold_base[k] : 0;
         auto decode = [&](TileRegs<VT, SIGMA, PACKED> &tr, int t) {
             if constexpr (PACKED) {
                 constexpr int T = OMEGA * SIGMA;
@@ -189,16 +214,15 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
 #pragma unroll
                     for (int i = 0; i < SIGMA; i++)
                         tr.c[i] = (code[i] & 0x800000u) ? (int32_t)(0x80000000u | (code[i] & 0x7FFFFFu))
-                                                        : (int32_t)slab_column_straight((uint32_t)k, code[i], hp.shift, hp.bits);
+                                                        : (int32_t)code[i] + own_base;
                 } else { // the slab ends inside this tile (one tile per slab)
 #pragma unroll
                     for (int i = 0; i < SIGMA; i++) {
                         const long long pos = first + (long long)lane * SIGMA + i;
-                        uint32_t slab = (uint32_t)k;
+                        int32_t base = own_base;
                         for (int j = k + 1; j < hp.slabs; j++)
-                            slab = pos >= (long long)hp.slab_off[j] ? (uint32_t)j : slab;
-                        tr.c[i] = (code[i] & 0x800000u) ? (int32_t)(0x80000000u | (code[i] & 0x7FFFFFu))
-                                                        : (int32_t)slab_column(slab, code[i], hp.shift, hp.bits);
+                            base = pos >= (long long)hp.slab_off[j] ? hp.cold_base[j] : base;
+                        tr.c[i] = (code[i] & 0x800000u) ? (int32_t)(0x80000000u | (code[i] & 0x7FFFFFu)) : (int32_t)code[i] + base;
                     }
                 }
             }
@@ -330,7 +354,7 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
         };
 
         auto load = [&](TileRegs<VT, SIGMA, PACKED> &tr, int t) {
-            range_load<VT, SIGMA, NT, PACKED>(tr, col, hp.col_lo, hp.col_hi, val, tile_desc, tile_ptr, t, lane, vz);
+            range_load<VT, SIGMA, NT, PACKED>(tr, col, hp.col_lo, hp.col_hi, val, tile_desc, tile_ptr, t, lane);
         };
         if constexpr (DEPTH == 1) {
             for (int t = tb; t < te; t++) {
@@ -346,8 +370,8 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
                 compute(a, xa);
             }
         } else {
-            // DEPTH 2: the next tile's streams go out right behind this tile's gathers and are in flight while it
-            // computes.  Tiles are taken in pairs (two register sets, no copies) and an odd last tile is peeled: a
+            // DEPTH 2: the next tile's streams go out right in front of this tile's gathers (their long HBM round trip
+            // starts first; same-call A/B: 1 % faster than behind them) and are in flight while it computes.  Tiles are taken in pairs (two register sets, no copies) and an odd last tile is peeled: a
             // `break` in the middle of the pair loop leaves the compiler a path on which the second set's loads are
             // still pending at the loop head, and it then drains the whole queue (s_waitcnt vmcnt(0)) in front of
             // every pair's gathers.
@@ -357,21 +381,21 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
             int t = tb;
             for (; t + 1 < te; t += 2) {
                 __builtin_amdgcn_sched_barrier(0);
+                load(b, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
                 decode(a, t);
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++)
                     xa[i] = cold_word(a.c[i]);
                 __builtin_amdgcn_sched_barrier(0);
-                load(b, t + 1);
-                __builtin_amdgcn_sched_barrier(0);
                 compute(a, xa);
+                __builtin_amdgcn_sched_barrier(0);
+                load(a, t + 2 < te ? t + 2 : t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 decode(b, t + 1);
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++)
                     xa[i] = cold_word(b.c[i]);
-                __builtin_amdgcn_sched_barrier(0);
-                load(a, t + 2 < te ? t + 2 : t + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 compute(b, xa);
             }
@@ -489,12 +513,58 @@ k_range_finish(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *_
     P[me.row] = sum;
 }
 
+// ---- the permuted copy of x ---------------------------------------------------------------------------------------------
+// One gather of the entries the hot child reads, in the order it reads them: the table images of all slabs (hot_cols),
+// then every slab's cold columns by descending use (cold_cols).  The column lists are read coalesced, x is gathered
+// (inside a slab's cold region ties keep column order, so the gather sweeps x upwards class by class), the copy is
+// written coalesced.
+template <typename VT>
+__global__ void __launch_bounds__(256)
+k_x_permute(int hot_entries, int cold_total, const int32_t *__restrict__ hot_cols, const int32_t *__restrict__ cold_cols,
+            const VT *__restrict__ x, VT *__restrict__ xp)
+{
+    constexpr int PER = 4;
+    const long long total = (long long)hot_entries + cold_total;
+    const long long i0 = ((long long)blockIdx.x * PER) * 256 + threadIdx.x;
+    int32_t c[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const long long i = i0 + u * 256;
+        c[u] = i < hot_entries ? hot_cols[i] : (i < total ? cold_cols[i - hot_entries] : 0);
+    }
+    VT v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++)
+        v[u] = x[(uint32_t)c[u]];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const long long i = i0 + u * 256;
+        if (i < total)
+            xp[i] = v[u];
+    }
+}
+
+hipError_t launch_x_permute(const DeviceArrays &d, int value_type, const void *x, hipStream_t s)
+{
+    const long long hot_entries = (long long)d.hot_slabs * d.hot_capacity, total = hot_entries + d.cold_total;
+    if (total <= 0)
+        return hipSuccess;
+    const unsigned blocks = (unsigned)((total + 1023) / 1024);
+    if (value_type == CSR5HIP_F64)
+        hipLaunchKernelGGL(k_x_permute<double>, dim3(blocks), dim3(256), 0, s, (int)hot_entries, d.cold_total, d.hot_cols,
+                           d.cold_cols, (const double *)x, (double *)const_cast<void *>(d.xperm));
+    else
+        hipLaunchKernelGGL(k_x_permute<float>, dim3(blocks), dim3(256), 0, s, (int)hot_entries, d.cold_total, d.hot_cols,
+                           d.cold_cols, (const float *)x, (float *)const_cast<void *>(d.xperm));
+    return hipGetLastError();
+}
+
 // ---- dispatch ----------------------------------------------------------------------------------------------------------
 template <typename VT, int SIGMA, bool NT, bool PACKED>
 static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const void *x, void *y, hipStream_t s)
 {
     HotParams hp{d.hot_slabs, d.hot_slabs / NUM_XCD, d.hot_capacity, d.hot_cols, d.hot_count, d.hot_tile0,
-                 d.col_lo,    d.col_hi,               d.slab_off,     d.slab_shift, d.slab_bits};
+                 d.col_lo,    d.col_hi,               d.slab_off,     d.xperm,    d.cold_base,  d.cold_total};
     const size_t lds = (size_t)d.hot_capacity * sizeof(VT) + (size_t)HOT_WAVES * HOT_WAVE_LDS;
     constexpr int DEPTH = CSR5_HOT_DEPTH;
     auto kern = k_spmv_range<VT, SIGMA, NT, DEPTH, PACKED>;

@@ -82,6 +82,11 @@ struct DeviceArrays {
     const uint8_t *col_hi;
     const int32_t *slab_off;   // [hot_slabs + 1] first child element of every slab
     int slab_shift, slab_bits; // the column -> slab map (csr5_slab.hip slab_of)
+    // permuted copy of x for the packed codes (k_x_permute): [hot_slabs][hot_capacity] table images, then the cold region
+    const void *xperm;
+    const int32_t *cold_base;  // [hot_slabs + 1] start of every slab's cold entries inside the cold region
+    const int32_t *cold_cols;  // [cold_total] column behind every cold entry
+    int cold_total;
 };
 
 // ---- conversion (csr5_format.hip) ----
@@ -118,8 +123,14 @@ hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capac
                            int32_t *hot_cols, int32_t *hot_count, unsigned long long *covered, hipStream_t s);
 hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacity, const uint32_t *chunk_start,
                            int32_t *hot_count, int32_t *tile0, int32_t *slab_off, hipStream_t s);
-hipError_t slab_hot_encode(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
-                           const void *hotmap, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, hipStream_t s);
+hipError_t slab_hot_rewrite(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
+                            const void *hotmap, int32_t *col2, hipStream_t s);
+size_t slab_cold_words(int n, int S, int bits, int shift);
+hipError_t slab_cold_sort_tmp_bytes(size_t total, int key_bits, size_t *bytes);
+hipError_t slab_hot_pack(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off, const void *hotmap,
+                         int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint32_t *cnt2, uint32_t *keys, uint32_t *keys_sorted,
+                         uint32_t *src_sorted, void *sort_tmp, size_t sort_tmp_bytes, int32_t *cold_base, int32_t *cold_cols,
+                         hipStream_t s);
 size_t slab_local_columns(int n, int bits, int shift); // columns of one slab (slab-local ids 0 .. this - 1)
 size_t slab_hotmap_bytes(int n, int S, int bits, int shift); // slab-major bitmap of the hot columns + group prefixes
 int slab_hot_buckets();
@@ -156,7 +167,9 @@ struct HotParams {
     const uint16_t *col_lo;
     const uint8_t *col_hi;
     const int32_t *slab_off;
-    int shift, bits;
+    const void *xp;                  // permuted copy of x (DeviceArrays::xperm)
+    const int32_t *cold_base;
+    int cold_total;
 };
 // child sigma of a hot slab structure: small enough for the y-compaction region (measured: the hot kernel is flat in
 // sigma between 8 and 16, R-MAT 22 320 / 324 / 329 us at 8 / 12 / 16)
@@ -170,5 +183,8 @@ hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type,
 // csr5_hot.hip: the slab child's SpMV when its column words are hot-encoded (persistent range kernel + finish)
 hipError_t launch_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, void *y,
                            const SpmvOptions &opt, hipStream_t s);
+// the permuted copy of x behind the packed codes of a hot child: xperm[i] = x[hot_cols[i]] for the table images,
+// xperm[slabs * capacity + i] = x[cold_cols[i]] for the cold region
+hipError_t launch_x_permute(const DeviceArrays &d, int value_type, const void *x, hipStream_t s);
 
 } // namespace csr5

@@ -30,7 +30,9 @@
 #include "csr5_internal.h"
 #include "csr5_slabmap.h"
 
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 namespace csr5 {
 
@@ -804,23 +806,30 @@ k_hot_rank(int bits, int shift, int capacity, size_t G, const uint4 *__restrict_
         hot_count[k] = (int32_t)(running + all);
 }
 
-// Rewrites the column words of the stacked matrix whose column has a slot in its slab's table to 0x80000000 | slot.
-// Persistent: workgroup b runs on XCD b % 8 (observed placement, used for locality only) and takes the slabs k = xcd,
-// xcd + 8, ... one after the other; per slab it stages the slab's bitmap and group prefixes in LDS (IN_LDS; a slab with
-// more than ~1.1 M columns reads them from memory instead) and streams its share of the slab's column words, four per
-// lane and load.
+// One persistent pass over the child's column words, slab after slab: workgroup b runs on XCD b % 8 (observed placement,
+// used for locality only) and takes the slabs k = xcd, xcd + 8, ...; per slab it stages the slab's hot bitmap and group
+// prefixes in LDS (IN_LDS; a slab with more than ~1.1 M columns reads them from memory instead) and streams its share
+// of the slab's column words, four per lane and load.  What it does with an element depends on MODE:
+//   ENC_REWRITE  a column with a slot in its slab's table becomes 0x80000000 | slot in col2 itself (child sigmas that are
+//                not multiples of four: the SpMV kernel reads 4-byte words and gathers cold columns from x directly)
+//   ENC_COUNT    counts how often every column is gathered COLD (not through the table) -- cnt2[slab][local id]; the
+//                ranking below turns the counts into the slab's frequency order
+//   ENC_PACK     every column word of the tiles 0 .. p-2 is written as a 24-bit code -- low 16 bits to col_lo, high 8 bits
+//                to col_hi, both in the child's CSR order, which is already the order lane l of k_spmv_range wants (its
+//                sigma elements are consecutive there): bit 23 = table slot in bits 0..13, else the RANK of the column in
+//                its slab's frequency order (rank_of[slab][local id], < 2^23) = its index in the slab's cold region of
+//                the permuted copy of x (csr5_hot.hip).  3 bytes per non-zero instead of 4 in the SpMV's streams; col2
+//                stays plain (the CSR tail tile reads it).
+// A tile belongs to the slab of its first element.  Elements behind the slab's end inside its last tile belong to the
+// following slab(s): they are cold there (that tile runs with THIS slab's table) and are counted / coded with the
+// numbering of THEIR slab.
 constexpr int ENCODE_BLOCK = 1024, ENCODE_WGS_PER_XCD = 32, ENCODE_UNROLL = 4;
-// PACK: instead of rewriting col2, every column word of the tiles 0 .. p-2 is written as a 24-bit code -- low 16 bits to
-// col_lo, high 8 bits to col_hi, both in the child's CSR order, which is already the order lane l of k_spmv_range wants
-// (its sigma elements are consecutive there): bit 23 = table slot in bits 0..13, else the slab-LOCAL column id (< 2^23).
-// 3 bytes per non-zero instead of 4 in the SpMV's streams; col2 stays plain (the CSR tail tile reads it).  Elements behind
-// the slab's end inside its last tile belong to the next slab: they are coded as plain local ids of THEIR slab (the SpMV
-// kernel knows where a slab ends).
-template <bool IN_LDS, bool PACK>
+constexpr int ENC_REWRITE = 0, ENC_COUNT = 1, ENC_PACK = 2;
+template <bool IN_LDS, int MODE>
 __global__ void __launch_bounds__(ENCODE_BLOCK)
 k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *__restrict__ slab_off,
              const uint4 *__restrict__ hotbits, const uint16_t *__restrict__ hotpre, size_t G, int32_t *__restrict__ col2,
-             uint16_t *__restrict__ col_lo, uint8_t *__restrict__ col_hi)
+             uint16_t *__restrict__ col_lo, uint8_t *__restrict__ col_hi, uint32_t *__restrict__ cnt2, size_t L)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *lbits = reinterpret_cast<uint4 *>(smem);
@@ -838,7 +847,8 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
             __syncthreads(); // (the previous slab's look-ups are done)
             for (size_t g = threadIdx.x; g < G; g += ENCODE_BLOCK) {
                 lbits[g] = gb[g];
-                lpre[g] = gp[g];
+                if (MODE != ENC_COUNT)
+                    lpre[g] = gp[g];
             }
             __syncthreads();
         }
@@ -848,21 +858,30 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
             const uint32_t g = local >> 7;
             uint32_t below;
             const bool hot = hot_lookup(IN_LDS ? lbits[g] : gb[g], local & 127u, below);
+            if (MODE == ENC_COUNT)
+                return hot ? 0 : -1;
             return hot ? (int)((uint32_t)(IN_LDS ? lpre[g] : gp[g]) + below) : -1;
         };
         auto encode = [&](int32_t c, long long pos) -> int32_t {
             const uint32_t local = slab_local((uint32_t)c, shift, bits);
-            if (PACK) {
-                const int slot = pos < own_end ? slot_of(local) : -1;
-                return slot >= 0 ? (int32_t)(0x800000u | (uint32_t)slot) : (int32_t)local;
+            if (MODE == ENC_REWRITE) {
+                const int slot = slot_of(local);
+                return slot >= 0 ? (int32_t)(0x80000000u | (uint32_t)slot) : c;
             }
-            const int slot = slot_of(local);
-            return slot >= 0 ? (int32_t)(0x80000000u | (uint32_t)slot) : c;
+            const int slot = pos < own_end ? slot_of(local) : -1;
+            if (slot >= 0)
+                return (int32_t)(0x800000u | (uint32_t)slot);
+            const size_t at = (size_t)(pos < own_end ? (uint32_t)mine : slab_of((uint32_t)c, shift, bits)) * L + local;
+            if (MODE == ENC_COUNT) {
+                atomicAdd(&cnt2[at], 1u);
+                return 0;
+            }
+            return (int32_t)cnt2[at]; // ENC_PACK: cnt2 holds rank_of by now
         };
-        // An element inside a tile owned by the PREVIOUS slab (a tile belongs to the slab of its first element) is gathered
-        // with that slab's table in LDS: it keeps its plain word.  So the slab's share starts at its first own tile.
+        // An element inside a tile owned by the PREVIOUS slab is gathered with that slab's table in LDS: it is that
+        // slab's business (REWRITE: it keeps its plain word).  So the slab's share starts at its first own tile.
         const long long begin = ((long long)soff[mine] + T - 1) / T * T;
-        long long end = PACK ? (own_end + T - 1) / T * T : own_end; // PACK: the whole last tile, foreign elements included
+        long long end = MODE == ENC_REWRITE ? own_end : (own_end + T - 1) / T * T; // else: the whole last tile, foreign elements included
         end = end < last ? end : last;
         if (begin >= end)
             continue;
@@ -888,22 +907,85 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
                     v[u].y = encode(v[u].y, pos + 1);
                     v[u].z = encode(v[u].z, pos + 2);
                     v[u].w = encode(v[u].w, pos + 3);
-                    if (PACK) {
+                    if (MODE == ENC_PACK) {
                         const uint32_t a = (uint32_t)v[u].x, b = (uint32_t)v[u].y, c = (uint32_t)v[u].z, d = (uint32_t)v[u].w;
                         lo4[q] = make_uint2((a & 0xFFFFu) | (b << 16), (c & 0xFFFFu) | (d << 16));
                         hi4[q] = ((a >> 16) & 0xFFu) | (((b >> 16) & 0xFFu) << 8) | (((c >> 16) & 0xFFu) << 16) | ((d >> 16) << 24);
-                    } else {
+                    } else if (MODE == ENC_REWRITE) {
                         c4[q] = v[u];
                     }
                 }
             }
         }
-        // (PACK: begin and end are multiples of the tile size, nothing is left over)
-        if (!PACK && j == 0 && (long long)threadIdx.x < end - begin - quads * 4) {
+        // (COUNT / PACK: begin and end are multiples of the tile size, nothing is left over)
+        if (MODE == ENC_REWRITE && j == 0 && (long long)threadIdx.x < end - begin - quads * 4) {
             const long long pos = begin + quads * 4 + threadIdx.x;
             col2[pos] = encode(col2[pos], pos);
         }
     }
+}
+
+// ---- frequency order of the cold columns of every slab (the layout of the permuted copy of x, csr5_hot.hip) ----------
+// cnt2[slab][local id] = cold uses of the column (ENC_COUNT).  A stable radix sort on (slab, 1023 - min(count, 1023))
+// with the index as payload puts every slab's columns in descending order of use, ties in column order; the first
+// ncold[k] positions of slab k (count > 0) are the slab's cold region.  Hot columns (gathered from the LDS table) and
+// columns nobody references have count 0 and fall behind it.
+constexpr uint32_t COLD_COUNT_CAP = 1023;
+__global__ void __launch_bounds__(SLAB_BLOCK)
+k_cold_keys(size_t total, size_t L, const uint32_t *__restrict__ cnt2, uint32_t *__restrict__ keys)
+{
+    const size_t i = (size_t)blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    if (i >= total)
+        return;
+    const uint32_t c = cnt2[i];
+    keys[i] = ((uint32_t)(i / L) << 10) | (COLD_COUNT_CAP - (c < COLD_COUNT_CAP ? c : COLD_COUNT_CAP));
+}
+// one thread per slab: ncold[k] = columns of slab k with a cold use (their keys sort in front of (k << 10) | 1023), then
+// cold_base[k] = start of the slab's cold region (exclusive prefix; cold_base[S] = all cold entries)
+__global__ void __launch_bounds__(SLAB_MAX)
+k_cold_layout(int S, size_t L, const uint32_t *__restrict__ keys_sorted, int32_t *__restrict__ cold_base)
+{
+    __shared__ int32_t n[SLAB_MAX];
+    const int k = threadIdx.x;
+    if (k < S) {
+        const uint32_t none = ((uint32_t)k << 10) | COLD_COUNT_CAP;
+        size_t lo = (size_t)k * L, hi = lo + L;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            if (keys_sorted[mid] < none)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        n[k] = (int32_t)(lo - (size_t)k * L);
+    }
+    __syncthreads();
+    if (k == 0) {
+        int32_t run = 0;
+        for (int i = 0; i < S; i++) {
+            cold_base[i] = run;
+            run += n[i];
+        }
+        cold_base[S] = run;
+    }
+}
+// sorted position q of slab k -> rank r = q - k L: rank_of[source index] = r (overwrites the counts), and the column of
+// the slab's r-th cold entry
+__global__ void __launch_bounds__(SLAB_BLOCK)
+k_cold_rank(size_t total, size_t L, int bits, int shift, const uint32_t *__restrict__ src_sorted,
+            const int32_t *__restrict__ cold_base, uint32_t *__restrict__ rank_of, int32_t *__restrict__ cold_cols)
+{
+    const size_t q = (size_t)blockIdx.x * SLAB_BLOCK + threadIdx.x;
+    if (q >= total)
+        return;
+    const uint32_t k = (uint32_t)(q / L);
+    const uint32_t r = (uint32_t)(q - (size_t)k * L);
+    const int32_t b = cold_base[k];
+    if ((int32_t)r >= cold_base[k + 1] - b)
+        return;
+    const uint32_t src = src_sorted[q];
+    rank_of[src] = r;
+    cold_cols[(size_t)b + r] = (int32_t)slab_column(k, (uint32_t)(src - (size_t)k * L), shift, bits);
 }
 
 // ---- host side -----------------------------------------------------------------------------------------
@@ -1060,16 +1142,19 @@ hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacit
     return hipGetLastError();
 }
 
-// col_lo != nullptr: packed 3-byte codes into col_lo / col_hi (col2 is only read); else col2 is rewritten in place
-hipError_t slab_hot_encode(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
-                           const void *hotmap, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, hipStream_t s)
+// mode ENC_REWRITE: col2 is rewritten in place; ENC_COUNT: cnt2[slab][local id] += cold uses; ENC_PACK: 3-byte codes into
+// col_lo / col_hi, cold columns coded by rank_of (= cnt2 after slab_cold_order); col2 is only read by the last two
+static hipError_t hot_encode_pass(int mode, int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
+                                  const void *hotmap, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint32_t *cnt2,
+                                  hipStream_t s)
 {
     const size_t G = slab_hot_groups(n, shift, bits);
+    const size_t L = slab_local_count(n, shift, bits);
     const uint4 *hotbits = (const uint4 *)hotmap;
     const uint16_t *hotpre = (const uint16_t *)(hotbits + (size_t)S * G);
     const size_t lds = G * (sizeof(uint4) + sizeof(uint16_t));
     const dim3 grid(NUM_XCD * ENCODE_WGS_PER_XCD), block(ENCODE_BLOCK);
-    const bool in_lds = lds <= 150 * 1024, pack = col_lo != nullptr;
+    const bool in_lds = lds <= 150 * 1024;
     auto launch = [&](auto kern) -> hipError_t {
         if (in_lds) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1078,12 +1163,56 @@ hipError_t slab_hot_encode(int n, int nnz, int T, int p, int S, int bits, int sh
                 return e;
         }
         hipLaunchKernelGGL(kern, grid, block, in_lds ? lds : 0, s, nnz, T, p, S, bits, shift, slab_off, hotbits, hotpre, G, col2,
-                           col_lo, col_hi);
+                           col_lo, col_hi, cnt2, L);
         return hipGetLastError();
     };
-    if (in_lds)
-        return pack ? launch(k_hot_encode<true, true>) : launch(k_hot_encode<true, false>);
-    return pack ? launch(k_hot_encode<false, true>) : launch(k_hot_encode<false, false>);
+    switch (mode) {
+    case ENC_REWRITE: return in_lds ? launch(k_hot_encode<true, ENC_REWRITE>) : launch(k_hot_encode<false, ENC_REWRITE>);
+    case ENC_COUNT: return in_lds ? launch(k_hot_encode<true, ENC_COUNT>) : launch(k_hot_encode<false, ENC_COUNT>);
+    default: return in_lds ? launch(k_hot_encode<true, ENC_PACK>) : launch(k_hot_encode<false, ENC_PACK>);
+    }
+}
+
+hipError_t slab_hot_rewrite(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
+                            const void *hotmap, int32_t *col2, hipStream_t s)
+{
+    return hot_encode_pass(ENC_REWRITE, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, nullptr, nullptr, nullptr, s);
+}
+
+// scratch of slab_hot_pack: counts / ranks, sort keys in and out, sorted sources (S L words each) + the sort's own
+size_t slab_cold_words(int n, int S, int bits, int shift) { return (size_t)S * slab_local_count(n, shift, bits); }
+hipError_t slab_cold_sort_tmp_bytes(size_t total, int key_bits, size_t *bytes)
+{
+    uint32_t *nu = nullptr;
+    rocprim::counting_iterator<uint32_t> iota(0u);
+    return rocprim::radix_sort_pairs(nullptr, *bytes, nu, nu, iota, nu, total, 0, key_bits, nullptr);
+}
+
+// The packed column codes of a hot child: counts the cold uses of every column, ranks each slab's columns by them
+// (cold_base[S + 1] = start of every slab's cold region, cold_cols = the column behind every cold entry, in the order
+// of the permuted copy of x) and writes the 3-byte codes.  words = slab_cold_words(); cnt2 .. src_sorted: `words`
+// uint32 each, cnt2 zeroed by the caller.
+hipError_t slab_hot_pack(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off, const void *hotmap,
+                         int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint32_t *cnt2, uint32_t *keys, uint32_t *keys_sorted,
+                         uint32_t *src_sorted, void *sort_tmp, size_t sort_tmp_bytes, int32_t *cold_base, int32_t *cold_cols,
+                         hipStream_t s)
+{
+    const size_t L = slab_local_count(n, shift, bits), total = (size_t)S * L;
+    hipError_t e = hot_encode_pass(ENC_COUNT, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, nullptr, nullptr, cnt2, s);
+    if (e != hipSuccess)
+        return e;
+    const unsigned blocks = (unsigned)((total + SLAB_BLOCK - 1) / SLAB_BLOCK);
+    hipLaunchKernelGGL(k_cold_keys, dim3(blocks), dim3(SLAB_BLOCK), 0, s, total, L, cnt2, keys);
+    rocprim::counting_iterator<uint32_t> iota(0u);
+    e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys, keys_sorted, iota, src_sorted, total, 0, bits + 10, s);
+    if (e != hipSuccess)
+        return e;
+    hipLaunchKernelGGL(k_cold_layout, dim3(1), dim3(SLAB_MAX), 0, s, S, L, keys_sorted, cold_base);
+    hipLaunchKernelGGL(k_cold_rank, dim3(blocks), dim3(SLAB_BLOCK), 0, s, total, L, bits, shift, src_sorted, cold_base, cnt2, cold_cols);
+    e = hipGetLastError();
+    if (e != hipSuccess)
+        return e;
+    return hot_encode_pass(ENC_PACK, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, col_lo, col_hi, cnt2, s);
 }
 
 size_t slab_local_columns(int n, int bits, int shift) { return slab_local_count(n, shift, bits); }

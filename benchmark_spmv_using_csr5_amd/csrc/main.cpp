@@ -85,6 +85,9 @@ static int call_anonymouslib_multi(const std::vector<int> &devs, int m, int n, i
     A.setSigma(sig && strcmp(sig, "tuned") ? atoi(sig) : ANONYMOUSLIB_AUTO_TUNED_SIGMA);
     if (const char *mode = getenv("CSR5_MODE"))
         A.setOption(CSR5HIP_OPT_SPMV_MODE, atoi(mode));
+    // this program writes x once and never again: the library may keep its private copy of x between spmv() calls
+    // (CSR5_X_SNAPSHOT=0 restores the library default, a copy per spmv())
+    A.setOption(CSR5HIP_OPT_X_SNAPSHOT, getenv("CSR5_X_SNAPSHOT") ? atoi(getenv("CSR5_X_SNAPSHOT")) : 1);
     anonymouslib_timer asCSR5_timer;
     asCSR5_timer.start();
     err = A.asCSR5();
@@ -201,6 +204,9 @@ static int call_anonymouslib(int m, int n, int nnzA, int *csrRowPtrA, int *csrCo
     const char *mode = getenv("CSR5_MODE");
     if (mode)
         A.setOption(CSR5HIP_OPT_SPMV_MODE, atoi(mode));
+    // this program writes x once and never again ("you only need to do it once!", CSR5_cuda/main.cu:63): the library may
+    // keep its private copy of x between spmv() calls (CSR5_X_SNAPSHOT=0 restores the library default, a copy per spmv())
+    A.setOption(CSR5HIP_OPT_X_SNAPSHOT, getenv("CSR5_X_SNAPSHOT") ? atoi(getenv("CSR5_X_SNAPSHOT")) : 1);
 
     A.warmup();
     if (tune) { // measured sigma selection (not in the reference): try every candidate, keep the fastest

@@ -145,6 +145,12 @@ class anonymouslibHandle:
         is not built and spmv() runs the plain kernel (info().slab_fallback == 1)"""
         return self.setOption(_capi.OPT_SLAB_MEMORY_MIB, int(value))
 
+    def setXSnapshot(self, value: int) -> int:
+        """hot-table slab kernel: 0 (default) = its permuted copy of x is refreshed by every spmv() (x read live, as the
+        reference does); 1 = once per setX() -- the caller promises not to change x's contents in between (what the
+        reference CLI does: CSR5_cuda/main.cu:63); csr5hip.h CSR5HIP_OPT_X_SNAPSHOT"""
+        return self.setOption(_capi.OPT_X_SNAPSHOT, int(value))
+
     def setZeroEmptyRows(self, value: int) -> int:
         """1 = spmv() also stores 0 into rows without non-zeros (solver coupling); 0 = reference behaviour"""
         return self.setOption(_capi.OPT_ZERO_EMPTY_ROWS, int(value))

@@ -88,6 +88,18 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       that was REQUESTED (CSR5HIP_OPT_COLUMN_SLABS >= 2) makes asCSR5() fail, after the
                                       matrix has been put back into CSR. */
 
+#define CSR5HIP_OPT_X_SNAPSHOT 11 /* With an LDS hot table the slab kernel gathers from a private, PERMUTED copy of x (every
+                                      slab's table image, then its remaining columns in descending order of use: the part of
+                                      x a slab reads is dense and its popular prefix stays in one L2).
+                                      0 (default) = the copy is taken by every spmv(): x is read live, exactly like the
+                                          reference's texture / __ldg gathers (csr5_spmv_cuda.h:7-23) -- a caller may change
+                                          x's contents between spmv() calls without telling the handle;
+                                      1 = the copy is taken once per setX() (by the first spmv() after it): the caller
+                                          promises that x's CONTENTS do not change until the next setX() -- what the
+                                          reference CLI does (CSR5_cuda/main.cu:63 "you only need to do it once!", then
+                                          NUM_RUN spmv() calls on the same x).  Call setX() again, with the same pointer,
+                                          after writing to x.  Handles without a hot table ignore the option. */
+
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
 /* Host-visible snapshot of the handle's private state (anonymouslib_cuda.h:27-52). */
@@ -123,6 +135,9 @@ typedef struct csr5hip_info {
                                       plain kernel is in use                                                */
     long long device_bytes;        /* device memory held by the handle (CSR5 arrays, kernel tables, slab structure,
                                       build temporaries it keeps); the caller's CSR, x and y are not counted */
+    int slab_x_permuted;           /* 1 = the slab kernel gathers from the permuted copy of x (CSR5HIP_OPT_X_SNAPSHOT)   */
+    int slab_cold_entries;         /* entries of that copy behind the table images (columns gathered from memory)        */
+    int x_snapshot;                /* CSR5HIP_OPT_X_SNAPSHOT as set                                                      */
 } csr5hip_info;
 
 /* anonymouslibHandle(m, n) -- anonymouslib_cuda.h:15.  Uses the current HIP device. */
