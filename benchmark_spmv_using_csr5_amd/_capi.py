@@ -39,6 +39,7 @@ OPT_SLAB_HOT = 9
 OPT_SLAB_MEMORY_MIB = 10
 OPT_X_SNAPSHOT = 11
 MULTI_OPT_ROW_WEIGHT = 100  # csr5hip_multi_set_option only (before input_csr)
+MULTI_OPT_OWN_REPLICAS = 101  # csr5hip_multi_set_option only (before set_x): devices[0]'s shards read a broadcast replica too
 
 
 class Csr5Info(C.Structure):

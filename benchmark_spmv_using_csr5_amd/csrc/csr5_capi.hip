@@ -802,9 +802,9 @@ static int build_slabs_impl(csr5hip_handle h)
         bits_first++;
     if (hot) {
         cold_words = slab_cold_words(g.n, S, bits_first, h->slab_shift);
-        HIP_TRY(slab_cold_sort_tmp_bytes(cold_words, bits_first + 10, &cold_sort_bytes));
+        HIP_TRY(slab_cold_sort_tmp_bytes(cold_words, bits_first, &cold_sort_bytes));
     }
-    const size_t o_cnt2 = take(cold_words * 4), o_keys = take(cold_words * 4), o_keys2 = take(cold_words * 4),
+    const size_t o_ref = take(cold_words), o_rank = take(cold_words * 4), o_keys = take(cold_words * 4), o_keys2 = take(cold_words * 4),
                  o_src = take(cold_words * 4), o_sort = take(cold_sort_bytes);
     if (h->slab_mem_mib > 0) {
         // second copy of column_index / value (+ 3-byte column codes with a hot table) + build temporaries + (upper bound)
@@ -929,10 +929,11 @@ static int build_slabs_impl(csr5hip_handle h)
             HIP_TRY(h->b_cold_base.reserve(((size_t)S + 1) * 4));
             HIP_TRY(h->b_cold_cols.reserve((cold_cap + 1) * 4));
             HIP_TRY(h->b_xperm.reserve(((size_t)S * hot_capacity + cold_cap + 1) * h->vsize()));
-            HIP_TRY(hipMemsetAsync(tb + o_cnt2, 0, cold_words * 4, s));
+            HIP_TRY(hipMemsetAsync(tb + o_ref, 0, cold_words, s));
             HIP_TRY(slab_hot_pack(g.n, g.nnz, hot_T, hot_p, S, bits, h->slab_shift, (const int32_t *)h->b_slab_off.ptr, ht.hotmap,
-                                  (int32_t *)h->b_col2.ptr, (uint16_t *)h->b_col_lo.ptr, (uint8_t *)h->b_col_hi.ptr,
-                                  (uint32_t *)(tb + o_cnt2), (uint32_t *)(tb + o_keys), (uint32_t *)(tb + o_keys2),
+                                  (const uint32_t *)ht.cnt, (int32_t *)h->b_col2.ptr, (uint16_t *)h->b_col_lo.ptr,
+                                  (uint8_t *)h->b_col_hi.ptr, (uint8_t *)(tb + o_ref), (uint32_t *)(tb + o_rank),
+                                  (uint32_t *)(tb + o_keys), (uint32_t *)(tb + o_keys2),
                                   (uint32_t *)(tb + o_src), tb + o_sort, cold_sort_bytes, (int32_t *)h->b_cold_base.ptr,
                                   (int32_t *)h->b_cold_cols.ptr, s));
             HIP_TRY(hipMemcpyAsync(&cold_total, (int32_t *)h->b_cold_base.ptr + S, 4, hipMemcpyDeviceToHost, s));

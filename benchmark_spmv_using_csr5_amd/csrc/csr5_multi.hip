@@ -142,6 +142,7 @@ struct csr5hip_multi_s {
     std::vector<void *> comm; // ncclComm_t per UNIQUE device, or empty
     bool distinct = true;     // no device id listed twice
     int broadcast_kind = 0;   // what the last set_x used: 1 = RCCL broadcast, 2 = device-to-device copies
+    bool own_replicas = false; // CSR5HIP_MULTI_OPT_OWN_REPLICAS: shards on devices[0] get a replica of x too
     size_t vsize() const { return value_type == CSR5HIP_F64 ? 8 : 4; }
 };
 
@@ -295,6 +296,10 @@ int csr5hip_multi_set_option(csr5hip_multi mh, int option, int value)
     DeviceGuard restore_device;
     if (!mh)
         return CSR5HIP_INVALID_ARGUMENT;
+    if (option == CSR5HIP_MULTI_OPT_OWN_REPLICAS) { // takes effect at the next set_x
+        mh->own_replicas = value != 0;
+        return CSR5HIP_SUCCESS;
+    }
     if (option == CSR5HIP_MULTI_OPT_ROW_WEIGHT) { // takes effect at the next input_csr
         if (value < 0 || value > 64)
             return CSR5HIP_INVALID_ARGUMENT;
@@ -348,7 +353,11 @@ int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x)
     const int G = mh->G;
     for (int g = 0; g < G; g++) {
         MHIP(hipSetDevice(mh->dev[g]));
-        if (mh->dev[g] == mh->dev[0]) {
+        if (mh->dev[g] == mh->dev[0] && !mh->own_replicas) {
+            if (mh->x[g] && mh->x_owned[g]) { // (a replica from an earlier set_x with own replicas)
+                MHIP(hipFree(mh->x[g]));
+                mh->x_owned[g] = 0;
+            }
             mh->x[g] = const_cast<void *>(d_x); // borrowed, as setX borrows (anonymouslib_cuda.h:222-260)
         } else {
             int first = g; // one replica per device, shared by the shards that live there
@@ -359,7 +368,7 @@ int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x)
                 }
             if (first != g) {
                 mh->x[g] = mh->x[first];
-            } else if (!mh->x[g]) {
+            } else if (!mh->x[g] || !mh->x_owned[g]) {
                 MHIP(hipMalloc(&mh->x[g], bytes ? bytes : 4));
                 mh->x_owned[g] = 1;
             }
@@ -367,7 +376,7 @@ int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x)
     }
     bool any_remote = false;
     for (int g = 0; g < G; g++)
-        any_remote = any_remote || mh->dev[g] != mh->dev[0];
+        any_remote = any_remote || mh->dev[g] != mh->dev[0] || mh->own_replicas;
     mh->broadcast_kind = 0;
     if (any_remote && mh->distinct && rccl().ok()) {
         if (mh->comm.empty()) {
@@ -397,7 +406,7 @@ int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x)
     }
     if (any_remote && mh->broadcast_kind == 0) {
         for (int g = 0; g < G; g++) {
-            if (mh->dev[g] == mh->dev[0])
+            if (mh->dev[g] == mh->dev[0] && !mh->own_replicas)
                 continue;
             bool first = true;
             for (int q = 0; q < g; q++)

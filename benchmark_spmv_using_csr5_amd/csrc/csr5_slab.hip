@@ -812,8 +812,11 @@ k_hot_rank(int bits, int shift, int capacity, size_t G, const uint4 *__restrict_
 // of the slab's column words, four per lane and load.  What it does with an element depends on MODE:
 //   ENC_REWRITE  a column with a slot in its slab's table becomes 0x80000000 | slot in col2 itself (child sigmas that are
 //                not multiples of four: the SpMV kernel reads 4-byte words and gathers cold columns from x directly)
-//   ENC_COUNT    counts how often every column is gathered COLD (not through the table) -- cnt2[slab][local id]; the
-//                ranking below turns the counts into the slab's frequency order
+//   ENC_MARK     marks every column that is gathered COLD (not through the table) somewhere -- one byte per column,
+//                ref[slab][local id], plain stores (all writers store 1).  Counting the cold uses exactly would take one
+//                global atomic per cold element: 91 M on R-MAT 24, 4.2 ms at the chip's 26.7 atomics per ns
+//                (profiles/r03_probes.txt) -- the ranking below takes the popularity from the sampled counts of the table
+//                selection instead and only needs to know WHICH columns to rank
 //   ENC_PACK     every column word of the tiles 0 .. p-2 is written as a 24-bit code -- low 16 bits to col_lo, high 8 bits
 //                to col_hi, both in the child's CSR order, which is already the order lane l of k_spmv_range wants (its
 //                sigma elements are consecutive there): bit 23 = table slot in bits 0..13, else the RANK of the column in
@@ -824,12 +827,13 @@ k_hot_rank(int bits, int shift, int capacity, size_t G, const uint4 *__restrict_
 // following slab(s): they are cold there (that tile runs with THIS slab's table) and are counted / coded with the
 // numbering of THEIR slab.
 constexpr int ENCODE_BLOCK = 1024, ENCODE_WGS_PER_XCD = 32, ENCODE_UNROLL = 4;
-constexpr int ENC_REWRITE = 0, ENC_COUNT = 1, ENC_PACK = 2;
+constexpr int ENC_REWRITE = 0, ENC_MARK = 1, ENC_PACK = 2;
 template <bool IN_LDS, int MODE>
 __global__ void __launch_bounds__(ENCODE_BLOCK)
 k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *__restrict__ slab_off,
              const uint4 *__restrict__ hotbits, const uint16_t *__restrict__ hotpre, size_t G, int32_t *__restrict__ col2,
-             uint16_t *__restrict__ col_lo, uint8_t *__restrict__ col_hi, uint32_t *__restrict__ cnt2, size_t L)
+             uint16_t *__restrict__ col_lo, uint8_t *__restrict__ col_hi, uint8_t *__restrict__ ref,
+             const uint32_t *__restrict__ rank_of, size_t L)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *lbits = reinterpret_cast<uint4 *>(smem);
@@ -847,7 +851,7 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
             __syncthreads(); // (the previous slab's look-ups are done)
             for (size_t g = threadIdx.x; g < G; g += ENCODE_BLOCK) {
                 lbits[g] = gb[g];
-                if (MODE != ENC_COUNT)
+                if (MODE != ENC_MARK)
                     lpre[g] = gp[g];
             }
             __syncthreads();
@@ -858,7 +862,7 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
             const uint32_t g = local >> 7;
             uint32_t below;
             const bool hot = hot_lookup(IN_LDS ? lbits[g] : gb[g], local & 127u, below);
-            if (MODE == ENC_COUNT)
+            if (MODE == ENC_MARK)
                 return hot ? 0 : -1;
             return hot ? (int)((uint32_t)(IN_LDS ? lpre[g] : gp[g]) + below) : -1;
         };
@@ -872,11 +876,11 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
             if (slot >= 0)
                 return (int32_t)(0x800000u | (uint32_t)slot);
             const size_t at = (size_t)(pos < own_end ? (uint32_t)mine : slab_of((uint32_t)c, shift, bits)) * L + local;
-            if (MODE == ENC_COUNT) {
-                atomicAdd(&cnt2[at], 1u);
+            if (MODE == ENC_MARK) {
+                ref[at] = 1;
                 return 0;
             }
-            return (int32_t)cnt2[at]; // ENC_PACK: cnt2 holds rank_of by now
+            return (int32_t)rank_of[at];
         };
         // An element inside a tile owned by the PREVIOUS slab is gathered with that slab's table in LDS: it is that
         // slab's business (REWRITE: it keeps its plain word).  So the slab's share starts at its first own tile.
@@ -917,7 +921,7 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
                 }
             }
         }
-        // (COUNT / PACK: begin and end are multiples of the tile size, nothing is left over)
+        // (MARK / PACK: begin and end are multiples of the tile size, nothing is left over)
         if (MODE == ENC_REWRITE && j == 0 && (long long)threadIdx.x < end - begin - quads * 4) {
             const long long pos = begin + quads * 4 + threadIdx.x;
             col2[pos] = encode(col2[pos], pos);
@@ -926,21 +930,29 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
 }
 
 // ---- frequency order of the cold columns of every slab (the layout of the permuted copy of x, csr5_hot.hip) ----------
-// cnt2[slab][local id] = cold uses of the column (ENC_COUNT).  A stable radix sort on (slab, 1023 - min(count, 1023))
-// with the index as payload puts every slab's columns in descending order of use, ties in column order; the first
-// ncold[k] positions of slab k (count > 0) are the slab's cold region.  Hot columns (gathered from the LDS table) and
-// columns nobody references have count 0 and fall behind it.
-constexpr uint32_t COLD_COUNT_CAP = 1023;
+// ref[slab][local id] = the column is gathered cold somewhere (ENC_MARK); cnt[column] = its sampled use count from the table
+// selection (k_col_count: one 64-element chunk in `stride`).  A stable radix sort on (slab, 1023 - min(count, 1023)) with
+// the index as payload puts every slab's marked columns in descending order of (sampled) use, ties -- among them all the
+// columns the sample missed -- in column order; unmarked columns (only ever read through the LDS table, or by nobody) get
+// the key 1024 and fall behind: the first ncold[k] positions of slab k are the slab's cold region.
+constexpr uint32_t COLD_COUNT_CAP = 1023, COLD_KEY_BITS = 11;
 __global__ void __launch_bounds__(SLAB_BLOCK)
-k_cold_keys(size_t total, size_t L, const uint32_t *__restrict__ cnt2, uint32_t *__restrict__ keys)
+k_cold_keys(size_t total, size_t L, int n, int bits, int shift, const uint8_t *__restrict__ ref, const uint32_t *__restrict__ cnt,
+            uint32_t *__restrict__ keys)
 {
     const size_t i = (size_t)blockIdx.x * SLAB_BLOCK + threadIdx.x;
     if (i >= total)
         return;
-    const uint32_t c = cnt2[i];
-    keys[i] = ((uint32_t)(i / L) << 10) | (COLD_COUNT_CAP - (c < COLD_COUNT_CAP ? c : COLD_COUNT_CAP));
+    const uint32_t k = (uint32_t)(i / L);
+    uint32_t low = COLD_COUNT_CAP + 1;
+    if (ref[i]) {
+        const uint32_t col = slab_column(k, (uint32_t)(i - (size_t)k * L), shift, bits);
+        const uint32_t c = col < (uint32_t)n ? cnt[col] : 0u;
+        low = COLD_COUNT_CAP - (c < COLD_COUNT_CAP ? c : COLD_COUNT_CAP);
+    }
+    keys[i] = (k << COLD_KEY_BITS) | low;
 }
-// one thread per slab: ncold[k] = columns of slab k with a cold use (their keys sort in front of (k << 10) | 1023), then
+// one thread per slab: ncold[k] = marked columns of slab k (their keys sort in front of (k << 11) | 1024), then
 // cold_base[k] = start of the slab's cold region (exclusive prefix; cold_base[S] = all cold entries)
 __global__ void __launch_bounds__(SLAB_MAX)
 k_cold_layout(int S, size_t L, const uint32_t *__restrict__ keys_sorted, int32_t *__restrict__ cold_base)
@@ -948,7 +960,7 @@ k_cold_layout(int S, size_t L, const uint32_t *__restrict__ keys_sorted, int32_t
     __shared__ int32_t n[SLAB_MAX];
     const int k = threadIdx.x;
     if (k < S) {
-        const uint32_t none = ((uint32_t)k << 10) | COLD_COUNT_CAP;
+        const uint32_t none = ((uint32_t)k << COLD_KEY_BITS) | (COLD_COUNT_CAP + 1);
         size_t lo = (size_t)k * L, hi = lo + L;
         while (lo < hi) {
             const size_t mid = (lo + hi) >> 1;
@@ -969,8 +981,7 @@ k_cold_layout(int S, size_t L, const uint32_t *__restrict__ keys_sorted, int32_t
         cold_base[S] = run;
     }
 }
-// sorted position q of slab k -> rank r = q - k L: rank_of[source index] = r (overwrites the counts), and the column of
-// the slab's r-th cold entry
+// sorted position q of slab k -> rank r = q - k L: rank_of[source index] = r, and the column of the slab's r-th cold entry
 __global__ void __launch_bounds__(SLAB_BLOCK)
 k_cold_rank(size_t total, size_t L, int bits, int shift, const uint32_t *__restrict__ src_sorted,
             const int32_t *__restrict__ cold_base, uint32_t *__restrict__ rank_of, int32_t *__restrict__ cold_cols)
@@ -1142,11 +1153,11 @@ hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacit
     return hipGetLastError();
 }
 
-// mode ENC_REWRITE: col2 is rewritten in place; ENC_COUNT: cnt2[slab][local id] += cold uses; ENC_PACK: 3-byte codes into
-// col_lo / col_hi, cold columns coded by rank_of (= cnt2 after slab_cold_order); col2 is only read by the last two
+// mode ENC_REWRITE: col2 is rewritten in place; ENC_MARK: ref[slab][local id] = 1 for cold uses; ENC_PACK: 3-byte codes into
+// col_lo / col_hi, cold columns coded by rank_of; col2 is only read by the last two
 static hipError_t hot_encode_pass(int mode, int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
-                                  const void *hotmap, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint32_t *cnt2,
-                                  hipStream_t s)
+                                  const void *hotmap, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint8_t *ref,
+                                  const uint32_t *rank_of, hipStream_t s)
 {
     const size_t G = slab_hot_groups(n, shift, bits);
     const size_t L = slab_local_count(n, shift, bits);
@@ -1163,12 +1174,12 @@ static hipError_t hot_encode_pass(int mode, int n, int nnz, int T, int p, int S,
                 return e;
         }
         hipLaunchKernelGGL(kern, grid, block, in_lds ? lds : 0, s, nnz, T, p, S, bits, shift, slab_off, hotbits, hotpre, G, col2,
-                           col_lo, col_hi, cnt2, L);
+                           col_lo, col_hi, ref, rank_of, L);
         return hipGetLastError();
     };
     switch (mode) {
     case ENC_REWRITE: return in_lds ? launch(k_hot_encode<true, ENC_REWRITE>) : launch(k_hot_encode<false, ENC_REWRITE>);
-    case ENC_COUNT: return in_lds ? launch(k_hot_encode<true, ENC_COUNT>) : launch(k_hot_encode<false, ENC_COUNT>);
+    case ENC_MARK: return in_lds ? launch(k_hot_encode<true, ENC_MARK>) : launch(k_hot_encode<false, ENC_MARK>);
     default: return in_lds ? launch(k_hot_encode<true, ENC_PACK>) : launch(k_hot_encode<false, ENC_PACK>);
     }
 }
@@ -1176,43 +1187,43 @@ static hipError_t hot_encode_pass(int mode, int n, int nnz, int T, int p, int S,
 hipError_t slab_hot_rewrite(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
                             const void *hotmap, int32_t *col2, hipStream_t s)
 {
-    return hot_encode_pass(ENC_REWRITE, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, nullptr, nullptr, nullptr, s);
+    return hot_encode_pass(ENC_REWRITE, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, nullptr, nullptr, nullptr, nullptr, s);
 }
 
-// scratch of slab_hot_pack: counts / ranks, sort keys in and out, sorted sources (S L words each) + the sort's own
+// scratch of slab_hot_pack: marks (1 byte), ranks, sort keys in and out, sorted sources (S L entries each) + the sort's own
 size_t slab_cold_words(int n, int S, int bits, int shift) { return (size_t)S * slab_local_count(n, shift, bits); }
-hipError_t slab_cold_sort_tmp_bytes(size_t total, int key_bits, size_t *bytes)
+hipError_t slab_cold_sort_tmp_bytes(size_t total, int slab_bits, size_t *bytes)
 {
     uint32_t *nu = nullptr;
     rocprim::counting_iterator<uint32_t> iota(0u);
-    return rocprim::radix_sort_pairs(nullptr, *bytes, nu, nu, iota, nu, total, 0, key_bits, nullptr);
+    return rocprim::radix_sort_pairs(nullptr, *bytes, nu, nu, iota, nu, total, 0, slab_bits + (int)COLD_KEY_BITS, nullptr);
 }
 
-// The packed column codes of a hot child: counts the cold uses of every column, ranks each slab's columns by them
-// (cold_base[S + 1] = start of every slab's cold region, cold_cols = the column behind every cold entry, in the order
-// of the permuted copy of x) and writes the 3-byte codes.  words = slab_cold_words(); cnt2 .. src_sorted: `words`
-// uint32 each, cnt2 zeroed by the caller.
+// The packed column codes of a hot child: marks the columns that are gathered cold, ranks each slab's marked columns by
+// their sampled use counts `cnt` (cold_base[S + 1] = start of every slab's cold region, cold_cols = the column behind
+// every cold entry, in the order of the permuted copy of x) and writes the 3-byte codes.  words = slab_cold_words();
+// ref: `words` bytes, zeroed by the caller; rank_of .. src_sorted: `words` uint32 each.
 hipError_t slab_hot_pack(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off, const void *hotmap,
-                         int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint32_t *cnt2, uint32_t *keys, uint32_t *keys_sorted,
-                         uint32_t *src_sorted, void *sort_tmp, size_t sort_tmp_bytes, int32_t *cold_base, int32_t *cold_cols,
-                         hipStream_t s)
+                         const uint32_t *cnt, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint8_t *ref, uint32_t *rank_of,
+                         uint32_t *keys, uint32_t *keys_sorted, uint32_t *src_sorted, void *sort_tmp, size_t sort_tmp_bytes,
+                         int32_t *cold_base, int32_t *cold_cols, hipStream_t s)
 {
     const size_t L = slab_local_count(n, shift, bits), total = (size_t)S * L;
-    hipError_t e = hot_encode_pass(ENC_COUNT, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, nullptr, nullptr, cnt2, s);
+    hipError_t e = hot_encode_pass(ENC_MARK, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, nullptr, nullptr, ref, nullptr, s);
     if (e != hipSuccess)
         return e;
     const unsigned blocks = (unsigned)((total + SLAB_BLOCK - 1) / SLAB_BLOCK);
-    hipLaunchKernelGGL(k_cold_keys, dim3(blocks), dim3(SLAB_BLOCK), 0, s, total, L, cnt2, keys);
+    hipLaunchKernelGGL(k_cold_keys, dim3(blocks), dim3(SLAB_BLOCK), 0, s, total, L, n, bits, shift, ref, cnt, keys);
     rocprim::counting_iterator<uint32_t> iota(0u);
-    e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys, keys_sorted, iota, src_sorted, total, 0, bits + 10, s);
+    e = rocprim::radix_sort_pairs(sort_tmp, sort_tmp_bytes, keys, keys_sorted, iota, src_sorted, total, 0, bits + (int)COLD_KEY_BITS, s);
     if (e != hipSuccess)
         return e;
     hipLaunchKernelGGL(k_cold_layout, dim3(1), dim3(SLAB_MAX), 0, s, S, L, keys_sorted, cold_base);
-    hipLaunchKernelGGL(k_cold_rank, dim3(blocks), dim3(SLAB_BLOCK), 0, s, total, L, bits, shift, src_sorted, cold_base, cnt2, cold_cols);
+    hipLaunchKernelGGL(k_cold_rank, dim3(blocks), dim3(SLAB_BLOCK), 0, s, total, L, bits, shift, src_sorted, cold_base, rank_of, cold_cols);
     e = hipGetLastError();
     if (e != hipSuccess)
         return e;
-    return hot_encode_pass(ENC_PACK, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, col_lo, col_hi, cnt2, s);
+    return hot_encode_pass(ENC_PACK, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, col_lo, col_hi, nullptr, rank_of, s);
 }
 
 size_t slab_local_columns(int n, int bits, int shift) { return slab_local_count(n, shift, bits); }

@@ -303,6 +303,11 @@ int csr5hip_multi_set_sigma(csr5hip_multi mh, int sigma);
 /* csr5hip_set_option on every shard; CSR5HIP_MULTI_OPT_ROW_WEIGHT (0..64, before input_csr) is the handle's own key */
 #define CSR5HIP_MULTI_OPT_ROW_WEIGHT 100
 #define CSR5HIP_MULTI_DEFAULT_ROW_WEIGHT 2
+/* 1 = the shards on devices[0] also read a REPLICA of x that the broadcast fills (root = devices[0] itself) instead of
+ * borrowing the caller's vector: with G = 1 the one RCCL collective of this path -- communicator over the device list,
+ * grouped ncclBroadcast -- then runs on a single GPU exactly as it does on eight (how the 1-GPU test box proves the
+ * RCCL bindings).  Default 0.  Takes effect at the next set_x. */
+#define CSR5HIP_MULTI_OPT_OWN_REPLICAS 101
 int csr5hip_multi_set_option(csr5hip_multi mh, int option, int value);
 int csr5hip_multi_as_csr5(csr5hip_multi mh);
 /* setX: d_x on devices[0], n values, borrowed by the shards that live there; ONE broadcast to the other devices */

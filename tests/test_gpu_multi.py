@@ -1,7 +1,8 @@
 """Multi-GPU path behind the C ABI (csr5hip_multi_*): cost-balanced (nnz + 2 per row) row blocks, one handle per shard, x replicated
 once, y sharded.  On a 1-GPU box every shard lives on device 0 (the device list repeats it), so the whole control
 flow -- device-side row cuts, shard copies + rebase, per-shard conversion, set_x, per-stream SpMV, gather -- runs;
-the RCCL broadcast itself needs >= 2 distinct devices and is exercised where they exist."""
+the RCCL broadcast between devices needs >= 2 distinct devices; its bindings and call sequence run here through a one-device
+communicator (test_rccl_broadcast_runs_on_one_device)."""
 import numpy as np
 import pytest
 
@@ -9,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
+from benchmark_spmv_using_csr5_amd import _capi  # noqa: E402
 from benchmark_spmv_using_csr5_amd import handle as H  # noqa: E402
 from benchmark_spmv_using_csr5_amd import matrices as M  # noqa: E402
 from benchmark_spmv_using_csr5_amd import sharding as S  # noqa: E402
@@ -22,7 +24,7 @@ def _devices(G):
     return [g % n for g in range(G)] if n >= 2 else [0] * G
 
 
-def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None, row_weight=None):
+def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None, row_weight=None, own_replicas=False):
     rp = torch.from_numpy(mat.row_ptr.astype(np.int32)).to(DEV)
     ci = torch.from_numpy(mat.col.astype(np.int32)).to(DEV)
     va = torch.from_numpy(val.astype(dtype)).to(DEV)
@@ -35,7 +37,13 @@ def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None, row_weigh
     if slabs is not None:
         assert A.setOption(6, slabs) == 0
     assert A.asCSR5() == 0
+    if own_replicas:
+        assert A.setOption(_capi.MULTI_OPT_OWN_REPLICAS, 1) == 0
     assert A.setX(xd) == 0
+    if own_replicas:
+        torch.cuda.synchronize()
+        xd.fill_(float("nan"))  # the shards must read the replica the broadcast filled, not the caller's vector
+        torch.cuda.synchronize()
     assert A.fill_y(0x7F) == 0  # a recognisable pattern in the rows SpMV must leave untouched
     assert A.spmv(1.0) == 0 and A.synchronize() == 0
     y = A.gather_y()
@@ -48,6 +56,29 @@ def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None, row_weigh
     assert A.destroy() == 0
     A.close()
     return y, cuts, nnzs, bkind, tails
+
+
+def test_rccl_broadcast_runs_on_one_device(oracle):
+    """The RCCL branch of csr5hip_multi_set_x (dlopen of librccl, the hand-declared prototypes of ncclCommInitAll /
+    ncclGroupStart / ncclBroadcast / ncclGroupEnd, the ncclUint8 constant) executed on the 1-GPU box: a one-device
+    communicator and a grouped broadcast from devices[0] into the shard's own replica of x.  What an 8-GPU node runs per
+    device, proven against the installed librccl before the first multi-GPU lease (nothing to match in the reference:
+    CSR5_cuda/main.cu:25-26 is cudaSetDevice(0))."""
+    for mat in zoo.small_zoo()[:6]:
+        val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=9, mode="int")
+        ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+        y, cuts, nnzs, bkind, tails = _run_multi(mat, val, x, 1, own_replicas=True)
+        assert bkind == 1, f"x was not replicated by the RCCL broadcast (kind {bkind}): {_capi.last_error()}"
+        has = np.diff(mat.row_ptr) > 0
+        assert np.array_equal(y[has], ref[has]), mat.name
+    # fp32, a matrix large enough for slabs: the replica feeds the slab child's permuted copy
+    mat = M.rmat(16, 8, seed=3)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float32, seed=4, mode="int")
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val.astype(np.float64), x.astype(np.float64))
+    y, cuts, nnzs, bkind, tails = _run_multi(mat, val, x, 1, dtype=np.float32, own_replicas=True)
+    assert bkind == 1
+    has = np.diff(mat.row_ptr) > 0
+    assert np.array_equal(y[has].astype(np.float64), ref[has])
 
 
 @pytest.mark.parametrize("G", [1, 2, 3, 8])
