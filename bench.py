@@ -333,8 +333,8 @@ def roofline_dict(prob, ev_ms_per_step, wall_ms_per_step, extra=None):
         "clock": "HIP events on the launch stream around the K timed steps (frac_wall: the same from the wall clock)",
         "frac_wall": round(prob.b_alg / (wall_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "traffic": None,
-        "kernel": ("csr5::k_spmv_range" if info.slab_hot else "csr5::k_spmv") +
-                  (" + csr5::k_slab_combine (both inside the step time)" if info.column_slabs else ""),
+        "kernel": ("csr5::k_spmv_range + csr5::k_range_finish" if info.slab_hot else "csr5::k_spmv") +
+                  (" + csr5::k_slab_combine (all inside the step time)" if info.column_slabs else ""),
         "algorithmic_bytes_per_launch": prob.b_alg,
         # diagnostic: bytes the CSR5 kernel actually streams = B_alg with row_ptr replaced by
         # tile_ptr + tile_desc (x and y still counted once)
@@ -580,6 +580,18 @@ def main():
                 roof = cold_is_the_number(prob, roof, ev_per_step, ms_per_step, cold_ms, k, cs)
             else:
                 roof["cold"] = cold_dict(prob, cold_ms, k, cs)
+        if world == 1 and info.slab_x_permuted and info.x_snapshot:
+            # the same workload with the library default: the permuted copy of x is re-taken by every spmv() (x read live)
+            _ck(prob.A.setXSnapshot(0), "setXSnapshot")
+            lsteps = max(5, steps // 4)
+            lwall, lev = timed(prob, lsteps, 2, args.launch, None)
+            _ck(prob.A.setXSnapshot(1), "setXSnapshot")
+            roof["x_live"] = {"launch_us": round(lev / lsteps * 1e3, 3),
+                              "frac": round(prob.b_alg / (lev / lsteps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": lsteps,
+                              "note": "library default CSR5HIP_OPT_X_SNAPSHOT = 0: csr5::k_x_permute runs inside every step "
+                                      "(a caller may overwrite x between spmv() calls without calling setX again); the "
+                                      "headline uses the reference CLI's protocol -- setX once, then the timed loop -- with "
+                                      "the copy taken once per setX"}
         part = ("whole matrix on one GPU" if world == 1 else
                 f"{scaling} scaling, {'row blocks of ONE matrix balanced by nnz + 2 * rows' if scaling == 'strong' else 'one fixed-size row block per GPU'}, "
                 "x replicated by one RCCL broadcast, no per-step collective")

@@ -138,7 +138,7 @@ struct csr5hip_handle_s {
     bool hot_enabled = false; // (child) column words are hot-encoded: spmv must use the persistent hot kernel
     bool hot_packed = false;  // (child) ... as packed codes next to the plain column words: only the values are transposed
     int hot_cover_pct = 0;    // (parent) share of the non-zeros whose column got a table slot
-    Buffer b_hot_cols, b_hot_count, b_hot_tile0, b_slab_off, b_lead;
+    Buffer b_hot_cols, b_hot_count, b_hot_tile0, b_slab_off, b_lead, b_range_head;
     Buffer b_col_lo, b_col_hi; // packed column codes of a hot child (3 bytes per non-zero)
     // permuted copy of x behind the packed codes (csr5_hot.hip k_x_permute): table images + frequency-ordered cold regions
     Buffer b_cold_base, b_cold_cols, b_xperm;
@@ -292,17 +292,19 @@ int csr5hip_set_x(csr5hip_handle h, const void *d_x)
     return CSR5HIP_SUCCESS;
 }
 
-// gfx950 table in the shape of the reference's (r, s, t, u) rule (anonymouslib_cuda.h:297-313):
-// k = nnz/m; sigma = r if k <= r; k if k <= s; s if k <= t; else u.
-// (r, s, t, u) = (6, 16, 256, 16), from a sweep of all sigma over mean row lengths 2..512, random and near-diagonal
-// columns, fp64 and fp32 (scripts/experiments/sigma_table.py, profiles/r01_sigma_table.txt): the sigma surface is
-// flat on gfx950 and the rule stays within 0-7 % of the measured best everywhere; r = 6 instead of the reference's 4
-// costs random-column matrices < 1 % and gains 4-8 % where the columns are local.  Beyond 256 non-zeros per row
-// sigma = 32 would gain 3-7 % on random columns but loses 10 % on the nd24k-like stand-in (x-window + jitter): u = 16.
+// gfx950 tables in the shape of the reference's (r, s, t, u) rule (anonymouslib_cuda.h:297-313, one table per
+// architecture and precision there too): k = nnz/m; sigma = r if k <= r; k if k <= s; s if k <= t; else u.
+// fp64: (6, 16, 256, 16); fp32: (8, 16, 256, 16) -- from sweeps of all sigma over mean row lengths 2..512, random and
+// near-diagonal columns (scripts/experiments/sigma_table.py; profiles/r01_sigma_table.txt, re-run on the round-4 kernels in
+// profiles/r04_sigma_table.txt): the sigma surface is flat on gfx950 and the rules stay within a few per cent of the measured
+// best everywhere.  r = 6 instead of the reference's 4 costs random-column fp64 matrices < 1 % and gains 4-8 % where the
+// columns are local; fp32 rows are half as wide, so a tile of the same byte size holds twice the elements: short rows
+// (k <= 8) with local columns ran 5-8 % faster at sigma = 8 than at 6, at no cost with random columns.  Beyond 256
+// non-zeros per row sigma = 32 would gain 3-7 % on random columns but loses 10 % on the nd24k-like stand-in (x-window +
+// jitter): u = 16.
 int csr5hip_auto_sigma(int m, int nnz, int value_type)
 {
-    (void)value_type;
-    const int r = 6, s = 16, t = 256, u = 16;
+    const int r = value_type == CSR5HIP_F32 ? 8 : 6, s = 16, t = 256, u = 16;
     const int k = m > 0 ? nnz / m : 0;
     if (k <= r) return r;
     if (k <= s) return k;
@@ -612,8 +614,11 @@ int csr5hip_as_csr5(csr5hip_handle h)
         rc = finish();
         if (rc != CSR5HIP_SUCCESS) {
             const std::string why = g_last_error;
-            if (launch_transpose(g, h->d, h->value_type, false, s) != hipSuccess ||
-                hipStreamSynchronize(s) != hipSuccess)
+            if (h->is_child && h->hot_packed)
+                h->format = -1; // only the VALUES of every tile were transposed (private arrays of a slab structure, which the
+                                // parent releases on failure): nothing to restore, the handle is unusable until inputCSR
+            else if (launch_transpose(g, h->d, h->value_type, false, s) != hipSuccess ||
+                     hipStreamSynchronize(s) != hipSuccess)
                 h->format = -1; // the arrays could not be restored: the handle is unusable until inputCSR
             g_last_error = why;
             return rc;
@@ -643,7 +648,7 @@ static void release_slabs(csr5hip_handle h)
         h->slab_child = nullptr;
     }
     for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty, &h->b_col_lo, &h->b_col_hi, &h->b_hot_cols,
-                      &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_slab_tmp, &h->b_cold_base, &h->b_cold_cols,
+                      &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_range_head, &h->b_slab_tmp, &h->b_cold_base, &h->b_cold_cols,
                       &h->b_xperm})
         b->release();
     h->slab_S = 0;
@@ -807,10 +812,18 @@ static int build_slabs_impl(csr5hip_handle h)
     const size_t o_ref = take(cold_words), o_rank = take(cold_words * 4), o_keys = take(cold_words * 4), o_keys2 = take(cold_words * 4),
                  o_src = take(cold_words * 4), o_sort = take(cold_sort_bytes);
     if (h->slab_mem_mib > 0) {
-        // second copy of column_index / value (+ 3-byte column codes with a hot table) + build temporaries + (upper bound)
-        // one partial sum per non-zero row piece
-        const unsigned long long need = (unsigned long long)g.nnz * (4 + h->vsize() + (hot ? 3 : 0)) + off +
-                                        (unsigned long long)g.m * (h->vsize() + 5);
+        // Upper bound of what the structure holds: the second copy of column_index / value (+ 3-byte column codes with a
+        // hot table), the build temporaries, one partial sum / row byte / child row pointer per (row, slab) segment --
+        // at most min(nnz, m * S) of them --, the combine's tables, the child's own conversion arena (descriptor word per
+        // 64 sigma elements, tile_ptr, carry state: ~300 B per child tile) and, with a hot table, the table columns, the
+        // wavefront-range words and the permuted copy of x with its column lists.
+        const unsigned long long seg_max = std::min<unsigned long long>((unsigned long long)g.nnz, (unsigned long long)g.m * S_alloc);
+        const unsigned long long child_tiles = (unsigned long long)g.nnz / ((unsigned long long)OMEGA * (hot ? hot_sigma : g.sigma)) + 2;
+        unsigned long long need = (unsigned long long)g.nnz * (4 + h->vsize() + (hot ? 3 : 0)) + off + seg_max * (h->vsize() + 5) +
+                                  slab_base_words(g.m, S_alloc) * 4ull + (unsigned long long)g.m / 8 + child_tiles * 300ull;
+        if (hot)
+            need += (unsigned long long)S * hot_capacity * (4 + h->vsize()) + (unsigned long long)S * HOT_RANGES_PER_SLAB * (h->vsize() + 4) +
+                    std::min<unsigned long long>(cold_words, (unsigned long long)g.nnz) * (4 + h->vsize());
         if (need > (unsigned long long)h->slab_mem_mib << 20)
             return fail_hip(hipErrorOutOfMemory, "column slabs: CSR5HIP_OPT_SLAB_MEMORY_MIB");
     }
@@ -851,6 +864,7 @@ static int build_slabs_impl(csr5hip_handle h)
         HIP_TRY(h->b_hot_tile0.reserve(((size_t)2 * S + 1) * 4)); // tile0[S + 1], then the slab order of the XCDs [S]
         HIP_TRY(h->b_slab_off.reserve(((size_t)S + 1) * 4));
         HIP_TRY(h->b_lead.reserve((size_t)S * HOT_RANGES_PER_SLAB * h->vsize())); // one leading partial per wavefront range
+        HIP_TRY(h->b_range_head.reserve(((size_t)S * HOT_RANGES_PER_SLAB + 1) * 4));
         HIP_TRY(hipMemsetAsync(ht.cnt, 0, nb, s));
         HIP_TRY(hipMemsetAsync(ht.hotmap, 0, slab_hotmap_bytes(g.n, S, bits_hot, h->slab_shift), s));
         HIP_TRY(hipMemsetAsync(ht.chist, 0, (size_t)S * slab_hot_buckets() * 4, s));
@@ -978,10 +992,19 @@ static int build_slabs_impl(csr5hip_handle h)
     c->d.hot_slabs = S;
     c->d.hot_capacity = hot_capacity;
     c->d.range_lead = h->b_lead.ptr;
+    c->d.range_head = (uint32_t *)h->b_range_head.ptr;
     int rc = csr5hip_input_csr(c, g.nnz, (int32_t *)h->b_row_ptr2.ptr, (int32_t *)h->b_col2.ptr, h->b_val2.ptr);
     c->sigma_request = hot ? hot_sigma : g.sigma;
     if (rc == CSR5HIP_SUCCESS)
         rc = csr5hip_as_csr5(c);
+    if (rc == CSR5HIP_SUCCESS && hot) {
+        // which row every wavefront range of the persistent kernel starts in (k_range_finish adds the seams)
+        hipError_t e = launch_range_heads(c->g, c->d, s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);
+        if (e != hipSuccess)
+            rc = fail_hip(e, "k_range_heads");
+    }
     if (rc != CSR5HIP_SUCCESS) {
         release_slabs(h);
         return rc;
@@ -1402,19 +1425,32 @@ int csr5hip_autotune_sigma(csr5hip_handle h, void *d_y, int *best_sigma, double 
     if (rc != CSR5HIP_SUCCESS)
         return rc;
     static const int candidates[] = {4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
-    int best = 0, capped_child_sigma = 0;
+    int best = 0;
+    // the slab child that served the last timed candidate: (slabs, hot table, child sigma); a later candidate that converts
+    // to the SAME child -- the child's sigma is capped, so every larger parent sigma may -- would time the same kernel again
+    int timed_S = -1, timed_hot = -1, timed_child_sigma = -1;
     double best_ms = 1e300;
     for (int sigma : candidates) {
         if ((long long)OMEGA * sigma > (long long)h->g.nnz && sigma != 4)
             continue; // fewer non-zeros than one tile: nothing to choose
-        if (capped_child_sigma && sigma > capped_child_sigma)
-            continue; // SpMV runs on the slab child, whose sigma is capped: this candidate would time the same kernel again
         h->sigma_request = sigma;
         rc = csr5hip_as_csr5(h);
         if (rc != CSR5HIP_SUCCESS)
             return rc;
-        if (h->slab_S > 0 && h->slab_child && h->slab_child->hot_enabled && h->slab_child->g.sigma < sigma)
-            capped_child_sigma = sigma; // (every larger parent sigma gives this same child)
+        // The slab decision itself depends on the parent's sigma (tile count, x-window coverage): only a candidate that
+        // was CONVERTED and produced the child already timed is skipped.
+        if (h->slab_S > 0 && h->slab_child && h->slab_child->hot_enabled) {
+            const int cs = h->slab_child->g.sigma;
+            if (h->slab_S == timed_S && timed_hot == 1 && cs == timed_child_sigma) {
+                rc = csr5hip_as_csr(h);
+                if (rc != CSR5HIP_SUCCESS)
+                    return rc;
+                continue;
+            }
+            timed_S = h->slab_S, timed_hot = 1, timed_child_sigma = cs;
+        } else {
+            timed_S = timed_hot = timed_child_sigma = -1;
+        }
         for (int i = 0; i < 3 && rc == CSR5HIP_SUCCESS; i++)
             rc = csr5hip_spmv(h, 1.0, d_y);
         // size the timed batch to ~0.5 ms from one timed probe launch
@@ -1495,8 +1531,8 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->x_snapshot = h->x_snapshot;
     long long bytes = (long long)h->b_arena.cap;
     for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
-                            &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_slab_tmp, &h->b_col_lo,
-                            &h->b_col_hi, &h->b_cold_base, &h->b_cold_cols, &h->b_xperm})
+                            &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_range_head, &h->b_slab_tmp,
+                            &h->b_col_lo, &h->b_col_hi, &h->b_cold_base, &h->b_cold_cols, &h->b_xperm})
         bytes += (long long)b->cap;
     if (h->slab_child)
         bytes += (long long)h->slab_child->b_arena.cap;

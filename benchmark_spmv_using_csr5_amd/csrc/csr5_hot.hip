@@ -422,21 +422,26 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
 // Seams: for every row that is open at the start of a range (or of the tail), in range order:
 //   P[row] = (the partial stored by the range in which the row begins, unless it begins exactly with this range)
 //          + the leads of all consecutive ranges that start inside the row -- the reference's calibrate pass
-//   (csr5_spmv_cuda.h:313-382) with a fixed association, so results are bit-reproducible.  The thread of the FIRST range
-//   of a row does the additions; a row spanning k ranges costs it k loads (hub rows: a few hundred at most per slab).
+//   (csr5_spmv_cuda.h:313-382) with a fixed association, so results are bit-reproducible.  Which row a range starts in is
+//   known at conversion (k_range_heads: `head`, one word per range, non-decreasing), so the thread of the FIRST range of a
+//   row finds the end of the row's run with one look at its neighbour (the usual case: the run is this range alone) or a
+//   bisection of `head`, and adds the run's leads with independent loads; a run longer than RUN_WAVE ranges (a dense
+//   row covers all 512 ranges of every slab) is summed by the whole wavefront.
+constexpr uint32_t RANGE_EXACT = 0x80000000u; // head bit: the range's first row BEGINS with the range's first element
+constexpr uint32_t RANGE_NONE = 0x7FFFFFFFu;  // head row of the (empty) ranges behind the last tile
+constexpr int RUN_WAVE = 64;
+
 struct RangeHead {
     int row;            // first row of the range, -1 = the range holds no tile
     long long first;    // index of its first element
 };
-__device__ __forceinline__ RangeHead range_head(const Geometry &g, const HotParams &hp, const uint32_t *__restrict__ tile_ptr,
-                                                int R, int nranges, int ranges_per_slab)
+__device__ __forceinline__ RangeHead range_head(const Geometry &g, const int32_t *__restrict__ tile0,
+                                                const uint32_t *__restrict__ tile_ptr, int R, int nranges, int ranges_per_slab)
 {
-    if (R < 0)
-        return RangeHead{-1, 0};
     if (R >= nranges)
         return RangeHead{g.tail_start < g.m ? g.tail_start : -1, (long long)(g.p - 1) * g.tile_elems};
     const int k = R / ranges_per_slab, rho = R % ranges_per_slab;
-    const int t0 = hp.tile0[k], n = hp.tile0[k + 1] - t0;
+    const int t0 = tile0[k], n = tile0[k + 1] - t0;
     const int q = n / ranges_per_slab, rem = n % ranges_per_slab;
     const int tb = t0 + rho * q + (rho < rem ? rho : rem);
     if (q + (rho < rem ? 1 : 0) <= 0)
@@ -444,24 +449,51 @@ __device__ __forceinline__ RangeHead range_head(const Geometry &g, const HotPara
     return RangeHead{(int)(tile_ptr[tb] & ROW_MASK), (long long)tb * g.tile_elems};
 }
 
+// conversion time, ONE workgroup: head[R] = first row of range R | RANGE_EXACT, for R = 0 .. nranges (the tail); a range
+// without tiles takes the word of the next range that has some (its lead is 0: it joins that range's run, or leads it)
+__global__ void __launch_bounds__(1024)
+k_range_heads(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ tile0,
+              const uint32_t *__restrict__ tile_ptr, int nranges, int ranges_per_slab, uint32_t *__restrict__ head)
+{
+    for (int R = threadIdx.x; R <= nranges; R += 1024) {
+        const RangeHead h = range_head(g, tile0, tile_ptr, R, nranges, ranges_per_slab);
+        head[R] = h.row < 0 ? 0xFFFFFFFFu : ((uint32_t)h.row | ((long long)row_ptr[h.row] == h.first ? RANGE_EXACT : 0u));
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint32_t fill[33]; // (nranges <= 64 * 512)
+    int nf = 0;
+    for (int R = threadIdx.x; R <= nranges; R += 1024, nf++) {
+        uint32_t w = head[R];
+        for (int R2 = R + 1; w == 0xFFFFFFFFu && R2 <= nranges; R2++)
+            w = head[R2];
+        fill[nf] = w == 0xFFFFFFFFu ? RANGE_NONE : w;
+    }
+    __syncthreads();
+    nf = 0;
+    for (int R = threadIdx.x; R <= nranges; R += 1024, nf++)
+        head[R] = fill[nf];
+}
+
 template <typename VT>
 __global__ void __launch_bounds__(256)
 k_range_finish(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-               const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
-               VT *__restrict__ P, const VT *__restrict__ lead, HotParams hp, int ranges_per_slab)
+               const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ head,
+               VT *__restrict__ P, const VT *__restrict__ lead, int nranges)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     VT *sprod = reinterpret_cast<VT *>(smem); // [T] tail products
     __shared__ VT tail_lead;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (OMEGA - 1);
     const int T = g.tile_elems;
     const long long first_tail = (long long)(g.p - 1) * T;
     const int E = (int)((long long)g.nnz - first_tail);
-    const int nranges = hp.slabs * ranges_per_slab;
     const int R = blockIdx.x * 256 + tid;
     // this thread's range and its neighbours: their loads go out together with the tail's
-    const RangeHead me = range_head(g, hp, tile_ptr, R <= nranges ? R : -1, nranges, ranges_per_slab);
-    RangeHead prev = range_head(g, hp, tile_ptr, R <= nranges ? R - 1 : -1, nranges, ranges_per_slab);
+    const bool in = R <= nranges;
+    const uint32_t hme = in ? head[R] : RANGE_NONE;
+    const uint32_t hprev = in && R > 0 ? head[R - 1] : 0xFFFFFFFFu;
+    const uint32_t hnext = in && R < nranges ? head[R + 1] : 0xFFFFFFFFu;
     for (int e = tid; e < E; e += 256) {
         const int32_t c = col[first_tail + e];
         sprod[e] = val[first_tail + e] * x[(uint32_t)c];
@@ -493,24 +525,55 @@ k_range_finish(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *_
             }
     }
     __syncthreads();
-    if (R > nranges || me.row < 0)
-        return;
-    for (int Rp = R - 2; prev.row < 0 && Rp >= 0; Rp--) // (empty ranges: only in slabs with fewer tiles than wavefronts)
-        prev = range_head(g, hp, tile_ptr, Rp, nranges, ranges_per_slab);
-    if (prev.row == me.row)
-        return; // not the first range of its row
-    // the row begins exactly with this range (nobody stored a partial for it) or inside an earlier one
-    VT sum = (long long)row_ptr[me.row] == me.first ? (VT)0 : P[me.row];
-    sum += R == nranges ? tail_lead : lead[R];
-    for (int R2 = R + 1; R2 <= nranges; R2++) {
-        const RangeHead h2 = range_head(g, hp, tile_ptr, R2, nranges, ranges_per_slab);
-        if (h2.row < 0)
-            continue;
-        if (h2.row != me.row)
-            break;
-        sum += R2 == nranges ? tail_lead : lead[R2];
+    const uint32_t row = hme & ROW_MASK;
+    // first range of its row?  (rows never decrease along the ranges)
+    const bool leader = in && row != RANGE_NONE && (R == 0 || (hprev & ROW_MASK) != row);
+    auto lead_of = [&](int R2) -> VT { return R2 == nranges ? tail_lead : lead[R2]; };
+    int stop = R + 1; // one past the last range of the run
+    if (leader && R < nranges && (hnext & ROW_MASK) == row) {
+        int lo = R + 2, hi = nranges + 1; // first index whose row differs, in (R + 1, nranges + 1]
+        while (lo < hi) {
+            const int mid = (int)(((unsigned)lo + (unsigned)hi) >> 1);
+            if ((head[mid] & ROW_MASK) == row)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        stop = lo;
     }
-    P[me.row] = sum;
+    const int len = stop - R;
+    // the row begins exactly with this range (nobody stored a partial for it) or inside an earlier one
+    VT sum = 0;
+    if (leader)
+        sum = (hme & RANGE_EXACT) ? (VT)0 : P[row];
+    if (leader && len <= RUN_WAVE) {
+        int R2 = R;
+        for (; R2 + 8 <= stop; R2 += 8) { // range order, eight independent loads at a time
+            VT part[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                part[j] = lead_of(R2 + j);
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                sum += part[j];
+        }
+        for (; R2 < stop; R2++)
+            sum += lead_of(R2);
+        P[row] = sum;
+    }
+    // long runs: the whole wavefront adds the leads (lane-strided partial sums, then a fixed-shape reduction)
+    unsigned long long todo = __ballot(leader && len > RUN_WAVE);
+    while (todo) {
+        const int who = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int r0 = __shfl(R, who, OMEGA), r1 = __shfl(stop, who, OMEGA);
+        VT part = 0;
+        for (int R2 = r0 + lane; R2 < r1; R2 += OMEGA)
+            part += lead_of(R2);
+        part = wave_sum(part);
+        if (lane == who)
+            P[row] = sum + part;
+    }
 }
 
 // ---- the permuted copy of x ---------------------------------------------------------------------------------------------
@@ -568,9 +631,20 @@ static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const v
     const size_t lds = (size_t)d.hot_capacity * sizeof(VT) + (size_t)HOT_WAVES * HOT_WAVE_LDS;
     constexpr int DEPTH = CSR5_HOT_DEPTH;
     auto kern = k_spmv_range<VT, SIGMA, NT, DEPTH, PACKED>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // the LDS limit of this instantiation is raised once per device and size, not on every SpMV (a host-side driver call
+    // in front of a launch of a few hundred microseconds; `lds` depends only on the table capacity and the value type)
+    static int lds_set[64]; // [device]: the size the attribute was last set to (0 = never)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess)
         return e;
+    if (dev < 0 || dev >= 64 || lds_set[dev] != (int)lds) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        if (dev >= 0 && dev < 64)
+            lds_set[dev] = (int)lds;
+    }
     if (g.p > 1) {
         hipLaunchKernelGGL(kern, dim3(NUM_XCD * HOT_WGS_PER_XCD), dim3(HOT_BLOCK), lds, s, g, d.col, (const VT *)d.val,
                            (const VT *)x, d.tile_ptr, d.tile_desc, (VT *)y, (VT *)d.range_lead, hp);
@@ -578,10 +652,20 @@ static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const v
         if (e != hipSuccess)
             return e;
     }
-    const int ranges = HOT_RANGES_PER_SLAB;
-    const int blocks = (d.hot_slabs * ranges + 1 + 255) / 256;
+    const int nranges = d.hot_slabs * HOT_RANGES_PER_SLAB;
+    const int blocks = (nranges + 1 + 255) / 256;
     hipLaunchKernelGGL(k_range_finish<VT>, dim3(blocks), dim3(256), (size_t)g.tile_elems * sizeof(VT), s, g, d.row_ptr, d.col,
-                       (const VT *)d.val, (const VT *)x, d.tile_ptr, (VT *)y, (const VT *)d.range_lead, hp, ranges);
+                       (const VT *)d.val, (const VT *)x, d.range_head, (VT *)y, (const VT *)d.range_lead, nranges);
+    return hipGetLastError();
+}
+
+// conversion time (after the child's tile_ptr exists): which row every wavefront range starts in
+hipError_t launch_range_heads(const Geometry &g, const DeviceArrays &d, hipStream_t s)
+{
+    if (g.p <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_range_heads, dim3(1), dim3(1024), 0, s, g, d.row_ptr, d.hot_tile0, d.tile_ptr,
+                       d.hot_slabs * HOT_RANGES_PER_SLAB, HOT_RANGES_PER_SLAB, d.range_head);
     return hipGetLastError();
 }
 

@@ -76,6 +76,7 @@ struct DeviceArrays {
     const int32_t *hot_tile0;  // [hot_slabs + 1] first tile of every slab, then [hot_slabs] the slabs each XCD walks
     int hot_slabs, hot_capacity;
     void *range_lead;          // [hot_slabs * HOT_RANGES_PER_SLAB] of vT: leading partial of every wavefront range (csr5_hot.hip)
+    uint32_t *range_head;      // [hot_slabs * HOT_RANGES_PER_SLAB + 1] first row of every range (+ the CSR tail), k_range_heads
     // packed column codes of a hot child (k_hot_encode PACK): 3 bytes per non-zero in the child's CSR order; nullptr = the
     // column words themselves are hot-encoded (col)
     const uint16_t *col_lo;
@@ -183,6 +184,7 @@ hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type,
 // csr5_hot.hip: the slab child's SpMV when its column words are hot-encoded (persistent range kernel + finish)
 hipError_t launch_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, void *y,
                            const SpmvOptions &opt, hipStream_t s);
+hipError_t launch_range_heads(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 // the permuted copy of x behind the packed codes of a hot child: xperm[i] = x[hot_cols[i]] for the table images,
 // xperm[slabs * capacity + i] = x[cold_cols[i]] for the cold region
 hipError_t launch_x_permute(const DeviceArrays &d, int value_type, const void *x, hipStream_t s);

@@ -48,12 +48,20 @@ double getFLOP(const iT nnz)
     return 2.0 * (double)nnz;
 }
 
-// wall-clock timer in milliseconds, same protocol as the reference's gettimeofday timer
+// Timer in milliseconds.  The CUDA variant's timer is a pair of events on the default stream whose stop() waits for the
+// device (CSR5_cuda/detail/cuda/utils_cuda.h:6-23), so a caller may time an asynchronous spmv() loop without a
+// synchronisation of its own.  Same guarantee here: start() and stop() drain the device before reading the host clock
+// (the AVX2 variant's timer is plain gettimeofday, CSR5_avx2/detail/utils.h -- its spmv() is synchronous).
 struct anonymouslib_timer {
     timeval t1, t2;
-    void start() { gettimeofday(&t1, 0); }
+    void start()
+    {
+        (void)csr5hip_synchronize();
+        gettimeofday(&t1, 0);
+    }
     double stop()
     {
+        (void)csr5hip_synchronize();
         gettimeofday(&t2, 0);
         return (t2.tv_sec - t1.tv_sec) * 1000.0 + (t2.tv_usec - t1.tv_usec) / 1000.0;
     }

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--slabs", default="auto")
     ap.add_argument("--hot", default="auto")
     ap.add_argument("--row-weight", type=int, default=None)
+    ap.add_argument("--x-snapshot", type=int, default=1, help="as bench.py: the permuted copy of x is taken once per setX")
     args = ap.parse_args()
     import torch
     from benchmark_spmv_using_csr5_amd import handle as H
@@ -44,6 +45,7 @@ def main():
         A.setSigma(-1)
         A.setColumnSlabs(1 if args.slabs == "auto" else int(args.slabs))
         A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.hot])
+        A.setXSnapshot(args.x_snapshot)
         ck(A.asCSR5(), "asCSR5")
         i = A.info()
         ck(A.spmv_repeat(1.0, y, 10), "spmv_repeat")

@@ -366,3 +366,65 @@ def test_slab_build_failure_falls_back_to_plain_kernel(oracle):
     assert A.setSlabMemoryMiB(0) == 0 and A.asCSR5() == 0 and A.info().column_slabs == 8
     assert A.destroy() == 0
     A.close()
+
+
+def test_permuted_x_live_and_snapshot(oracle):
+    """The hot child gathers from a private permuted copy of x (table images + frequency-ordered cold regions).
+    Default (CSR5HIP_OPT_X_SNAPSHOT = 0): the copy is taken by every spmv(), so x is read LIVE like the reference's texture
+    gathers (csr5_spmv_cuda.h:7-23) -- a caller may overwrite x's contents between calls without telling the handle.
+    Snapshot mode: the copy is taken by the first spmv() after setX(); writing x and calling setX() again (same pointer)
+    refreshes it.  Both also through hipGraph replay, fp64 and fp32, bit-exact on integer data."""
+    mat = M.rmat(15, 16, seed=11)
+    for dtype in (np.float64, np.float32):
+        tdt = torch.float64 if dtype == np.float64 else torch.float32
+        val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=21, mode="int")
+        x = (x % 3).astype(dtype)  # small: doubled twice it stays exact in fp32 row sums
+        val = (val % 3).astype(dtype)
+        ref1 = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val.astype(np.float64), x.astype(np.float64))
+        has = np.diff(mat.row_ptr) > 0
+        rp = torch.from_numpy(mat.row_ptr.astype(np.int32)).to(DEV)
+        ci = torch.from_numpy(mat.col.astype(np.int32)).to(DEV)
+        va = torch.from_numpy(val).to(DEV)
+        xd = torch.from_numpy(x).to(DEV)
+        y = torch.zeros(mat.m, dtype=tdt, device=DEV)
+        A = H.anonymouslibHandle(mat.m, mat.n, dtype=np.dtype(dtype).name)
+        assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0  # setX BEFORE asCSR5, as the reference CLI does
+        assert A.setSigma(16) == 0 and A.setColumnSlabs(8) == 0 and A.setSlabHot(2) == 0
+        assert A.asCSR5() == 0
+        info = A.info()
+        assert info.slab_hot == 1 and info.slab_x_permuted == 1 and info.x_snapshot == 0
+
+        def check(factor, what):
+            torch.cuda.synchronize()
+            got = y.cpu().numpy().astype(np.float64)
+            assert np.array_equal(got[has], factor * ref1[has]), (what, np.dtype(dtype).name)
+
+        assert A.spmv(1.0, y) == 0
+        check(1, "live, first call")
+        xd.mul_(2)  # no setX: the next spmv must see the new contents
+        assert A.spmv(1.0, y) == 0
+        check(2, "live, x overwritten in place")
+        assert A.spmv_repeat(1.0, y, 3) == 0
+        check(2, "live, graph replay")
+        xd.mul_(2)
+        assert A.spmv_repeat(1.0, y, 3) == 0  # the SAME captured graph re-reads x
+        check(4, "live, graph replay after another overwrite")
+        # snapshot mode
+        assert A.setXSnapshot(1) == 0 and A.info().x_snapshot == 1
+        assert A.setX(xd) == 0
+        assert A.spmv(1.0, y) == 0
+        check(4, "snapshot, first call after setX")
+        xd.div_(4)
+        assert A.setX(xd) == 0  # contents changed: setX again, same pointer
+        assert A.spmv_repeat(1.0, y, 2) == 0
+        check(1, "snapshot, setX after overwrite, graph replay")
+        assert A.spmv(1.0, y) == 0
+        check(1, "snapshot, eager call after the graph")
+        # conversion cycle keeps working and restores the caller's arrays
+        assert A.asCSR() == 0 and A.asCSR5() == 0
+        assert A.spmv(1.0, y) == 0
+        check(1, "snapshot, after asCSR / asCSR5")
+        assert A.destroy() == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(ci.cpu().numpy(), mat.col)
+        A.close()
