@@ -691,14 +691,14 @@ static int slab_count_for(const csr5hip_handle_s *h)
     // 119 / 441 / 1674 us: every further round costs a table refill and a workgroup barrier)
     // (beyond R-MAT 24 -- scale 25 / 26, x = 268 / 537 MB -- four slabs per XCD win again: 3 011 vs 3 113 us, 6 691 vs 6 970 us)
     int S = xbytes < 64LL * 1024 * 1024 ? 8 : (xbytes < 256LL * 1024 * 1024 ? 16 : 32);
-    // ... as long as every wavefront of the persistent kernel still gets a dozen tiles per slab: a matrix with few
+    // ... as long as every wavefront of the persistent kernel still gets two dozen tiles per slab: a matrix with few
     // non-zeros per column of x -- one of eight row blocks of R-MAT 24 holds 33 M non-zeros against the full 134-MB x --
-    // runs out of tiles first (8 per wavefront and slab at 16 slabs), and the pipeline restart and table refill of every
-    // slab then cost more than the coverage buys.  Measured alone on the GPU (scripts/experiments/shard_alone.py): blocks
-    // 0 / 3 / 7 of 8 take 198 / 214 / 198 us with 16 slabs and 200 / 201 / 176 us with 8; blocks of 4 (74 M non-zeros, 18
-    // tiles per wavefront and slab) 336 / 354 vs 367 / 352 us.
+    // runs out of tiles first (18 per wavefront and slab at 16 slabs), and the pipeline restart and table refill of every
+    // slab then cost more than the coverage buys.  Measured alone on the GPU (scripts/experiments/shard_alone.py, round 4:
+    // 256 wavefront ranges per slab): blocks 0 / 3 / 7 of 8 take 173 / 193 / 188 us with 16 slabs and 176 / 188 / 175 us
+    // with 8; blocks of 4 (74 M non-zeros, 35 tiles per wavefront and slab) are faster with 16.
     const long long child_tiles = (long long)h->g.nnz / ((long long)OMEGA * hot_child_sigma(h->g.sigma, (int)h->vsize()));
-    while (S > NUM_XCD && child_tiles / ((long long)S * HOT_RANGES_PER_SLAB) < 12)
+    while (S > NUM_XCD && child_tiles / ((long long)S * HOT_RANGES_PER_SLAB) < 24)
         S /= 2;
     return S;
 }

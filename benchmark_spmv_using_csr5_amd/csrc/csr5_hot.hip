@@ -19,7 +19,7 @@
 
 namespace csr5 {
 
-constexpr int HOT_BLOCK = 1024;
+constexpr int HOT_BLOCK = HOT_WAVES * OMEGA;
 
 // PACKED: the child's column words come as 3-byte codes (k_hot_encode PACK) in CSR order -- lane l's sigma codes are
 // consecutive: 2 sigma bytes of col_lo, sigma bytes of col_hi -- and are decoded into c[] when they have arrived.
@@ -371,8 +371,10 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
             }
         } else {
             // DEPTH 2: the next tile's streams go out right in front of this tile's gathers (their long HBM round trip
-            // starts first; same-call A/B: 1 % faster than behind them) and are in flight while it computes.  Tiles are taken in pairs (two register sets, no copies) and an odd last tile is peeled: a
-            // `break` in the middle of the pair loop leaves the compiler a path on which the second set's loads are
+            // starts first; same-call A/B: 1 % faster than behind them) and are in flight while it computes.  (Streams
+            // TWO tiles ahead -- three register sets, 132 VGPRs -- measured equal at 8 wavefronts per CU and 3 % slower at
+            // 16: profiles/r04_probes.txt.)  Tiles are taken in pairs (two register sets, no copies) and an odd last
+            // tile is peeled: a `break` in the middle of the pair loop leaves the compiler a path on which the second set's loads are
             // still pending at the loop head, and it then drains the whole queue (s_waitcnt vmcnt(0)) in front of
             // every pair's gathers.
             TileRegs<VT, SIGMA, PACKED> a, b;

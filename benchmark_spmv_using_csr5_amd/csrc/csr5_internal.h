@@ -150,9 +150,16 @@ struct SpmvOptions {
     int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_range + k_range_finish
 };
 constexpr int HOT_LDS_BYTES = 128 * 1024;  // upper bound of the LDS table of hot x entries per workgroup (k_spmv_range)
-constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_range (16 wavefronts)
-constexpr int HOT_WAVES = 16;
-constexpr int HOT_WGS_PER_XCD = 32;        // one 1024-thread workgroup per CU
+constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_range
+// Wavefronts of the persistent workgroup (one workgroup per CU).  The kernel is bound by the L1's outstanding requests,
+// not by occupancy, so every y-compaction region given back to the table buys coverage: same-call A/B on R-MAT 24 / 22
+// (profiles/r04_probes.txt) 16 wavefronts + 12 288 fp64 slots 1 197 / 260 us, 12 + 14 336: 1 181 / 253, 8 + 16 384:
+// 1 178 / 253, 6 + 17 408: 1 200 / 266, 4 + 18 432: 1 304 / 300.
+#ifndef CSR5_HOT_WAVES
+#define CSR5_HOT_WAVES 8
+#endif
+constexpr int HOT_WAVES = CSR5_HOT_WAVES;
+constexpr int HOT_WGS_PER_XCD = 32;        // one workgroup per CU
 constexpr int HOT_RANGES_PER_SLAB = HOT_WGS_PER_XCD * HOT_WAVES; // every wavefront of the slab's XCD owns one tile range
 #ifndef CSR5_HOT_DEPTH
 #define CSR5_HOT_DEPTH 2                   // tiles whose streams are in flight per wavefront (1 or 2)

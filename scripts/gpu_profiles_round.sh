@@ -3,7 +3,7 @@
 # WRITE_SIZE, TCC hit/miss; counters only), parsed ON THE BOX into small files under gpurun_out/profiles_$ROUND/
 # (the raw rocprofv3 directories are deleted: gpurun copies back at most 64 MiB).
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 OUT=$REPO/gpurun_out/profiles_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -20,11 +20,14 @@ run() { # tag, bench args
   python3 $REPO/scripts/profile_parse.py $tag $d $OUT
   rm -rf $d
 }
-run rmat24 --steps 20 --warmup 5
-run rmat24_noslab --steps 10 --warmup 2 --slabs 0
-run rmat22 --workload rmat22 --steps 30 --warmup 5
-run webbase --workload webbase --steps 300 --no-cold
-run webbase_noslab --workload webbase --steps 300 --slabs 0 --no-cold
-run scircuit --workload scircuit --steps 1000 --no-cold
-run nd24k --workload nd24k --steps 200 --no-cold
+# RUNS = which of the runs below to make (default: all)
+RUNS=${RUNS:-"rmat24 rmat24_noslab rmat22 webbase webbase_noslab scircuit nd24k"}
+want() { case " $RUNS " in *" $1 "*) return 0;; esac; return 1; }
+want rmat24 && run rmat24 --steps 20 --warmup 5
+want rmat24_noslab && run rmat24_noslab --steps 10 --warmup 2 --slabs 0
+want rmat22 && run rmat22 --workload rmat22 --steps 30 --warmup 5
+want webbase && run webbase --workload webbase --steps 300 --no-cold
+want webbase_noslab && run webbase_noslab --workload webbase --steps 300 --slabs 0 --no-cold
+want scircuit && run scircuit --workload scircuit --steps 1000 --no-cold
+want nd24k && run nd24k --workload nd24k --steps 200 --no-cold
 ls -la $OUT
