@@ -135,8 +135,8 @@ struct csr5hip_handle_s {
     Buffer b_slab_tmp; // temporaries of the slab build; kept between conversions only while small (SLAB_TMP_KEEP)
     // LDS hot table of the slab child (k_spmv_hot): chosen at conversion, see csr5_slab.hip
     int hot_request = 1;      // CSR5HIP_OPT_SLAB_HOT: 0 off, 1 auto, 2 force
-    bool hot_enabled = false; // (child) column words are hot-encoded: spmv must use the persistent hot kernel
-    bool hot_packed = false;  // (child) ... as packed codes next to the plain column words: only the values are transposed
+    bool hot_enabled = false; // (child) its columns are hot-encoded as packed codes next to the plain column words (only the values
+                              // are transposed): spmv must use the persistent range kernel
     int hot_cover_pct = 0;    // (parent) share of the non-zeros whose column got a table slot
     Buffer b_hot_cols, b_hot_count, b_hot_tile0, b_slab_off, b_lead, b_range_head;
     Buffer b_col_lo, b_col_hi; // packed column codes of a hot child (3 bytes per non-zero)
@@ -602,7 +602,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
         if (rc != CSR5HIP_SUCCESS)
             return rc;
         // step 3: in-place tile transpose of column_index and value, then the kernel-side tables
-        if (h->is_child && h->hot_packed)
+        if (h->is_child && h->hot_enabled)
             HIP_TRY(launch_transpose_values(g, h->d, h->value_type, s)); // (the column codes are read in CSR order)
         else
             HIP_TRY(launch_transpose(g, h->d, h->value_type, true, s));
@@ -614,7 +614,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
         rc = finish();
         if (rc != CSR5HIP_SUCCESS) {
             const std::string why = g_last_error;
-            if (h->is_child && h->hot_packed)
+            if (h->is_child && h->hot_enabled)
                 h->format = -1; // only the VALUES of every tile were transposed (private arrays of a slab structure, which the
                                 // parent releases on failure): nothing to restore, the handle is unusable until inputCSR
             else if (launch_transpose(g, h->d, h->value_type, false, s) != hipSuccess ||
@@ -691,14 +691,13 @@ static int slab_count_for(const csr5hip_handle_s *h)
     // 119 / 441 / 1674 us: every further round costs a table refill and a workgroup barrier)
     // (beyond R-MAT 24 -- scale 25 / 26, x = 268 / 537 MB -- four slabs per XCD win again: 3 011 vs 3 113 us, 6 691 vs 6 970 us)
     int S = xbytes < 64LL * 1024 * 1024 ? 8 : (xbytes < 256LL * 1024 * 1024 ? 16 : 32);
-    // ... as long as every wavefront of the persistent kernel still gets two dozen tiles per slab: a matrix with few
-    // non-zeros per column of x -- one of eight row blocks of R-MAT 24 holds 33 M non-zeros against the full 134-MB x --
-    // runs out of tiles first (18 per wavefront and slab at 16 slabs), and the pipeline restart and table refill of every
-    // slab then cost more than the coverage buys.  Measured alone on the GPU (scripts/experiments/shard_alone.py, round 4:
-    // 256 wavefront ranges per slab): blocks 0 / 3 / 7 of 8 take 173 / 193 / 188 us with 16 slabs and 176 / 188 / 175 us
-    // with 8; blocks of 4 (74 M non-zeros, 35 tiles per wavefront and slab) are faster with 16.
-    const long long child_tiles = (long long)h->g.nnz / ((long long)OMEGA * hot_child_sigma(h->g.sigma, (int)h->vsize()));
-    while (S > NUM_XCD && child_tiles / ((long long)S * HOT_RANGES_PER_SLAB) < 24)
+    // ... as long as every wavefront of the persistent kernel still gets a dozen tiles per slab (256 ranges per slab): below
+    // that the pipeline restart and the table refill of every slab cost more than the coverage buys.  One of eight row
+    // blocks of R-MAT 24 (25-37 M non-zeros against the full 134-MB x; 12-18 tiles per wavefront and slab at 16 slabs) is
+    // faster with 16 slabs once its tables are full -- 165 / 180 / 177 us for blocks 0 / 3 / 7 against 176 / 186 / 169 with
+    // 8 (scripts/experiments/shard_alone.py, profiles/r04_shards.txt).
+    const long long child_tiles = (long long)h->g.nnz / ((long long)OMEGA * hot_child_sigma((int)h->vsize()));
+    while (S > NUM_XCD && child_tiles / ((long long)S * HOT_RANGES_PER_SLAB) < 12)
         S /= 2;
     return S;
 }
@@ -751,13 +750,17 @@ static int build_slabs_impl(csr5hip_handle h)
     int S_plain = auto_count ? slab_count_without_table(h) : S; // the count if the table is not used
 
     // LDS hot table for the persistent kernel (fused mode, S a multiple of the 8 XCDs, register budget of 16 waves/CU)?
-    const int hot_sigma = hot_child_sigma(g.sigma, (int)h->vsize());
+    const int hot_sigma = hot_child_sigma((int)h->vsize());
     const int hot_T = OMEGA * hot_sigma;
     const int hot_p = (int)(((long long)g.nnz + hot_T - 1) / hot_T);
+    // (a slab-local column id -- and with it a cold rank -- must fit the 23 bits of a packed column code)
+    int bits_s = 0;
+    while ((1 << bits_s) < S)
+        bits_s++;
     bool hot = h->hot_request != 0 && S % NUM_XCD == 0 && h->opt.mode == 1 && hot_sigma >= 4 && hot_p >= 2 &&
-               (long long)g.n * (long long)h->vsize() <= 0x7FFFFFFFLL;
+               (long long)g.n * (long long)h->vsize() <= 0x7FFFFFFFLL &&
+               slab_local_columns(g.n, bits_s, h->slab_shift) <= ((size_t)1 << 23);
     int hot_capacity = 0;
-    bool hot_packed = false;
     if (hot) {
         int dev = 0, lds_max = 0;
         HIP_TRY(hipGetDevice(&dev));
@@ -856,8 +859,12 @@ static int build_slabs_impl(csr5hip_handle h)
         // plenty to rank columns, and a full count serialises on the very columns it is looking for.
         stride = (int)(g.nnz / (4LL * 1024 * 1024));
         stride = stride < 1 ? 1 : (stride > 64 ? 64 : stride); // (R-MAT 24: 1/64 ranks as well as 1/32, 1/128 costs 1.5 % of the SpMV)
-        // a slot is staged by each of the ~32 workgroups of the slab's XCD in every SpMV: it must be used more often
-        int min_count = 48 / stride;
+        // A slot is staged by each of the 32 workgroups of the slab's XCD in every SpMV (a coalesced copy out of the
+        // permuted x: about what two cold gathers cost), so a column must be used a few times per SpMV to earn one -- and
+        // the sample must have seen it twice to say so.  16 uses: with 48 (round 3) a row block of R-MAT 24 -- its columns
+        // are used an eighth as often -- left a quarter of its table empty (coverage 60 -> 72 %, 189 -> 180 us on the slowest
+        // of the eight blocks, profiles/r04_shards.txt); the whole matrix fills its tables either way.
+        int min_count = 16 / stride;
         min_count = min_count < 2 ? 2 : min_count;
         HIP_TRY(h->b_hot_cols.reserve((size_t)S * hot_capacity * 4));
         HIP_TRY(h->b_hot_count.reserve((size_t)S * 4));
@@ -932,10 +939,9 @@ static int build_slabs_impl(csr5hip_handle h)
             load[best] += first_tile[k + 1] - first_tile[k];
         }
         HIP_TRY(hipMemcpyAsync((int32_t *)h->b_hot_tile0.ptr + S + 1, order.data(), (size_t)S * 4, hipMemcpyHostToDevice, s));
-        // 3-byte column codes next to the plain words when a lane's codes are whole dwords and a slab-local id fits 23 bits
-        hot_packed = hot_sigma % 4 == 0 && slab_local_columns(g.n, bits, h->slab_shift) <= ((size_t)1 << 23);
+        // 3-byte column codes next to the plain words (the child's sigma is a multiple of four: whole dwords per lane)
         int32_t cold_total = 0;
-        if (hot_packed) {
+        {
             HIP_TRY(h->b_col_lo.reserve((size_t)g.nnz * 2 + 64));
             HIP_TRY(h->b_col_hi.reserve((size_t)g.nnz + 64));
             // the cold region holds at most one entry per column of every slab, and no more than there are non-zeros
@@ -951,9 +957,6 @@ static int build_slabs_impl(csr5hip_handle h)
                                   (uint32_t *)(tb + o_src), tb + o_sort, cold_sort_bytes, (int32_t *)h->b_cold_base.ptr,
                                   (int32_t *)h->b_cold_cols.ptr, s));
             HIP_TRY(hipMemcpyAsync(&cold_total, (int32_t *)h->b_cold_base.ptr + S, 4, hipMemcpyDeviceToHost, s));
-        } else {
-            HIP_TRY(slab_hot_rewrite(g.n, g.nnz, hot_T, hot_p, S, bits, h->slab_shift, (const int32_t *)h->b_slab_off.ptr,
-                                     ht.hotmap, (int32_t *)h->b_col2.ptr, s));
         }
         HIP_TRY(hipStreamSynchronize(s));
         h->cold_total = cold_total;
@@ -975,16 +978,15 @@ static int build_slabs_impl(csr5hip_handle h)
     c->ldsy_request = h->ldsy_request;
     c->nt_request = h->nt_request;
     c->hot_enabled = hot;
-    c->hot_packed = hot && hot_packed;
-    c->d.col_lo = c->hot_packed ? (const uint16_t *)h->b_col_lo.ptr : nullptr;
-    c->d.col_hi = c->hot_packed ? (const uint8_t *)h->b_col_hi.ptr : nullptr;
+    c->d.col_lo = hot ? (const uint16_t *)h->b_col_lo.ptr : nullptr;
+    c->d.col_hi = hot ? (const uint8_t *)h->b_col_hi.ptr : nullptr;
     c->d.slab_off = (const int32_t *)h->b_slab_off.ptr;
     c->d.slab_shift = h->slab_shift;
     c->d.slab_bits = bits;
-    c->d.xperm = c->hot_packed ? h->b_xperm.ptr : nullptr;
-    c->d.cold_base = c->hot_packed ? (const int32_t *)h->b_cold_base.ptr : nullptr;
-    c->d.cold_cols = c->hot_packed ? (const int32_t *)h->b_cold_cols.ptr : nullptr;
-    c->d.cold_total = c->hot_packed ? h->cold_total : 0;
+    c->d.xperm = hot ? h->b_xperm.ptr : nullptr;
+    c->d.cold_base = hot ? (const int32_t *)h->b_cold_base.ptr : nullptr;
+    c->d.cold_cols = hot ? (const int32_t *)h->b_cold_cols.ptr : nullptr;
+    c->d.cold_total = hot ? h->cold_total : 0;
     h->xperm_valid = false;
     c->d.hot_cols = (const int32_t *)h->b_hot_cols.ptr;
     c->d.hot_count = (const int32_t *)h->b_hot_count.ptr;
@@ -1019,7 +1021,7 @@ static int build_slabs_impl(csr5hip_handle h)
 // (or graph capture) that needs it
 static hipError_t ensure_x_snapshot(csr5hip_handle h, hipStream_t s)
 {
-    if (!h->x_snapshot || h->xperm_valid || h->slab_S <= 0 || !h->slab_child->hot_packed)
+    if (!h->x_snapshot || h->xperm_valid || h->slab_S <= 0 || !h->slab_child->hot_enabled)
         return hipSuccess;
     hipError_t e = launch_x_permute(h->slab_child->d, h->value_type, h->x, s);
     if (e == hipSuccess)
@@ -1034,7 +1036,7 @@ static hipError_t enqueue_spmv(csr5hip_handle h, void *d_y, hipStream_t s)
     if (h->slab_S > 0) {
         csr5hip_handle c = h->slab_child;
         hipError_t e = hipSuccess;
-        if (c->hot_packed && !(h->x_snapshot && h->xperm_valid)) {
+        if (c->hot_enabled && !(h->x_snapshot && h->xperm_valid)) {
             // the packed codes index the permuted copy of x: taken by every spmv() (x is read live, as the reference reads
             // it), or -- CSR5HIP_OPT_X_SNAPSHOT -- once per setX
             e = launch_x_permute(c->d, c->value_type, h->x, s);
@@ -1526,7 +1528,7 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_hot = h->slab_S > 0 && h->slab_child->hot_enabled ? 1 : 0;
     info->slab_hot_cover_pct = h->hot_cover_pct;
     info->slab_fallback = h->slab_fallback ? 1 : 0;
-    info->slab_x_permuted = h->slab_S > 0 && h->slab_child->hot_packed ? 1 : 0;
+    info->slab_x_permuted = h->slab_S > 0 && h->slab_child->hot_enabled ? 1 : 0;
     info->slab_cold_entries = info->slab_x_permuted ? h->cold_total : 0;
     info->x_snapshot = h->x_snapshot;
     long long bytes = (long long)h->b_arena.cap;

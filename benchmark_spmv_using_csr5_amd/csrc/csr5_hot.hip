@@ -2,8 +2,9 @@
 //
 // What it computes is the reference's tile kernel (CSR5_cuda/detail/cuda/csr5_spmv_cuda.h:59-311: fast / normal track,
 // lane-local flag walk, cross-lane segmented sum) on the child's CSR5 arrays; how the work is laid out is ours:
-//   * one 1024-thread workgroup per CU stays resident; XCD x walks its slabs in order, refilling the LDS table with
-//     the slab's hot x entries (hot gathers = ds_read_b64, cold ones = range-checked buffer loads);
+//   * one workgroup of HOT_WAVES wavefronts per CU stays resident; XCD x walks its slabs in order, refilling the LDS table
+//     with the slab's hot x entries (hot gathers = ds_read_b64, cold ones = range-checked buffer loads from the permuted
+//     copy of x);
 //   * every WAVEFRONT owns ONE CONTIGUOUS RANGE of the slab's tiles (512 ranges per slab).  The row that is open at a
 //     tile boundary therefore meets its continuation in the registers of the same wavefront: a tile needs no header,
 //     no re-read of its successor's first elements, no carry slot and no atomic -- the reference's calibrate pass
@@ -21,12 +22,14 @@ namespace csr5 {
 
 constexpr int HOT_BLOCK = HOT_WAVES * OMEGA;
 
-// PACKED: the child's column words come as 3-byte codes (k_hot_encode PACK) in CSR order -- lane l's sigma codes are
-// consecutive: 2 sigma bytes of col_lo, sigma bytes of col_hi -- and are decoded into c[] when they have arrived.
-template <typename VT, int SIGMA, bool PACKED>
+// The child's column words come as 3-byte codes (k_hot_encode ENC_PACK) in CSR order -- lane l's sigma codes are
+// consecutive: 2 sigma bytes of col_lo, sigma bytes of col_hi (whole dwords: the child's sigma is a multiple of four) --
+// and are decoded into c[] when they have arrived.
+template <typename VT, int SIGMA>
 struct TileRegs {
+    static_assert(SIGMA % 4 == 0, "a lane's column codes are whole dwords");
     int32_t c[SIGMA];
-    uint32_t plo[PACKED ? SIGMA / 2 : 1], phi[PACKED ? SIGMA / 4 : 1];
+    uint32_t plo[SIGMA / 2], phi[SIGMA / 4];
     VT v[SIGMA];
     uint32_t w0, tp0, tp1;
 };
@@ -52,24 +55,17 @@ __device__ __forceinline__ void load_dwords(uint32_t *dst, const uint32_t *p)
 
 // every load of tile t: column words first (the gathers wait for them only), then the descriptor word, the tile_ptr
 // pair (scalar) and the values
-template <typename VT, int SIGMA, bool NT, bool PACKED>
-__device__ __forceinline__ void range_load(TileRegs<VT, SIGMA, PACKED> &r, const int32_t *__restrict__ col,
-                                           const uint16_t *__restrict__ col_lo, const uint8_t *__restrict__ col_hi,
-                                           const VT *__restrict__ val, const uint32_t *__restrict__ tile_desc,
-                                           const uint32_t *__restrict__ tile_ptr, int t, int lane)
+template <typename VT, int SIGMA, bool NT>
+__device__ __forceinline__ void range_load(TileRegs<VT, SIGMA> &r, const uint16_t *__restrict__ col_lo,
+                                           const uint8_t *__restrict__ col_hi, const VT *__restrict__ val,
+                                           const uint32_t *__restrict__ tile_desc, const uint32_t *__restrict__ tile_ptr, int t,
+                                           int lane)
 {
     constexpr int T = OMEGA * SIGMA;
     const VT *vt = val + (size_t)t * T + lane;
-    if constexpr (PACKED) {
-        const size_t first = (size_t)t * T + (size_t)lane * SIGMA;
-        load_dwords<SIGMA / 2, NT>(r.plo, reinterpret_cast<const uint32_t *>(col_lo + first));
-        load_dwords<SIGMA / 4, NT>(r.phi, reinterpret_cast<const uint32_t *>(col_hi + first));
-    } else {
-        const int32_t *ct = col + (size_t)t * T + lane;
-#pragma unroll
-        for (int i = 0; i < SIGMA; i++)
-            r.c[i] = NT ? __builtin_nontemporal_load(ct + i * OMEGA) : ct[i * OMEGA];
-    }
+    const size_t first = (size_t)t * T + (size_t)lane * SIGMA;
+    load_dwords<SIGMA / 2, NT>(r.plo, reinterpret_cast<const uint32_t *>(col_lo + first));
+    load_dwords<SIGMA / 4, NT>(r.phi, reinterpret_cast<const uint32_t *>(col_hi + first));
     r.w0 = tile_desc[(size_t)t * OMEGA + lane];
     {
         // the tile_ptr pair is wave-uniform: through the scalar cache (constant address space -> s_load_dwordx2, requested
@@ -91,11 +87,10 @@ struct OpenRow {
     bool is_lead; // the row was already open when the range began: the partial goes to lead[range], not to P
 };
 
-template <typename VT, int SIGMA, bool NT, int DEPTH, bool PACKED>
+template <typename VT, int SIGMA, bool NT, int DEPTH>
 __global__ void __launch_bounds__(HOT_BLOCK)
-k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__ val, const VT *__restrict__ x,
-             const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc, VT *__restrict__ P,
-             VT *__restrict__ lead, HotParams hp)
+k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict__ tile_ptr,
+             const uint32_t *__restrict__ tile_desc, VT *__restrict__ P, VT *__restrict__ lead, HotParams hp)
 {
     static_assert(num_packet_of(SIGMA) == 1, "a hot child keeps one descriptor packet");
     using word_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
@@ -107,18 +102,17 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
     const int xcd = blockIdx.x % NUM_XCD, wg = blockIdx.x / NUM_XCD, nwg = gridDim.x / NUM_XCD;
     const int lane = threadIdx.x & (OMEGA - 1), wave = threadIdx.x >> 6;
     VT *seg = reinterpret_cast<VT *>(smem + (size_t)hp.capacity * sizeof(VT) + (size_t)wave * HOT_WAVE_LDS);
-    // Cold gathers.  PACKED: from the cold region of the permuted copy of x (hp.xp: [slabs][capacity] table images, then
-    // every slab's cold columns in descending order of use -- k_x_permute), so that the part of x a slab gathers from is
-    // dense and its popular prefix stays in the XCD's L2; otherwise from x itself.
-    const VT *xcold = PACKED ? static_cast<const VT *>(hp.xp) + (size_t)hp.slabs * hp.capacity : x;
-    const int xcold_bytes = PACKED ? hp.cold_total * (int)sizeof(VT) : g.n * (int)sizeof(VT);
-    const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(xcold), (short)0, xcold_bytes, 0x00020000);
+    // Cold gathers come from the cold region of the permuted copy of x (hp.xp: [slabs][capacity] table images, then every
+    // slab's cold columns in descending order of use -- k_x_permute), so that the part of x a slab gathers from is dense and
+    // its popular prefix stays in the XCD's L2.
+    const VT *xcold = static_cast<const VT *>(hp.xp) + (size_t)hp.slabs * hp.capacity;
+    const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(xcold), (short)0, hp.cold_total * (int)sizeof(VT), 0x00020000);
 
     for (int r = 0; r < hp.rounds; r++) {
         const int k = hp.tile0[hp.slabs + 1 + xcd * hp.rounds + r];
         const int nhot = hp.count[k];
         __syncthreads(); // every wavefront is done with the previous slab's table
-        if constexpr (PACKED) {
+        {
             // the slab's table image is one contiguous run of the permuted copy: a coalesced copy
             const VT *img = static_cast<const VT *>(hp.xp) + (size_t)k * hp.capacity;
             for (int j0 = 0; j0 < nhot; j0 += HOT_BLOCK * 8) {
@@ -130,29 +124,6 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
                 }
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
-                    if (j < nhot)
-                        hot[j] = j ? xw[q] : (VT)0; // slot 0 = +0.0: what the cold lanes read
-                }
-            }
-        } else {
-            const int32_t *hc = hp.cols + (size_t)k * hp.capacity;
-            // Refill in batches of 16 slots per thread: all column words first (coalesced), then all gathers, then the
-            // LDS writes -- two memory round trips per batch instead of two dependent ones per slot.
-            for (int j0 = 0; j0 < nhot; j0 += HOT_BLOCK * 16) {
-                int32_t cw[16];
-                VT xw[16];
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
-                    cw[q] = hc[j < nhot ? j : 0]; // (unconditional load at a clamped index: a select on the LOADED value compiles to
-                                                  //  sixteen branches with a full wait each)
-                }
-#pragma unroll
-                for (int q = 0; q < 16; q++)
-                    xw[q] = x[(uint32_t)cw[q]];
-#pragma unroll
-                for (int q = 0; q < 16; q++) {
                     const int j = j0 + q * HOT_BLOCK + (int)threadIdx.x;
                     if (j < nhot)
                         hot[j] = j ? xw[q] : (VT)0; // slot 0 = +0.0: what the cold lanes read
@@ -196,14 +167,14 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
             return __builtin_bit_cast(word_t, hot[cw < 0 ? (unsigned)cw & 0x7FFFFFFFu : 0u]);
         };
 
-        // PACKED: the 3-byte codes of tile t -> gather words (bit 31 | slot, or the index into the cold region of the
+        // the 3-byte codes of tile t -> gather words (bit 31 | slot, or the index into the cold region of the
         // permuted copy: start of the element's slab + its column's rank there).  The element's slab is this slab, except
         // behind the slab's end inside its last tile (the elements there belong to the following slab(s)).  A quarter fewer
         // column bytes and two wide loads instead of eight; the decode is a shift, an or and an add per element.
-        const long long own_end = PACKED ? (long long)hp.slab_off[k + 1] : 0;
-        const int32_t own_base = PACKED ? hp.cold_base[k] : 0;
-        auto decode = [&](TileRegs<VT, SIGMA, PACKED> &tr, int t) {
-            if constexpr (PACKED) {
+        const long long own_end = (long long)hp.slab_off[k + 1];
+        const int32_t own_base = hp.cold_base[k];
+        auto decode = [&](TileRegs<VT, SIGMA> &tr, int t) {
+            {
                 constexpr int T = OMEGA * SIGMA;
                 const long long first = (long long)t * T;
                 uint32_t code[SIGMA];
@@ -229,7 +200,7 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
         };
 
         // ---- one tile whose loads (streams in `tr`, cold gathers in `xg`) are in flight or done -------------------------
-        auto compute = [&](const TileRegs<VT, SIGMA, PACKED> &tr, const word_t (&xg)[SIGMA]) {
+        auto compute = [&](const TileRegs<VT, SIGMA> &tr, const word_t (&xg)[SIGMA]) {
             VT mx[SIGMA];
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
@@ -353,12 +324,12 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
             open.is_lead = false;
         };
 
-        auto load = [&](TileRegs<VT, SIGMA, PACKED> &tr, int t) {
-            range_load<VT, SIGMA, NT, PACKED>(tr, col, hp.col_lo, hp.col_hi, val, tile_desc, tile_ptr, t, lane);
+        auto load = [&](TileRegs<VT, SIGMA> &tr, int t) {
+            range_load<VT, SIGMA, NT>(tr, hp.col_lo, hp.col_hi, val, tile_desc, tile_ptr, t, lane);
         };
         if constexpr (DEPTH == 1) {
             for (int t = tb; t < te; t++) {
-                TileRegs<VT, SIGMA, PACKED> a;
+                TileRegs<VT, SIGMA> a;
                 word_t xa[SIGMA];
                 load(a, t);
                 __builtin_amdgcn_sched_barrier(0);
@@ -377,7 +348,7 @@ k_spmv_range(Geometry g, const int32_t *__restrict__ col, const VT *__restrict__
             // tile is peeled: a `break` in the middle of the pair loop leaves the compiler a path on which the second set's loads are
             // still pending at the loop head, and it then drains the whole queue (s_waitcnt vmcnt(0)) in front of
             // every pair's gathers.
-            TileRegs<VT, SIGMA, PACKED> a, b;
+            TileRegs<VT, SIGMA> a, b;
             word_t xa[SIGMA];
             load(a, tb);
             int t = tb;
@@ -463,18 +434,24 @@ k_range_heads(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__
     }
     __threadfence_block();
     __syncthreads();
-    uint32_t fill[33]; // (nranges <= 64 * 512)
-    int nf = 0;
-    for (int R = threadIdx.x; R <= nranges; R += 1024, nf++) {
-        uint32_t w = head[R];
-        for (int R2 = R + 1; w == 0xFFFFFFFFu && R2 <= nranges; R2++)
-            w = head[R2];
-        fill[nf] = w == 0xFFFFFFFFu ? RANGE_NONE : w;
+    // ranges without tiles (0xFFFFFFFF), from the top down, 1024 at a time: everything above the chunk is final, and a word
+    // of the chunk that a neighbour is filling at this moment is either still empty (skipped) or already what this thread
+    // is looking for
+    for (int base = (nranges / 1024) * 1024; base >= 0; base -= 1024) {
+        const int R = base + (int)threadIdx.x;
+        if (R <= nranges && head[R] == 0xFFFFFFFFu) {
+            uint32_t w = 0xFFFFFFFFu;
+            for (int R2 = R + 1; w == 0xFFFFFFFFu && R2 <= nranges; R2++)
+                w = __hip_atomic_load(&head[R2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (w != 0xFFFFFFFFu)
+                __hip_atomic_store(&head[R], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __threadfence_block();
+        __syncthreads();
     }
-    __syncthreads();
-    nf = 0;
-    for (int R = threadIdx.x; R <= nranges; R += 1024, nf++)
-        head[R] = fill[nf];
+    for (int R = threadIdx.x; R <= nranges; R += 1024) // (only the ranges behind the last tile are still empty)
+        if (head[R] == 0xFFFFFFFFu)
+            head[R] = RANGE_NONE;
 }
 
 template <typename VT>
@@ -625,14 +602,14 @@ hipError_t launch_x_permute(const DeviceArrays &d, int value_type, const void *x
 }
 
 // ---- dispatch ----------------------------------------------------------------------------------------------------------
-template <typename VT, int SIGMA, bool NT, bool PACKED>
+template <typename VT, int SIGMA, bool NT>
 static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const void *x, void *y, hipStream_t s)
 {
-    HotParams hp{d.hot_slabs, d.hot_slabs / NUM_XCD, d.hot_capacity, d.hot_cols, d.hot_count, d.hot_tile0,
-                 d.col_lo,    d.col_hi,               d.slab_off,     d.xperm,    d.cold_base,  d.cold_total};
+    HotParams hp{d.hot_slabs, d.hot_slabs / NUM_XCD, d.hot_capacity, d.hot_count, d.hot_tile0, d.col_lo,
+                 d.col_hi,    d.slab_off,             d.xperm,        d.cold_base, d.cold_total};
     const size_t lds = (size_t)d.hot_capacity * sizeof(VT) + (size_t)HOT_WAVES * HOT_WAVE_LDS;
     constexpr int DEPTH = CSR5_HOT_DEPTH;
-    auto kern = k_spmv_range<VT, SIGMA, NT, DEPTH, PACKED>;
+    auto kern = k_spmv_range<VT, SIGMA, NT, DEPTH>;
     // the LDS limit of this instantiation is raised once per device and size, not on every SpMV (a host-side driver call
     // in front of a launch of a few hundred microseconds; `lds` depends only on the table capacity and the value type)
     static int lds_set[64]; // [device]: the size the attribute was last set to (0 = never)
@@ -648,8 +625,8 @@ static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const v
             lds_set[dev] = (int)lds;
     }
     if (g.p > 1) {
-        hipLaunchKernelGGL(kern, dim3(NUM_XCD * HOT_WGS_PER_XCD), dim3(HOT_BLOCK), lds, s, g, d.col, (const VT *)d.val,
-                           (const VT *)x, d.tile_ptr, d.tile_desc, (VT *)y, (VT *)d.range_lead, hp);
+        hipLaunchKernelGGL(kern, dim3(NUM_XCD * HOT_WGS_PER_XCD), dim3(HOT_BLOCK), lds, s, g, (const VT *)d.val, d.tile_ptr,
+                           d.tile_desc, (VT *)y, (VT *)d.range_lead, hp);
         e = hipGetLastError();
         if (e != hipSuccess)
             return e;
@@ -671,32 +648,21 @@ hipError_t launch_range_heads(const Geometry &g, const DeviceArrays &d, hipStrea
     return hipGetLastError();
 }
 
-// packed column codes exist only for child sigmas that are multiples of four (whole dwords of col_lo / col_hi per lane)
-template <typename VT, int S>
-static hipError_t launch_range_packed(const Geometry &g, const DeviceArrays &d, const void *x, void *y, bool nt, hipStream_t s)
-{
-    if constexpr (S % 4 == 0) {
-        if (d.col_lo)
-            return nt ? launch_range<VT, S, true, true>(g, d, x, y, s) : launch_range<VT, S, false, true>(g, d, x, y, s);
-    }
-    if (d.col_lo)
-        return hipErrorInvalidValue;
-    return nt ? launch_range<VT, S, true, false>(g, d, x, y, s) : launch_range<VT, S, false, false>(g, d, x, y, s);
-}
-
+// a hot child is converted at sigma = hot_child_sigma(): 8 for fp64, 16 for fp32 (whole dwords of column codes per lane,
+// a tile's segments fit the y-compaction region)
 template <typename VT>
 static hipError_t launch_range_sigma(const Geometry &g, const DeviceArrays &d, const void *x, void *y, bool nt, hipStream_t s)
 {
+    if (!d.col_lo || !d.xperm)
+        return hipErrorInvalidValue;
     switch (g.sigma) {
 #define CSR5_HOT_CASE(S)                                                                                               \
     case S:                                                                                                            \
         if constexpr ((size_t)OMEGA * S * sizeof(VT) <= (size_t)HOT_WAVE_LDS)                                          \
-            return launch_range_packed<VT, S>(g, d, x, y, nt, s);                                                     \
+            return nt ? launch_range<VT, S, true>(g, d, x, y, s) : launch_range<VT, S, false>(g, d, x, y, s);         \
         else                                                                                                           \
             return hipErrorInvalidValue;
-        CSR5_HOT_CASE(4) CSR5_HOT_CASE(5) CSR5_HOT_CASE(6) CSR5_HOT_CASE(7) CSR5_HOT_CASE(8) CSR5_HOT_CASE(9)
-        CSR5_HOT_CASE(10) CSR5_HOT_CASE(11) CSR5_HOT_CASE(12) CSR5_HOT_CASE(13) CSR5_HOT_CASE(14) CSR5_HOT_CASE(15)
-        CSR5_HOT_CASE(16)
+        CSR5_HOT_CASE(8) CSR5_HOT_CASE(16)
 #undef CSR5_HOT_CASE
     default: return hipErrorInvalidValue;
     }

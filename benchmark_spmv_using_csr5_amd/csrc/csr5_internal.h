@@ -77,8 +77,7 @@ struct DeviceArrays {
     int hot_slabs, hot_capacity;
     void *range_lead;          // [hot_slabs * HOT_RANGES_PER_SLAB] of vT: leading partial of every wavefront range (csr5_hot.hip)
     uint32_t *range_head;      // [hot_slabs * HOT_RANGES_PER_SLAB + 1] first row of every range (+ the CSR tail), k_range_heads
-    // packed column codes of a hot child (k_hot_encode PACK): 3 bytes per non-zero in the child's CSR order; nullptr = the
-    // column words themselves are hot-encoded (col)
+    // packed column codes of a hot child (k_hot_encode ENC_PACK): 3 bytes per non-zero in the child's CSR order
     const uint16_t *col_lo;
     const uint8_t *col_hi;
     const int32_t *slab_off;   // [hot_slabs + 1] first child element of every slab
@@ -124,8 +123,6 @@ hipError_t slab_hot_select(int n, int nnz, int S, int bits, int shift, int capac
                            int32_t *hot_cols, int32_t *hot_count, unsigned long long *covered, hipStream_t s);
 hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacity, const uint32_t *chunk_start,
                            int32_t *hot_count, int32_t *tile0, int32_t *slab_off, hipStream_t s);
-hipError_t slab_hot_rewrite(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
-                            const void *hotmap, int32_t *col2, hipStream_t s);
 size_t slab_cold_words(int n, int S, int bits, int shift);
 hipError_t slab_cold_sort_tmp_bytes(size_t total, int slab_bits, size_t *bytes);
 hipError_t slab_hot_pack(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off, const void *hotmap,
@@ -167,11 +164,10 @@ constexpr int HOT_RANGES_PER_SLAB = HOT_WGS_PER_XCD * HOT_WAVES; // every wavefr
 // what the persistent kernel needs to know about the slabs (device arrays built by csr5_slab.hip)
 struct HotParams {
     int slabs, rounds, capacity;     // S, S / 8, table capacity in elements
-    const int32_t *cols;             // [slabs * capacity] hot column of every table slot
     const int32_t *count;            // [slabs] slots in use
     const int32_t *tile0;            // [slabs + 1] first tile owned by each slab (tile0[S] = p - 1); behind it [slabs]: the slabs of
                                      // XCD 0 (one per round), of XCD 1, ... (dealt by size at conversion)
-    // packed column codes (DeviceArrays::col_lo ...), used by the PACKED kernel variant only
+    // packed column codes (DeviceArrays::col_lo ...)
     const uint16_t *col_lo;
     const uint8_t *col_hi;
     const int32_t *slab_off;
@@ -179,13 +175,11 @@ struct HotParams {
     const int32_t *cold_base;
     int cold_total;
 };
-// child sigma of a hot slab structure: small enough for the y-compaction region (measured: the hot kernel is flat in
-// sigma between 8 and 16, R-MAT 22 320 / 324 / 329 us at 8 / 12 / 16)
-constexpr int hot_child_sigma(int parent_sigma, int value_size)
-{
-    const int cap = HOT_WAVE_LDS / (OMEGA * value_size);
-    return parent_sigma < cap ? parent_sigma : cap;
-}
+// sigma of a hot slab child: a tile's values fill the y-compaction region exactly (8 for fp64, 16 for fp32: multiples of four,
+// so a lane's 3-byte column codes are whole dwords), whatever the parent's sigma.  Measured: the hot kernel is flat in sigma
+// between 8 and 16 (R-MAT 22 320 / 324 / 329 us at 8 / 12 / 16) and 8 % slower at 4; a child that inherited a parent's
+// sigma of 6 or 7 (row blocks of short rows) used to fall off the packed-code path.
+constexpr int hot_child_sigma(int value_size) { return HOT_WAVE_LDS / (OMEGA * value_size); }
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s);
 // csr5_hot.hip: the slab child's SpMV when its column words are hot-encoded (persistent range kernel + finish)

@@ -810,8 +810,6 @@ k_hot_rank(int bits, int shift, int capacity, size_t G, const uint4 *__restrict_
 // used for locality only) and takes the slabs k = xcd, xcd + 8, ...; per slab it stages the slab's hot bitmap and group
 // prefixes in LDS (IN_LDS; a slab with more than ~1.1 M columns reads them from memory instead) and streams its share
 // of the slab's column words, four per lane and load.  What it does with an element depends on MODE:
-//   ENC_REWRITE  a column with a slot in its slab's table becomes 0x80000000 | slot in col2 itself (child sigmas that are
-//                not multiples of four: the SpMV kernel reads 4-byte words and gathers cold columns from x directly)
 //   ENC_MARK     marks every column that is gathered COLD (not through the table) somewhere -- one byte per column,
 //                ref[slab][local id], plain stores (all writers store 1).  Counting the cold uses exactly would take one
 //                global atomic per cold element: 91 M on R-MAT 24, 4.2 ms at the chip's 26.7 atomics per ns
@@ -827,7 +825,7 @@ k_hot_rank(int bits, int shift, int capacity, size_t G, const uint4 *__restrict_
 // following slab(s): they are cold there (that tile runs with THIS slab's table) and are counted / coded with the
 // numbering of THEIR slab.
 constexpr int ENCODE_BLOCK = 1024, ENCODE_WGS_PER_XCD = 32, ENCODE_UNROLL = 4;
-constexpr int ENC_REWRITE = 0, ENC_MARK = 1, ENC_PACK = 2;
+constexpr int ENC_MARK = 1, ENC_PACK = 2;
 template <bool IN_LDS, int MODE>
 __global__ void __launch_bounds__(ENCODE_BLOCK)
 k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *__restrict__ slab_off,
@@ -868,10 +866,6 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
         };
         auto encode = [&](int32_t c, long long pos) -> int32_t {
             const uint32_t local = slab_local((uint32_t)c, shift, bits);
-            if (MODE == ENC_REWRITE) {
-                const int slot = slot_of(local);
-                return slot >= 0 ? (int32_t)(0x80000000u | (uint32_t)slot) : c;
-            }
             const int slot = pos < own_end ? slot_of(local) : -1;
             if (slot >= 0)
                 return (int32_t)(0x800000u | (uint32_t)slot);
@@ -883,9 +877,10 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
             return (int32_t)rank_of[at];
         };
         // An element inside a tile owned by the PREVIOUS slab is gathered with that slab's table in LDS: it is that
-        // slab's business (REWRITE: it keeps its plain word).  So the slab's share starts at its first own tile.
+        // slab's business.  So the slab's share starts at its first own tile and covers its whole last tile, foreign
+        // elements included.
         const long long begin = ((long long)soff[mine] + T - 1) / T * T;
-        long long end = MODE == ENC_REWRITE ? own_end : (own_end + T - 1) / T * T; // else: the whole last tile, foreign elements included
+        long long end = (own_end + T - 1) / T * T;
         end = end < last ? end : last;
         if (begin >= end)
             continue;
@@ -915,17 +910,11 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
                         const uint32_t a = (uint32_t)v[u].x, b = (uint32_t)v[u].y, c = (uint32_t)v[u].z, d = (uint32_t)v[u].w;
                         lo4[q] = make_uint2((a & 0xFFFFu) | (b << 16), (c & 0xFFFFu) | (d << 16));
                         hi4[q] = ((a >> 16) & 0xFFu) | (((b >> 16) & 0xFFu) << 8) | (((c >> 16) & 0xFFu) << 16) | ((d >> 16) << 24);
-                    } else if (MODE == ENC_REWRITE) {
-                        c4[q] = v[u];
                     }
                 }
             }
         }
-        // (MARK / PACK: begin and end are multiples of the tile size, nothing is left over)
-        if (MODE == ENC_REWRITE && j == 0 && (long long)threadIdx.x < end - begin - quads * 4) {
-            const long long pos = begin + quads * 4 + threadIdx.x;
-            col2[pos] = encode(col2[pos], pos);
-        }
+        // (begin and end are multiples of the tile size, nothing is left over)
     }
 }
 
@@ -1153,8 +1142,8 @@ hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacit
     return hipGetLastError();
 }
 
-// mode ENC_REWRITE: col2 is rewritten in place; ENC_MARK: ref[slab][local id] = 1 for cold uses; ENC_PACK: 3-byte codes into
-// col_lo / col_hi, cold columns coded by rank_of; col2 is only read by the last two
+// mode ENC_MARK: ref[slab][local id] = 1 for cold uses; ENC_PACK: 3-byte codes into col_lo / col_hi, cold columns coded by
+// rank_of; col2 is only read
 static hipError_t hot_encode_pass(int mode, int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
                                   const void *hotmap, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint8_t *ref,
                                   const uint32_t *rank_of, hipStream_t s)
@@ -1177,17 +1166,9 @@ static hipError_t hot_encode_pass(int mode, int n, int nnz, int T, int p, int S,
                            col_lo, col_hi, ref, rank_of, L);
         return hipGetLastError();
     };
-    switch (mode) {
-    case ENC_REWRITE: return in_lds ? launch(k_hot_encode<true, ENC_REWRITE>) : launch(k_hot_encode<false, ENC_REWRITE>);
-    case ENC_MARK: return in_lds ? launch(k_hot_encode<true, ENC_MARK>) : launch(k_hot_encode<false, ENC_MARK>);
-    default: return in_lds ? launch(k_hot_encode<true, ENC_PACK>) : launch(k_hot_encode<false, ENC_PACK>);
-    }
-}
-
-hipError_t slab_hot_rewrite(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
-                            const void *hotmap, int32_t *col2, hipStream_t s)
-{
-    return hot_encode_pass(ENC_REWRITE, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, nullptr, nullptr, nullptr, nullptr, s);
+    if (mode == ENC_MARK)
+        return in_lds ? launch(k_hot_encode<true, ENC_MARK>) : launch(k_hot_encode<false, ENC_MARK>);
+    return in_lds ? launch(k_hot_encode<true, ENC_PACK>) : launch(k_hot_encode<false, ENC_PACK>);
 }
 
 // scratch of slab_hot_pack: marks (1 byte), ranks, sort keys in and out, sorted sources (S L entries each) + the sort's own

@@ -2,7 +2,7 @@
 """Resource table of the SpMV kernels from hipcc's own -Rpass-analysis=kernel-resource-usage remarks.
 
     python scripts/kernel_resources.py [--filter k_spmv] [--sigmas few|all] > profiles/rNN_resources.md
-Compiles csr5_spmv.hip (and csr5_slab.hip) for gfx950 with the remark pass on and prints, per kernel instantiation,
+Compiles csr5_spmv.hip, csr5_slab.hip and csr5_hot.hip for gfx950 with the remark pass on and prints, per kernel instantiation,
 VGPRs / SGPRs / scratch / LDS / occupancy in waves per SIMD.  Runs without a GPU."""
 import argparse
 import os
@@ -21,13 +21,13 @@ def demangle(names):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--filter", default="k_spmv|k_slab|k_calibrate")
+    ap.add_argument("--filter", default="k_spmv|k_slab|k_calibrate|k_range|k_x_permute")
     ap.add_argument("--sigmas", default="few")
     ap.add_argument("--match", default=None, help="regex on the demangled name")
     args = ap.parse_args()
     rows = []
     for src, defs in (("csr5_spmv.hip", ["-DCSR5_SPMV_ONLY_F64"]), ("csr5_spmv.hip", ["-DCSR5_SPMV_ONLY_F32"]),
-                      ("csr5_slab.hip", [])):
+                      ("csr5_slab.hip", []), ("csr5_hot.hip", [])):
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
                f"-I{ROOT}/include", "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src),
                "-o", "/dev/null"] + defs + (["-DCSR5_FEW_SIGMAS"] if args.sigmas == "few" else [])
