@@ -858,10 +858,7 @@ static int build_slabs_impl(csr5hip_handle h)
         // Column use counts come from a sample of the non-zeros (one 64-element chunk in `stride`): ~4 M samples are
         // plenty to rank columns, and a full count serialises on the very columns it is looking for.
         stride = (int)(g.nnz / (4LL * 1024 * 1024));
-        int stride_cap = 64;
-        if (const char *e = getenv("CSR5_EXPERIMENT_STRIDE_CAP"))
-            stride_cap = atoi(e);
-        stride = stride < 1 ? 1 : (stride > stride_cap ? stride_cap : stride); // (R-MAT 24: 1/64 ranks as well as 1/32, 1/128 costs 1.5 % of the SpMV)
+        stride = stride < 1 ? 1 : (stride > 64 ? 64 : stride); // (R-MAT 24: 1/64 ranks as well as 1/32 -- also the cold regions, round 4: 1/16 and 1/8 leave the L2 misses at 30.8 M and cost 0.7 / 1.8 ms of conversion --, 1/128 costs 1.5 % of the SpMV)
         // A slot is staged by each of the 32 workgroups of the slab's XCD in every SpMV (a coalesced copy out of the
         // permuted x: about what two cold gathers cost), so a column must be used a few times per SpMV to earn one -- and
         // the sample must have seen it twice to say so.  16 uses: with 48 (round 3) a row block of R-MAT 24 -- its columns
