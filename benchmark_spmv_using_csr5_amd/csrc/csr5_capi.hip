@@ -257,6 +257,7 @@ int csr5hip_set_stream(csr5hip_handle h, void *hip_stream)
     if (!h)
         return CSR5HIP_INVALID_ARGUMENT;
     h->stream = (hipStream_t)hip_stream;
+    h->xperm_valid = false; // (snapshot mode: the copy was taken on the old stream; the new one takes its own, in order)
     h->drop_graphs();
     return CSR5HIP_SUCCESS;
 }

@@ -20,3 +20,9 @@ for scale, S in ((22, 8), (24, 16), (20, 8)):
     if S == 16:
         pair = cnt.reshape(8, 2).sum(1)
         print("   per XCD (2 consecutive slabs): max/mean = %.3f" % (pair.max() / pair.mean()))
+        # what the library does (csr5_capi.hip build_slabs): longest slab first onto the XCD with the least work that has a round free
+        load, used = [0] * 8, [0] * 8
+        for k in sorted(range(S), key=lambda k: -cnt[k]):
+            x = min((x for x in range(8) if used[x] < 2), key=lambda x: load[x])
+            load[x] += int(cnt[k]); used[x] += 1
+        print("   per XCD (dealt longest first): max/mean = %.4f  min/mean = %.4f" % (max(load) / (sum(load) / 8), min(load) / (sum(load) / 8)))
