@@ -806,12 +806,9 @@ static int build_slabs_impl(csr5hip_handle h)
                  o_thr = take((size_t)S_alloc * 8);
     // ranking of the cold columns behind the packed codes (slab_hot_pack): counts / ranks, sort keys in and out, sources
     size_t cold_words = 0, cold_sort_bytes = 0;
-    int bits_first = 0;
-    while ((1 << bits_first) < S)
-        bits_first++;
-    if (hot) {
-        cold_words = slab_cold_words(g.n, S, bits_first, h->slab_shift);
-        HIP_TRY(slab_cold_sort_tmp_bytes(cold_words, bits_first, &cold_sort_bytes));
+    if (hot) { // (S keeps this value while the table stays in use: bits_s = log2 S)
+        cold_words = slab_cold_words(g.n, S, bits_s, h->slab_shift);
+        HIP_TRY(slab_cold_sort_tmp_bytes(cold_words, bits_s, &cold_sort_bytes));
     }
     const size_t o_ref = take(cold_words), o_rank = take(cold_words * 4), o_keys = take(cold_words * 4), o_keys2 = take(cold_words * 4),
                  o_src = take(cold_words * 4), o_sort = take(cold_sort_bytes);
@@ -853,9 +850,7 @@ static int build_slabs_impl(csr5hip_handle h)
     // decides the slab count -- without a table fewer slabs are better, and the partition below then runs once.
     int stride = 1;
     if (hot) {
-        int bits_hot = 0;
-        while ((1 << bits_hot) < S)
-            bits_hot++;
+        const int bits_hot = bits_s;
         // Column use counts come from a sample of the non-zeros (one 64-element chunk in `stride`): ~4 M samples are
         // plenty to rank columns, and a full count serialises on the very columns it is looking for.
         stride = (int)(g.nnz / (4LL * 1024 * 1024));
