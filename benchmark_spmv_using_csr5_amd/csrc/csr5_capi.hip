@@ -1019,6 +1019,15 @@ static hipError_t ensure_x_snapshot(csr5hip_handle h, hipStream_t s)
 {
     if (!h->x_snapshot || h->xperm_valid || h->slab_S <= 0 || !h->slab_child->hot_enabled)
         return hipSuccess;
+    // a caller capturing its own graph gets the copy recorded with every spmv() (enqueue_spmv: the copy is not there yet
+    // while the graph is only being built)
+    if (s != nullptr) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cap) != hipSuccess)
+            (void)hipGetLastError(); // (the query itself failed: treat the stream as not capturing)
+        else if (cap != hipStreamCaptureStatusNone)
+            return hipSuccess;
+    }
     hipError_t e = launch_x_permute(h->slab_child->d, h->value_type, h->x, s);
     if (e == hipSuccess)
         h->xperm_valid = true;

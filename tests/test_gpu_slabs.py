@@ -420,6 +420,26 @@ def test_permuted_x_live_and_snapshot(oracle):
         check(1, "snapshot, setX after overwrite, graph replay")
         assert A.spmv(1.0, y) == 0
         check(1, "snapshot, eager call after the graph")
+        # a caller capturing spmv() into a graph of its own (torch's capture on a side stream): the copy is recorded with the
+        # SpMV, so the replay is right even though nothing ran while the graph was being built
+        side = torch.cuda.Stream(device=DEV)
+        assert A.setStream(side) == 0
+        xd.mul_(2)
+        torch.cuda.synchronize()
+        assert A.setX(xd) == 0
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                assert A.spmv(1.0, y) == 0
+        y.zero_()
+        graph.replay()
+        check(2, "snapshot, caller-captured graph")
+        xd.div_(2)
+        torch.cuda.synchronize()
+        assert A.setStream(torch.cuda.current_stream(DEV)) == 0 and A.setX(xd) == 0
+        assert A.spmv(1.0, y) == 0
+        check(1, "snapshot, back on the current stream")
+        del graph
         # conversion cycle keeps working and restores the caller's arrays
         assert A.asCSR() == 0 and A.asCSR5() == 0
         assert A.spmv(1.0, y) == 0
