@@ -750,7 +750,7 @@ static int build_slabs_impl(csr5hip_handle h)
     const bool auto_count = h->slab_request == 1;
     int S_plain = auto_count ? slab_count_without_table(h) : S; // the count if the table is not used
 
-    // LDS hot table for the persistent kernel (fused mode, S a multiple of the 8 XCDs, register budget of 16 waves/CU)?
+    // LDS hot table for the persistent kernel (fused mode, S a multiple of the 8 XCDs)?
     const int hot_sigma = hot_child_sigma((int)h->vsize());
     const int hot_T = OMEGA * hot_sigma;
     const int hot_p = (int)(((long long)g.nnz + hot_T - 1) / hot_T);

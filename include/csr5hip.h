@@ -73,8 +73,8 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       0 = off, 1 = auto (default), 2/4/8/16/32/64 = that many slabs */
 #define CSR5HIP_OPT_SLAB_SHIFT  7  /* log2 of the number of adjacent columns hashed to the same slab (default 4 =
                                       one 128-byte line of fp64 x) */
-#define CSR5HIP_OPT_SLAB_HOT    9  /* column slabs only: keep each slab's most used columns of x in a 128-KB LDS table of a
-                                      persistent kernel (power-law inputs put most non-zeros on few columns): 0 = off,
+#define CSR5HIP_OPT_SLAB_HOT    9  /* column slabs only: keep each slab's most used columns of x (16 384 fp64 / 32 768 fp32) in a 128-KB
+                                      LDS table of a persistent kernel (power-law inputs put most non-zeros on few columns): 0 = off,
                                       1 = auto (default: on when the table covers >= 25 % of the non-zeros), 2 = force */
 #define CSR5HIP_OPT_ZERO_EMPTY_ROWS 8 /* 1 = spmv() also stores 0 into rows without non-zeros (so y is fully defined
                                       without the caller zeroing it -- what a solver that feeds y back as x needs);
