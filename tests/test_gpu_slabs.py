@@ -448,3 +448,24 @@ def test_permuted_x_live_and_snapshot(oracle):
         torch.cuda.synchronize()
         assert np.array_equal(ci.cpu().numpy(), mat.col)
         A.close()
+
+
+def test_hot_table_refused_when_a_slab_exceeds_the_code_width(oracle):
+    """A packed column code has 23 bits for a slab-local column: a matrix whose slabs would hold more columns gets no hot
+    table (forced or not) and runs the plain slab path -- same exact result."""
+    rng = np.random.default_rng(5)
+    m, n, S = 3000, (1 << 23) * 8 + 4096, 8  # 8 slabs of 2^23 + 512 columns
+    lens = rng.integers(0, 40, size=m)
+    row_ptr = np.zeros(m + 1, dtype=np.int64)
+    row_ptr[1:] = np.cumsum(lens)
+    nnz = int(row_ptr[-1])
+    col = np.concatenate([np.sort(rng.integers(0, n, size=l)) for l in lens]).astype(np.int32)
+    mat = M.CsrMatrix(m, n, row_ptr.astype(np.int32), col, np.zeros(nnz), "wide")
+    val = rng.integers(0, 10, size=nnz).astype(np.float64)
+    x = rng.integers(0, 10, size=n).astype(np.float64)
+    info = {}
+    arrays, col_t, val_t, ys = _run(mat, val, x, 8, H.SPMV_FUSED, slabs=S, hot=2, info_out=info)
+    assert info["column_slabs"] == S and info["slab_hot"] == 0
+    ref = oracle.csr_spmv(m, mat.row_ptr, mat.col, val, x)
+    has = lens > 0
+    assert np.array_equal(ys[0][has], ref[has])
