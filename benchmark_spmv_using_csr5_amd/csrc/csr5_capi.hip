@@ -454,7 +454,8 @@ static int reserve_aux(csr5hip_handle h)
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
     const size_t p1 = (size_t)g.p + 1;
-    const size_t desc_words = (size_t)(g.p > 0 ? g.p : 1) * OMEGA * g.num_packet;
+    // (a hot slab child keeps no descriptor array: see build_format_arrays)
+    const size_t desc_words = h->is_child && h->hot_enabled ? OMEGA : (size_t)(g.p > 0 ? g.p : 1) * OMEGA * g.num_packet;
     const size_t offset_cap = h->is_child ? p1 : (size_t)g.m + p1; // (a slab child has no empty rows)
     h->scan_tmp_bytes = offset_scan_tmp_bytes((int)p1);
     size_t off = 0;
@@ -556,6 +557,10 @@ static int build_format_arrays(csr5hip_handle h)
     hipStream_t s = h->stream;
     // step 1: tile_ptr (+ empty-row marks) -- flag scatter shares the row pass
     HIP_TRY(launch_row_scan(g, h->d, s));
+    // A hot slab child needs nothing else: its bit flags ride in the packed column codes, the range kernel recomputes
+    // y_offset from them, and it has no empty rows (no offsets).  (k_tile_desc on the 40 M-row child of R-MAT 24: 0.4 ms.)
+    if (h->is_child && h->hot_enabled)
+        return CSR5HIP_SUCCESS;
 
     // step 2: tile_desc, offset_ptr scan, empty-row offsets (the kernel leaves unflagged tiles at once)
     HIP_TRY(launch_tile_desc(g, h->d, s));
@@ -754,13 +759,13 @@ static int build_slabs_impl(csr5hip_handle h)
     const int hot_sigma = hot_child_sigma((int)h->vsize());
     const int hot_T = OMEGA * hot_sigma;
     const int hot_p = (int)(((long long)g.nnz + hot_T - 1) / hot_T);
-    // (a slab-local column id -- and with it a cold rank -- must fit the 23 bits of a packed column code)
+    // (a slab-local column id -- and with it a cold rank -- must fit the 22 bits a packed column code has for it)
     int bits_s = 0;
     while ((1 << bits_s) < S)
         bits_s++;
     bool hot = h->hot_request != 0 && S % NUM_XCD == 0 && h->opt.mode == 1 && hot_sigma >= 4 && hot_p >= 2 &&
                (long long)g.n * (long long)h->vsize() <= 0x7FFFFFFFLL &&
-               slab_local_columns(g.n, bits_s, h->slab_shift) <= ((size_t)1 << 23);
+               slab_local_columns(g.n, bits_s, h->slab_shift) <= ((size_t)1 << 22);
     int hot_capacity = 0;
     if (hot) {
         int dev = 0, lds_max = 0;
@@ -947,7 +952,7 @@ static int build_slabs_impl(csr5hip_handle h)
             HIP_TRY(h->b_xperm.reserve(((size_t)S * hot_capacity + cold_cap + 1) * h->vsize()));
             HIP_TRY(hipMemsetAsync(tb + o_ref, 0, cold_words, s));
             HIP_TRY(slab_hot_pack(g.n, g.nnz, hot_T, hot_p, S, bits, h->slab_shift, (const int32_t *)h->b_slab_off.ptr, ht.hotmap,
-                                  (const uint32_t *)ht.cnt, (int32_t *)h->b_col2.ptr, (uint16_t *)h->b_col_lo.ptr,
+                                  (const uint32_t *)ht.cnt, (const uint32_t *)t.key, (int32_t *)h->b_col2.ptr, (uint16_t *)h->b_col_lo.ptr,
                                   (uint8_t *)h->b_col_hi.ptr, (uint8_t *)(tb + o_ref), (uint32_t *)(tb + o_rank),
                                   (uint32_t *)(tb + o_keys), (uint32_t *)(tb + o_keys2),
                                   (uint32_t *)(tb + o_src), tb + o_sort, cold_sort_bytes, (int32_t *)h->b_cold_base.ptr,

@@ -31,7 +31,8 @@ struct TileRegs {
     int32_t c[SIGMA];
     uint32_t plo[SIGMA / 2], phi[SIGMA / 4];
     VT v[SIGMA];
-    uint32_t w0, tp0, tp1;
+    uint32_t flags; // bit 31 - i = element i starts a row (bit 22 of its column code; set by decode)
+    uint32_t tp0, tp1;
 };
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -53,20 +54,18 @@ __device__ __forceinline__ void load_dwords(uint32_t *dst, const uint32_t *p)
     }
 }
 
-// every load of tile t: column words first (the gathers wait for them only), then the descriptor word, the tile_ptr
-// pair (scalar) and the values
+// every load of tile t: column codes first (the gathers wait for them only; they carry the tile's bit flags too: the
+// descriptor array of the reference format is not read), then the tile_ptr pair (scalar) and the values
 template <typename VT, int SIGMA, bool NT>
 __device__ __forceinline__ void range_load(TileRegs<VT, SIGMA> &r, const uint16_t *__restrict__ col_lo,
                                            const uint8_t *__restrict__ col_hi, const VT *__restrict__ val,
-                                           const uint32_t *__restrict__ tile_desc, const uint32_t *__restrict__ tile_ptr, int t,
-                                           int lane)
+                                           const uint32_t *__restrict__ tile_ptr, int t, int lane)
 {
     constexpr int T = OMEGA * SIGMA;
     const VT *vt = val + (size_t)t * T + lane;
     const size_t first = (size_t)t * T + (size_t)lane * SIGMA;
     load_dwords<SIGMA / 2, NT>(r.plo, reinterpret_cast<const uint32_t *>(col_lo + first));
     load_dwords<SIGMA / 4, NT>(r.phi, reinterpret_cast<const uint32_t *>(col_hi + first));
-    r.w0 = tile_desc[(size_t)t * OMEGA + lane];
     {
         // the tile_ptr pair is wave-uniform: through the scalar cache (constant address space -> s_load_dwordx2, requested
         // one tile ahead like the streams), which keeps it off the vector memory path -- the unit this kernel saturates
@@ -89,12 +88,11 @@ struct OpenRow {
 
 template <typename VT, int SIGMA, bool NT, int DEPTH>
 __global__ void __launch_bounds__(HOT_BLOCK)
-k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict__ tile_ptr,
-             const uint32_t *__restrict__ tile_desc, VT *__restrict__ P, VT *__restrict__ lead, HotParams hp)
+k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict__ tile_ptr, VT *__restrict__ P,
+             VT *__restrict__ lead, HotParams hp)
 {
     static_assert(num_packet_of(SIGMA) == 1, "a hot child keeps one descriptor packet");
     using word_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
-    constexpr int bit_y = bit_y_of(SIGMA), bit_all = bit_y + BIT_SS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // typed LDS pointer: keeps the table reads on ds_read (a generic pointer would merge the hot/cold select into one
     // flat_load)
@@ -178,13 +176,18 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
                 constexpr int T = OMEGA * SIGMA;
                 const long long first = (long long)t * T;
                 uint32_t code[SIGMA];
+                uint32_t fl = 0;
 #pragma unroll
-                for (int i = 0; i < SIGMA; i++)
+                for (int i = 0; i < SIGMA; i++) {
                     code[i] = ((tr.plo[i / 2] >> (16 * (i & 1))) & 0xFFFFu) | (((tr.phi[i / 4] >> (8 * (i & 3))) & 0xFFu) << 16);
+                    fl |= ((code[i] >> 22) & 1u) << (31 - i); // the element starts a row (the reference's bit flag)
+                    code[i] &= 0xBFFFFFu;
+                }
+                tr.flags = fl;
                 if (first + T <= own_end) { // (wave-uniform) straight-line: this code sits in front of the tile's gathers
 #pragma unroll
                     for (int i = 0; i < SIGMA; i++)
-                        tr.c[i] = (code[i] & 0x800000u) ? (int32_t)(0x80000000u | (code[i] & 0x7FFFFFu))
+                        tr.c[i] = (code[i] & 0x800000u) ? (int32_t)(0x80000000u | (code[i] & 0x3FFFFFu))
                                                         : (int32_t)code[i] + own_base;
                 } else { // the slab ends inside this tile (one tile per slab)
 #pragma unroll
@@ -193,7 +196,7 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
                         int32_t base = own_base;
                         for (int j = k + 1; j < hp.slabs; j++)
                             base = pos >= (long long)hp.slab_off[j] ? hp.cold_base[j] : base;
-                        tr.c[i] = (code[i] & 0x800000u) ? (int32_t)(0x80000000u | (code[i] & 0x7FFFFFu)) : (int32_t)code[i] + base;
+                        tr.c[i] = (code[i] & 0x800000u) ? (int32_t)(0x80000000u | (code[i] & 0x3FFFFFu)) : (int32_t)code[i] + base;
                     }
                 }
             }
@@ -206,13 +209,25 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
             for (int i = 0; i < SIGMA; i++)
                 mx[i] = __builtin_bit_cast(VT, (word_t)(xg[i] | table_word(tr.c[i])));
             const uint32_t tp0 = __builtin_amdgcn_readfirstlane(tr.tp0), tp1 = __builtin_amdgcn_readfirstlane(tr.tp1);
-            const uint32_t w0 = tr.w0;
             const int rs = (int)(tp0 & ROW_MASK);
-            // decode before any data-dependent branch (loads consumed only inside a branch get sunk into it)
-            const uint32_t flags = w0 << bit_all; // element i -> bit 31-i
-            int y_off = (int)(w0 >> (32 - bit_y));
+            const uint32_t flags = tr.flags; // element i -> bit 31-i
             const bool f0 = (flags >> 31) | (lane == 0);
             const bool present = f0 | ((flags & 0x7FFFFFFFu) != 0);
+            // y_offset of the reference's descriptor (format_cuda.h:161-267, our k_tile_desc), recomputed from the flags instead
+            // of loaded: segments that start in the lane, exclusive wave prefix, minus one for lanes > 0
+            int y_off;
+            {
+                const int stop = __builtin_popcount(flags & 0x7FFFFFFFu);
+                int segn = stop - (f0 ? 0 : 1) + (present ? 1 : 0);
+                segn = segn > 0 ? segn : 0;
+                int incl = segn;
+#pragma unroll
+                for (int d_ = 1; d_ < OMEGA; d_ <<= 1) {
+                    const int up = __shfl_up(incl, d_, OMEGA);
+                    incl += lane >= d_ ? up : 0;
+                }
+                y_off = lane ? incl - segn - 1 : 0;
+            }
             if (open.row < 0)
                 open.row = rs; // first tile of the range
             if (rs != open.row) {
@@ -325,7 +340,7 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
         };
 
         auto load = [&](TileRegs<VT, SIGMA> &tr, int t) {
-            range_load<VT, SIGMA, NT>(tr, hp.col_lo, hp.col_hi, val, tile_desc, tile_ptr, t, lane);
+            range_load<VT, SIGMA, NT>(tr, hp.col_lo, hp.col_hi, val, tile_ptr, t, lane);
         };
         if constexpr (DEPTH == 1) {
             for (int t = tb; t < te; t++) {
@@ -625,8 +640,8 @@ static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const v
             lds_set[dev] = (int)lds;
     }
     if (g.p > 1) {
-        hipLaunchKernelGGL(kern, dim3(NUM_XCD * HOT_WGS_PER_XCD), dim3(HOT_BLOCK), lds, s, g, (const VT *)d.val, d.tile_ptr,
-                           d.tile_desc, (VT *)y, (VT *)d.range_lead, hp);
+        hipLaunchKernelGGL(kern, dim3(NUM_XCD * HOT_WGS_PER_XCD), dim3(HOT_BLOCK), lds, s, g, (const VT *)d.val, d.tile_ptr, (VT *)y,
+                           (VT *)d.range_lead, hp);
         e = hipGetLastError();
         if (e != hipSuccess)
             return e;

@@ -126,7 +126,7 @@ hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacit
 size_t slab_cold_words(int n, int S, int bits, int shift);
 hipError_t slab_cold_sort_tmp_bytes(size_t total, int slab_bits, size_t *bytes);
 hipError_t slab_hot_pack(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off, const void *hotmap,
-                         const uint32_t *cnt, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint8_t *ref, uint32_t *rank_of,
+                         const uint32_t *cnt, const uint32_t *key2, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint8_t *ref, uint32_t *rank_of,
                          uint32_t *keys, uint32_t *keys_sorted, uint32_t *src_sorted, void *sort_tmp, size_t sort_tmp_bytes,
                          int32_t *cold_base, int32_t *cold_cols, hipStream_t s);
 size_t slab_local_columns(int n, int bits, int shift); // columns of one slab (slab-local ids 0 .. this - 1)

@@ -817,9 +817,10 @@ k_hot_rank(int bits, int shift, int capacity, size_t G, const uint4 *__restrict_
 //                selection instead and only needs to know WHICH columns to rank
 //   ENC_PACK     every column word of the tiles 0 .. p-2 is written as a 24-bit code -- low 16 bits to col_lo, high 8 bits
 //                to col_hi, both in the child's CSR order, which is already the order lane l of k_spmv_range wants (its
-//                sigma elements are consecutive there): bit 23 = table slot in bits 0..13, else the RANK of the column in
-//                its slab's frequency order (rank_of[slab][local id], < 2^23) = its index in the slab's cold region of
-//                the permuted copy of x (csr5_hot.hip).  3 bytes per non-zero instead of 4 in the SpMV's streams; col2
+//                sigma elements are consecutive there): bit 23 = table slot in bits 0..14, else the RANK of the column in
+//                its slab's frequency order (rank_of[slab][local id], < 2^22) = its index in the slab's cold region of
+//                the permuted copy of x (csr5_hot.hip); bit 22 = the element starts a row of the child (the bit flag of the
+//                reference's descriptor, from the segment keys).  3 bytes per non-zero instead of 4 in the SpMV's streams; col2
 //                stays plain (the CSR tail tile reads it).
 // A tile belongs to the slab of its first element.  Elements behind the slab's end inside its last tile belong to the
 // following slab(s): they are cold there (that tile runs with THIS slab's table) and are counted / coded with the
@@ -831,7 +832,7 @@ __global__ void __launch_bounds__(ENCODE_BLOCK)
 k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *__restrict__ slab_off,
              const uint4 *__restrict__ hotbits, const uint16_t *__restrict__ hotpre, size_t G, int32_t *__restrict__ col2,
              uint16_t *__restrict__ col_lo, uint8_t *__restrict__ col_hi, uint8_t *__restrict__ ref,
-             const uint32_t *__restrict__ rank_of, size_t L)
+             const uint32_t *__restrict__ rank_of, size_t L, const uint32_t *__restrict__ key)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint4 *lbits = reinterpret_cast<uint4 *>(smem);
@@ -907,7 +908,12 @@ k_hot_encode(int nnz, int T, int p, int S, int bits, int shift, const int32_t *_
                     v[u].z = encode(v[u].z, pos + 2);
                     v[u].w = encode(v[u].w, pos + 3);
                     if (MODE == ENC_PACK) {
-                        const uint32_t a = (uint32_t)v[u].x, b = (uint32_t)v[u].y, c = (uint32_t)v[u].z, d = (uint32_t)v[u].w;
+                        // bit 22 = the element starts a row of the child (a segment): the reference format's bit flag,
+                        // carried by the code so that the SpMV kernel does not read the descriptor array
+                        uint32_t k4[4];
+                        const unsigned st = segment_starts4(key, pos, (long long)nnz, k4);
+                        const uint32_t a = (uint32_t)v[u].x | ((st & 1u) << 22), b = (uint32_t)v[u].y | (((st >> 1) & 1u) << 22),
+                                       c = (uint32_t)v[u].z | (((st >> 2) & 1u) << 22), d = (uint32_t)v[u].w | (((st >> 3) & 1u) << 22);
                         lo4[q] = make_uint2((a & 0xFFFFu) | (b << 16), (c & 0xFFFFu) | (d << 16));
                         hi4[q] = ((a >> 16) & 0xFFu) | (((b >> 16) & 0xFFu) << 8) | (((c >> 16) & 0xFFu) << 16) | ((d >> 16) << 24);
                     }
@@ -1146,7 +1152,7 @@ hipError_t slab_hot_finish(int S, int p_hist, int p, int T, int nnz, int capacit
 // rank_of; col2 is only read
 static hipError_t hot_encode_pass(int mode, int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off,
                                   const void *hotmap, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint8_t *ref,
-                                  const uint32_t *rank_of, hipStream_t s)
+                                  const uint32_t *rank_of, const uint32_t *key, hipStream_t s)
 {
     const size_t G = slab_hot_groups(n, shift, bits);
     const size_t L = slab_local_count(n, shift, bits);
@@ -1163,7 +1169,7 @@ static hipError_t hot_encode_pass(int mode, int n, int nnz, int T, int p, int S,
                 return e;
         }
         hipLaunchKernelGGL(kern, grid, block, in_lds ? lds : 0, s, nnz, T, p, S, bits, shift, slab_off, hotbits, hotpre, G, col2,
-                           col_lo, col_hi, ref, rank_of, L);
+                           col_lo, col_hi, ref, rank_of, L, key);
         return hipGetLastError();
     };
     if (mode == ENC_MARK)
@@ -1185,12 +1191,12 @@ hipError_t slab_cold_sort_tmp_bytes(size_t total, int slab_bits, size_t *bytes)
 // every cold entry, in the order of the permuted copy of x) and writes the 3-byte codes.  words = slab_cold_words();
 // ref: `words` bytes, zeroed by the caller; rank_of .. src_sorted: `words` uint32 each.
 hipError_t slab_hot_pack(int n, int nnz, int T, int p, int S, int bits, int shift, const int32_t *slab_off, const void *hotmap,
-                         const uint32_t *cnt, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint8_t *ref, uint32_t *rank_of,
+                         const uint32_t *cnt, const uint32_t *key2, int32_t *col2, uint16_t *col_lo, uint8_t *col_hi, uint8_t *ref, uint32_t *rank_of,
                          uint32_t *keys, uint32_t *keys_sorted, uint32_t *src_sorted, void *sort_tmp, size_t sort_tmp_bytes,
                          int32_t *cold_base, int32_t *cold_cols, hipStream_t s)
 {
     const size_t L = slab_local_count(n, shift, bits), total = (size_t)S * L;
-    hipError_t e = hot_encode_pass(ENC_MARK, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, nullptr, nullptr, ref, nullptr, s);
+    hipError_t e = hot_encode_pass(ENC_MARK, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, nullptr, nullptr, ref, nullptr, nullptr, s);
     if (e != hipSuccess)
         return e;
     const unsigned blocks = (unsigned)((total + SLAB_BLOCK - 1) / SLAB_BLOCK);
@@ -1204,7 +1210,7 @@ hipError_t slab_hot_pack(int n, int nnz, int T, int p, int S, int bits, int shif
     e = hipGetLastError();
     if (e != hipSuccess)
         return e;
-    return hot_encode_pass(ENC_PACK, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, col_lo, col_hi, nullptr, rank_of, s);
+    return hot_encode_pass(ENC_PACK, n, nnz, T, p, S, bits, shift, slab_off, hotmap, col2, col_lo, col_hi, nullptr, rank_of, key2, s);
 }
 
 size_t slab_local_columns(int n, int bits, int shift) { return slab_local_count(n, shift, bits); }
