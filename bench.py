@@ -592,6 +592,27 @@ def main():
                                       "(a caller may overwrite x between spmv() calls without calling setX again); the "
                                       "headline uses the reference CLI's protocol -- setX once, then the timed loop -- with "
                                       "the copy taken once per setX"}
+        if world == 1 and info.slab_hot and dtype_name == "f64" and not info.slab_values_narrowed and hasattr(prob.A, "setNarrowValues"):
+            # the same workload with CSR5HIP_OPT_NARROW_VALUES: the reference CLI's rand() % 10 values are exact in fp32, so
+            # the slab kernel may stream them as fp32 (same result bit for bit).  NOT the headline: the roofline's algorithmic
+            # bytes count the 8-byte value stream.
+            try:
+                _ck(prob.A.setNarrowValues(1), "setNarrowValues")
+                if prob.A.info().slab_values_narrowed:
+                    nsteps = max(5, steps // 4)
+                    y_before = prob.yd.clone()
+                    nwall, nev = timed(prob, nsteps, 2, args.launch, None)
+                    same = bool(torch.equal(y_before, prob.yd))
+                    nus = nev / nsteps * 1e3
+                    roof["narrowed_values"] = {
+                        "launch_us": round(nus, 3), "gflops": round(2.0 * prob.nnz / (nus * 1e-6) / 1e9, 1),
+                        "stream_bytes_per_launch": prob.b_alg - 4 * prob.nnz, "y_bit_identical_to_headline_run": same, "steps": nsteps,
+                        "frac_of_roof_on_the_bytes_it_streams": round((prob.b_alg - 4 * prob.nnz) / (nus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "opt-in CSR5HIP_OPT_NARROW_VALUES = 1 (library default 0): every value of this matrix is exactly "
+                                "representable in fp32, the hot child's value stream is kept as fp32 and widened in registers"}
+                _ck(prob.A.setNarrowValues(0), "setNarrowValues")
+            except Exception as exc:  # an older library under CSR5HIP_LIB
+                roof["narrowed_values"] = {"error": str(exc)}
         part = ("whole matrix on one GPU" if world == 1 else
                 f"{scaling} scaling, {'row blocks of ONE matrix balanced by nnz + 2 * rows' if scaling == 'strong' else 'one fixed-size row block per GPU'}, "
                 "x replicated by one RCCL broadcast, no per-step collective")

@@ -38,6 +38,7 @@ OPT_ZERO_EMPTY_ROWS = 8
 OPT_SLAB_HOT = 9
 OPT_SLAB_MEMORY_MIB = 10
 OPT_X_SNAPSHOT = 11
+OPT_NARROW_VALUES = 12
 MULTI_OPT_ROW_WEIGHT = 100  # csr5hip_multi_set_option only (before input_csr)
 MULTI_OPT_OWN_REPLICAS = 101  # csr5hip_multi_set_option only (before set_x): devices[0]'s shards read a broadcast replica too
 
@@ -59,6 +60,7 @@ class Csr5Info(C.Structure):
         ("slab_hot", C.c_int), ("slab_hot_cover_pct", C.c_int), ("slab_fallback", C.c_int),
         ("device_bytes", C.c_longlong),
         ("slab_x_permuted", C.c_int), ("slab_cold_entries", C.c_int), ("x_snapshot", C.c_int),
+        ("slab_values_narrowed", C.c_int),
     ]
 
 

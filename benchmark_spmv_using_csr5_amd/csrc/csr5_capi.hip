@@ -131,9 +131,9 @@ struct csr5hip_handle_s {
     int slab_m2 = 0;
     double t_slab = 0;
     csr5hip_handle_s *slab_child = nullptr;
-    Buffer b_row_ptr2, b_col2, b_val2, b_P, b_rowidx, b_base, b_nonempty;
+    Buffer b_row_ptr2, b_col2, b_val2, b_val32, b_P, b_rowidx, b_base, b_nonempty;
     Buffer b_slab_tmp; // temporaries of the slab build; kept between conversions only while small (SLAB_TMP_KEEP)
-    // LDS hot table of the slab child (k_spmv_hot): chosen at conversion, see csr5_slab.hip
+    // LDS hot table of the slab child (k_spmv_range): chosen at conversion, see csr5_slab.hip
     int hot_request = 1;      // CSR5HIP_OPT_SLAB_HOT: 0 off, 1 auto, 2 force
     bool hot_enabled = false; // (child) its columns are hot-encoded as packed codes next to the plain column words (only the values
                               // are transposed): spmv must use the persistent range kernel
@@ -143,6 +143,8 @@ struct csr5hip_handle_s {
     // permuted copy of x behind the packed codes (csr5_hot.hip k_x_permute): table images + frequency-ordered cold regions
     Buffer b_cold_base, b_cold_cols, b_xperm;
     int x_snapshot = 0;    // CSR5HIP_OPT_X_SNAPSHOT: 0 = the copy is refreshed by every spmv(), 1 = by setX only
+    int narrow_request = 0; // CSR5HIP_OPT_NARROW_VALUES: 1 = keep the hot child's fp64 values as fp32 when every one of them is exact
+    bool values_narrowed = false;
     bool xperm_valid = false; // (snapshot mode) the copy holds the current x
     int cold_total = 0;       // entries of the cold region
 
@@ -403,6 +405,17 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         h->x_snapshot = value;
         h->xperm_valid = false;
         break;
+    case CSR5HIP_OPT_NARROW_VALUES:
+        if (value != 0 && value != 1)
+            return CSR5HIP_INVALID_ARGUMENT;
+        if (h->narrow_request != value) {
+            h->narrow_request = value;
+            if (h->format == CSR5HIP_FORMAT_CSR5) {
+                h->drop_graphs();
+                return build_slabs(h);
+            }
+        }
+        break;
     case CSR5HIP_OPT_SLAB_MEMORY_MIB:
         if (value < 0)
             return CSR5HIP_INVALID_ARGUMENT;
@@ -653,7 +666,8 @@ static void release_slabs(csr5hip_handle h)
         csr5hip_free(h->slab_child);
         h->slab_child = nullptr;
     }
-    for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty, &h->b_col_lo, &h->b_col_hi, &h->b_hot_cols,
+    h->values_narrowed = false;
+    for (Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_val32, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty, &h->b_col_lo, &h->b_col_hi, &h->b_hot_cols,
                       &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_range_head, &h->b_slab_tmp, &h->b_cold_base, &h->b_cold_cols,
                       &h->b_xperm})
         b->release();
@@ -827,6 +841,8 @@ static int build_slabs_impl(csr5hip_handle h)
         const unsigned long long child_tiles = (unsigned long long)g.nnz / ((unsigned long long)OMEGA * (hot ? hot_sigma : g.sigma)) + 2;
         unsigned long long need = (unsigned long long)g.nnz * (4 + h->vsize() + (hot ? 3 : 0)) + off + seg_max * (h->vsize() + 5) +
                                   slab_base_words(g.m, S_alloc) * 4ull + (unsigned long long)g.m / 8 + child_tiles * 300ull;
+        if (hot && h->narrow_request && h->value_type == CSR5HIP_F64)
+            need += (unsigned long long)g.nnz * 4ull; // the fp32 copy of the child's values
         if (hot)
             need += (unsigned long long)S * hot_capacity * (4 + h->vsize()) + (unsigned long long)S * HOT_RANGES_PER_SLAB * (h->vsize() + 4) +
                     std::min<unsigned long long>(cold_words, (unsigned long long)g.nnz) * (4 + h->vsize());
@@ -1007,6 +1023,32 @@ static int build_slabs_impl(csr5hip_handle h)
             e = hipStreamSynchronize(s);
         if (e != hipSuccess)
             rc = fail_hip(e, "k_range_heads");
+    }
+    h->values_narrowed = false;
+    c->d.val32 = nullptr;
+    if (rc == CSR5HIP_SUCCESS && hot && h->narrow_request && h->value_type == CSR5HIP_F64 && g.nnz > 0) {
+        // CSR5HIP_OPT_NARROW_VALUES: when every value is exactly representable in fp32 the range kernel streams them as fp32
+        // (converted back in registers: the same products, bit for bit); the fp64 array stays for the CSR tail and asCSR
+        unsigned *flag = c->d.counters + 5;
+        unsigned inexact = 1;
+        hipError_t e = launch_fp32_exact((const double *)c->d.val, (size_t)g.nnz, flag, s);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(&inexact, flag, sizeof(inexact), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(s);
+        if (e == hipSuccess && !inexact) {
+            e = h->b_val32.reserve((size_t)g.nnz * sizeof(float));
+            if (e == hipSuccess)
+                e = launch_narrow((const double *)c->d.val, (size_t)g.nnz, (float *)h->b_val32.ptr, s);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(s);
+            if (e == hipSuccess) {
+                c->d.val32 = (const float *)h->b_val32.ptr;
+                h->values_narrowed = true;
+            }
+        }
+        if (e != hipSuccess)
+            rc = fail_hip(e, "narrow values");
     }
     if (rc != CSR5HIP_SUCCESS) {
         release_slabs(h);
@@ -1541,8 +1583,9 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_x_permuted = h->slab_S > 0 && h->slab_child->hot_enabled ? 1 : 0;
     info->slab_cold_entries = info->slab_x_permuted ? h->cold_total : 0;
     info->x_snapshot = h->x_snapshot;
+    info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
     long long bytes = (long long)h->b_arena.cap;
-    for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
+    for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_val32, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
                             &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_range_head, &h->b_slab_tmp,
                             &h->b_col_lo, &h->b_col_hi, &h->b_cold_base, &h->b_cold_cols, &h->b_xperm})
         bytes += (long long)b->cap;

@@ -1,11 +1,11 @@
-// csr5_hot.hip -- the persistent kernel of the column-slab child with an LDS hot table (csr5_slab.hip), round 3.
+// csr5_hot.hip -- the persistent kernel of the column-slab child with an LDS hot table (csr5_slab.hip), rounds 3-4.
 //
 // What it computes is the reference's tile kernel (CSR5_cuda/detail/cuda/csr5_spmv_cuda.h:59-311: fast / normal track,
 // lane-local flag walk, cross-lane segmented sum) on the child's CSR5 arrays; how the work is laid out is ours:
 //   * one workgroup of HOT_WAVES wavefronts per CU stays resident; XCD x walks its slabs in order, refilling the LDS table
 //     with the slab's hot x entries (hot gathers = ds_read_b64, cold ones = range-checked buffer loads from the permuted
 //     copy of x);
-//   * every WAVEFRONT owns ONE CONTIGUOUS RANGE of the slab's tiles (512 ranges per slab).  The row that is open at a
+//   * every WAVEFRONT owns ONE CONTIGUOUS RANGE of the slab's tiles (HOT_RANGES_PER_SLAB = 256 ranges per slab).  The row that is open at a
 //     tile boundary therefore meets its continuation in the registers of the same wavefront: a tile needs no header,
 //     no re-read of its successor's first elements, no carry slot and no atomic -- the reference's calibrate pass
 //     (csr5_spmv_cuda.h:313-382) shrinks to ONE leading partial per range (`lead`), added by k_range_finish;
@@ -25,12 +25,14 @@ constexpr int HOT_BLOCK = HOT_WAVES * OMEGA;
 // The child's column words come as 3-byte codes (k_hot_encode ENC_PACK) in CSR order -- lane l's sigma codes are
 // consecutive: 2 sigma bytes of col_lo, sigma bytes of col_hi (whole dwords: the child's sigma is a multiple of four) --
 // and are decoded into c[] when they have arrived.
-template <typename VT, int SIGMA>
+// ST = the type the values are STORED in (VT, or float for an fp64 matrix whose values are all exactly representable in fp32:
+// CSR5HIP_OPT_NARROW_VALUES -- half the value stream, the same products bit for bit)
+template <typename ST, int SIGMA>
 struct TileRegs {
     static_assert(SIGMA % 4 == 0, "a lane's column codes are whole dwords");
     int32_t c[SIGMA];
     uint32_t plo[SIGMA / 2], phi[SIGMA / 4];
-    VT v[SIGMA];
+    ST v[SIGMA];
     uint32_t flags; // bit 31 - i = element i starts a row (bit 22 of its column code; set by decode)
     uint32_t tp0, tp1;
 };
@@ -86,12 +88,12 @@ struct OpenRow {
     bool is_lead; // the row was already open when the range began: the partial goes to lead[range], not to P
 };
 
-template <typename VT, int SIGMA, bool NT, int DEPTH>
+template <typename VT, int SIGMA, bool NT, int DEPTH, typename ST = VT>
 __global__ void __launch_bounds__(HOT_BLOCK)
-k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict__ tile_ptr, VT *__restrict__ P,
+k_spmv_range(Geometry g, const ST *__restrict__ val, const uint32_t *__restrict__ tile_ptr, VT *__restrict__ P,
              VT *__restrict__ lead, HotParams hp)
 {
-    static_assert(num_packet_of(SIGMA) == 1, "a hot child keeps one descriptor packet");
+    static_assert(num_packet_of(SIGMA) == 1, "the bit flags of a hot child's tile fit one word per lane");
     using word_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // typed LDS pointer: keeps the table reads on ds_read (a generic pointer would merge the hot/cold select into one
@@ -171,7 +173,7 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
         // column bytes and two wide loads instead of eight; the decode is a shift, an or and an add per element.
         const long long own_end = (long long)hp.slab_off[k + 1];
         const int32_t own_base = hp.cold_base[k];
-        auto decode = [&](TileRegs<VT, SIGMA> &tr, int t) {
+        auto decode = [&](TileRegs<ST, SIGMA> &tr, int t) {
             {
                 constexpr int T = OMEGA * SIGMA;
                 const long long first = (long long)t * T;
@@ -203,7 +205,7 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
         };
 
         // ---- one tile whose loads (streams in `tr`, cold gathers in `xg`) are in flight or done -------------------------
-        auto compute = [&](const TileRegs<VT, SIGMA> &tr, const word_t (&xg)[SIGMA]) {
+        auto compute = [&](const TileRegs<ST, SIGMA> &tr, const word_t (&xg)[SIGMA]) {
             VT mx[SIGMA];
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
@@ -242,13 +244,13 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
                 VT s = 0;
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++)
-                    s = __builtin_fma(tr.v[i], mx[i], s);
+                    s = __builtin_fma((VT)tr.v[i], mx[i], s);
                 open.val += wave_sum(s);
                 return;
             }
             const unsigned long long pmask = __ballot(present);
             bool direct = f0 && lane != 0;
-            VT sum = tr.v[0] * mx[0];
+            VT sum = (VT)tr.v[0] * mx[0];
             VT first_sum = 0;
 #pragma unroll
             for (int i = 1; i < SIGMA; i++) {
@@ -261,7 +263,7 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
                     direct = true;
                     sum = 0;
                 }
-                sum = __builtin_fma(tr.v[i], mx[i], sum);
+                sum = __builtin_fma((VT)tr.v[i], mx[i], sum);
             }
             if (!direct)
                 first_sum = sum;
@@ -339,12 +341,12 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
             open.is_lead = false;
         };
 
-        auto load = [&](TileRegs<VT, SIGMA> &tr, int t) {
-            range_load<VT, SIGMA, NT>(tr, hp.col_lo, hp.col_hi, val, tile_ptr, t, lane);
+        auto load = [&](TileRegs<ST, SIGMA> &tr, int t) {
+            range_load<ST, SIGMA, NT>(tr, hp.col_lo, hp.col_hi, val, tile_ptr, t, lane);
         };
         if constexpr (DEPTH == 1) {
             for (int t = tb; t < te; t++) {
-                TileRegs<VT, SIGMA> a;
+                TileRegs<ST, SIGMA> a;
                 word_t xa[SIGMA];
                 load(a, t);
                 __builtin_amdgcn_sched_barrier(0);
@@ -363,7 +365,7 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
             // tile is peeled: a `break` in the middle of the pair loop leaves the compiler a path on which the second set's loads are
             // still pending at the loop head, and it then drains the whole queue (s_waitcnt vmcnt(0)) in front of
             // every pair's gathers.
-            TileRegs<VT, SIGMA> a, b;
+            TileRegs<ST, SIGMA> a, b;
             word_t xa[SIGMA];
             load(a, tb);
             int t = tb;
@@ -414,7 +416,7 @@ k_spmv_range(Geometry g, const VT *__restrict__ val, const uint32_t *__restrict_
 //   known at conversion (k_range_heads: `head`, one word per range, non-decreasing), so the thread of the FIRST range of a
 //   row finds the end of the row's run with one look at its neighbour (the usual case: the run is this range alone) or a
 //   bisection of `head`, and adds the run's leads with independent loads; a run longer than RUN_WAVE ranges (a dense
-//   row covers all 512 ranges of every slab) is summed by the whole wavefront.
+//   row covers all 256 ranges of every slab) is summed by the whole wavefront.
 constexpr uint32_t RANGE_EXACT = 0x80000000u; // head bit: the range's first row BEGINS with the range's first element
 constexpr uint32_t RANGE_NONE = 0x7FFFFFFFu;  // head row of the (empty) ranges behind the last tile
 constexpr int RUN_WAVE = 64;
@@ -616,15 +618,57 @@ hipError_t launch_x_permute(const DeviceArrays &d, int value_type, const void *x
     return hipGetLastError();
 }
 
+// ---- CSR5HIP_OPT_NARROW_VALUES: an fp64 value stream kept as fp32 when that loses nothing ----------------------------------
+// *flag |= 1 if some value is not exactly representable as a NORMAL fp32 number (or +-0, +-inf); NaNs fail the test too
+__global__ void __launch_bounds__(256) k_fp32_exact(const double *__restrict__ v, size_t n, unsigned *__restrict__ flag)
+{
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const double a = v[i];
+        const float f = (float)a;
+        const double mag = a < 0 ? -a : a;
+        bad |= !((double)f == a) || (mag != 0.0 && mag < 1.17549435082228750797e-38);
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & (OMEGA - 1)) == 0)
+        *flag = 1u;
+}
+__global__ void __launch_bounds__(256) k_narrow(const double *__restrict__ v, size_t n, float *__restrict__ o)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        o[i] = (float)v[i];
+}
+hipError_t launch_fp32_exact(const double *v, size_t n, unsigned *flag, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(unsigned), s);
+    if (e != hipSuccess || n == 0)
+        return e;
+    const size_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(k_fp32_exact, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, v, n, flag);
+    return hipGetLastError();
+}
+hipError_t launch_narrow(const double *v, size_t n, float *o, hipStream_t s)
+{
+    if (n == 0)
+        return hipSuccess;
+    const size_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(k_narrow, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, v, n, o);
+    return hipGetLastError();
+}
+
 // ---- dispatch ----------------------------------------------------------------------------------------------------------
-template <typename VT, int SIGMA, bool NT>
+template <typename VT, int SIGMA, bool NT, typename ST = VT>
 static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const void *x, void *y, hipStream_t s)
 {
     HotParams hp{d.hot_slabs, d.hot_slabs / NUM_XCD, d.hot_capacity, d.hot_count, d.hot_tile0, d.col_lo,
                  d.col_hi,    d.slab_off,             d.xperm,        d.cold_base, d.cold_total};
     const size_t lds = (size_t)d.hot_capacity * sizeof(VT) + (size_t)HOT_WAVES * HOT_WAVE_LDS;
     constexpr int DEPTH = CSR5_HOT_DEPTH;
-    auto kern = k_spmv_range<VT, SIGMA, NT, DEPTH>;
+    if constexpr (std::is_same<VT, double>::value && std::is_same<ST, double>::value) {
+        if (d.val32) // the child's values are kept as fp32 (every one of them exactly): the instantiation that streams 4-byte values
+            return launch_range<VT, SIGMA, NT, float>(g, d, x, y, s);
+    }
+    auto kern = k_spmv_range<VT, SIGMA, NT, DEPTH, ST>;
+    const ST *val = std::is_same<ST, VT>::value ? (const ST *)d.val : (const ST *)d.val32;
     // the LDS limit of this instantiation is raised once per device and size, not on every SpMV (a host-side driver call
     // in front of a launch of a few hundred microseconds; `lds` depends only on the table capacity and the value type)
     static int lds_set[64]; // [device]: the size the attribute was last set to (0 = never)
@@ -640,7 +684,7 @@ static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const v
             lds_set[dev] = (int)lds;
     }
     if (g.p > 1) {
-        hipLaunchKernelGGL(kern, dim3(NUM_XCD * HOT_WGS_PER_XCD), dim3(HOT_BLOCK), lds, s, g, (const VT *)d.val, d.tile_ptr, (VT *)y,
+        hipLaunchKernelGGL(kern, dim3(NUM_XCD * HOT_WGS_PER_XCD), dim3(HOT_BLOCK), lds, s, g, val, d.tile_ptr, (VT *)y,
                            (VT *)d.range_lead, hp);
         e = hipGetLastError();
         if (e != hipSuccess)

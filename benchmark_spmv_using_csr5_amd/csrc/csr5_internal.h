@@ -70,7 +70,7 @@ struct DeviceArrays {
     uint32_t *tile_hdr;     // [8p] fused kernel: carry_meta[t], carry_meta[t+1].x and the tile_ptr pair in ONE 32-B record
     uint32_t *counters;     // [16] conversion statistics: x-window tiles, covered non-zeros, long runs, gather lines; [4] = workgroups
                             // done; [8..15] = four 64-bit wall-clock stamps, one per conversion phase (k_row_scan, k_tile_desc, ...)
-    // column-slab child with an LDS hot table (csr5_slab.hip / k_spmv_hot): column words with bit 31 set index the table
+    // column-slab child with an LDS hot table (csr5_slab.hip / k_spmv_range): column words with bit 31 set index the table
     const int32_t *hot_cols;   // [hot_slabs * hot_capacity]
     const int32_t *hot_count;  // [hot_slabs]
     const int32_t *hot_tile0;  // [hot_slabs + 1] first tile of every slab, then [hot_slabs] the slabs each XCD walks
@@ -87,6 +87,8 @@ struct DeviceArrays {
     const int32_t *cold_base;  // [hot_slabs + 1] start of every slab's cold entries inside the cold region
     const int32_t *cold_cols;  // [cold_total] column behind every cold entry
     int cold_total;
+    // CSR5HIP_OPT_NARROW_VALUES: the hot child's values (tile order, like val) as fp32 -- every one of them exactly; else nullptr
+    const float *val32;
 };
 
 // ---- conversion (csr5_format.hip) ----
@@ -185,6 +187,8 @@ hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type,
 // csr5_hot.hip: the slab child's SpMV when its column words are hot-encoded (persistent range kernel + finish)
 hipError_t launch_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, void *y,
                            const SpmvOptions &opt, hipStream_t s);
+hipError_t launch_fp32_exact(const double *v, size_t n, unsigned *flag, hipStream_t s);
+hipError_t launch_narrow(const double *v, size_t n, float *o, hipStream_t s);
 hipError_t launch_range_heads(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 // the permuted copy of x behind the packed codes of a hot child: xperm[i] = x[hot_cols[i]] for the table images,
 // xperm[slabs * capacity + i] = x[cold_cols[i]] for the cold region

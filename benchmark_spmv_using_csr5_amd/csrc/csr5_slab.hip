@@ -522,7 +522,7 @@ k_slab_combine(int m, int tail_start, int zero_empty, int m2, const uint32_t *__
     }
 }
 
-// ---- hot columns of every slab (LDS table of the persistent kernel k_spmv_hot, csr5_spmv.hip) ---------------------
+// ---- hot columns of every slab (LDS table of the persistent kernel k_spmv_range, csr5_hot.hip) ---------------------
 // Power-law inputs concentrate their non-zeros on few columns: the HOT_CAPACITY most used columns of a slab (those
 // used at least `min_count` times -- a table entry is staged once per workgroup and SpMV, so a rarely used column
 // would cost more than it saves) get a slot in the slab's table and their column words are rewritten to

@@ -88,6 +88,8 @@ static int call_anonymouslib_multi(const std::vector<int> &devs, int m, int n, i
     // this program writes x once and never again: the library may keep its private copy of x between spmv() calls
     // (CSR5_X_SNAPSHOT=0 restores the library default, a copy per spmv())
     A.setOption(CSR5HIP_OPT_X_SNAPSHOT, getenv("CSR5_X_SNAPSHOT") ? atoi(getenv("CSR5_X_SNAPSHOT")) : 1);
+    if (const char *narrow = getenv("CSR5_NARROW_VALUES")) // opt-in: fp32-exact fp64 values streamed as fp32 (csr5hip.h)
+        A.setOption(CSR5HIP_OPT_NARROW_VALUES, atoi(narrow));
     anonymouslib_timer asCSR5_timer;
     asCSR5_timer.start();
     err = A.asCSR5();
@@ -207,6 +209,8 @@ static int call_anonymouslib(int m, int n, int nnzA, int *csrRowPtrA, int *csrCo
     // this program writes x once and never again ("you only need to do it once!", CSR5_cuda/main.cu:63): the library may
     // keep its private copy of x between spmv() calls (CSR5_X_SNAPSHOT=0 restores the library default, a copy per spmv())
     A.setOption(CSR5HIP_OPT_X_SNAPSHOT, getenv("CSR5_X_SNAPSHOT") ? atoi(getenv("CSR5_X_SNAPSHOT")) : 1);
+    if (const char *narrow = getenv("CSR5_NARROW_VALUES")) // opt-in: fp32-exact fp64 values streamed as fp32 (csr5hip.h)
+        A.setOption(CSR5HIP_OPT_NARROW_VALUES, atoi(narrow));
 
     A.warmup();
     if (tune) { // measured sigma selection (not in the reference): try every candidate, keep the fastest

@@ -151,6 +151,11 @@ class anonymouslibHandle:
         reference CLI does: CSR5_cuda/main.cu:63); csr5hip.h CSR5HIP_OPT_X_SNAPSHOT"""
         return self.setOption(_capi.OPT_X_SNAPSHOT, int(value))
 
+    def setNarrowValues(self, value: int) -> int:
+        """fp64 + hot table: 1 = stream the values as fp32 when every one of them is exactly representable (same results bit
+        for bit, 4 bytes less per non-zero); 0 (default) = off; csr5hip.h CSR5HIP_OPT_NARROW_VALUES"""
+        return self.setOption(_capi.OPT_NARROW_VALUES, int(value))
+
     def setZeroEmptyRows(self, value: int) -> int:
         """1 = spmv() also stores 0 into rows without non-zeros (solver coupling); 0 = reference behaviour"""
         return self.setOption(_capi.OPT_ZERO_EMPTY_ROWS, int(value))

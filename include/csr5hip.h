@@ -99,6 +99,14 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                           reference CLI does (CSR5_cuda/main.cu:63 "you only need to do it once!", then
                                           NUM_RUN spmv() calls on the same x).  Call setX() again, with the same pointer,
                                           after writing to x.  Handles without a hot table ignore the option. */
+#define CSR5HIP_OPT_NARROW_VALUES 12 /* fp64 matrices with an LDS hot table: 1 = when EVERY value of the matrix is exactly
+                                      representable as a (normal) fp32 number -- integer weights, 0/1 adjacency, the
+                                      reference CLI's rand() % 10 data (CSR5_cuda/main.cu:229-233) -- the slab kernel
+                                      streams the values as fp32 and widens them in registers: 4 bytes less per non-zero,
+                                      the same products and sums bit for bit (checked on the device at conversion; any
+                                      other matrix keeps its fp64 stream).  0 (default) = off: the value stream is the
+                                      8-byte one the roofline's algorithmic bytes count.  csr5hip_info.slab_values_narrowed
+                                      says what happened.  +4 bytes per non-zero of device memory. */
 
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
@@ -138,6 +146,7 @@ typedef struct csr5hip_info {
     int slab_x_permuted;           /* 1 = the slab kernel gathers from the permuted copy of x (CSR5HIP_OPT_X_SNAPSHOT)   */
     int slab_cold_entries;         /* entries of that copy behind the table images (columns gathered from memory)        */
     int x_snapshot;                /* CSR5HIP_OPT_X_SNAPSHOT as set                                                      */
+    int slab_values_narrowed;      /* 1 = CSR5HIP_OPT_NARROW_VALUES took effect: the slab kernel streams fp32 values       */
 } csr5hip_info;
 
 /* anonymouslibHandle(m, n) -- anonymouslib_cuda.h:15.  Uses the current HIP device. */

@@ -469,3 +469,72 @@ def test_hot_table_refused_when_a_slab_exceeds_the_code_width(oracle):
     ref = oracle.csr_spmv(m, mat.row_ptr, mat.col, val, x)
     has = lens > 0
     assert np.array_equal(ys[0][has], ref[has])
+
+
+def test_narrowed_value_stream_is_lossless(oracle):
+    """CSR5HIP_OPT_NARROW_VALUES: an fp64 matrix whose values are ALL exactly representable in fp32 has its hot child's
+    value stream kept as fp32 (widened in registers): the result is the same bit for bit as with the fp64 stream -- also on
+    non-integer data (multiples of 1/8, real x).  One inexact value, an fp32 handle or a matrix without a hot table keep the
+    fp64 stream; the option can be switched after the conversion."""
+    mat = M.rmat(15, 16, seed=5)
+    rng = np.random.default_rng(17)
+    rp = torch.from_numpy(mat.row_ptr.astype(np.int32)).to(DEV)
+    has = np.diff(mat.row_ptr) > 0
+
+    def run(val, x, narrow, hot=2, dtype=np.float64, toggle_after=False):
+        tdt = torch.float64 if dtype == np.float64 else torch.float32
+        ci = torch.from_numpy(mat.col.astype(np.int32)).to(DEV)
+        va = torch.from_numpy(val.astype(dtype)).to(DEV)
+        xd = torch.from_numpy(x.astype(dtype)).to(DEV)
+        y = torch.zeros(mat.m, dtype=tdt, device=DEV)
+        A = H.anonymouslibHandle(mat.m, mat.n, dtype=np.dtype(dtype).name)
+        assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0
+        assert A.setSigma(16) == 0 and A.setColumnSlabs(8) == 0 and A.setSlabHot(hot) == 0
+        if not toggle_after:
+            assert A.setNarrowValues(narrow) == 0
+        assert A.asCSR5() == 0
+        if toggle_after:
+            assert A.info().slab_values_narrowed == 0
+            assert A.setNarrowValues(narrow) == 0  # rebuilds the slab structure
+        info = A.info()
+        assert A.spmv(1.0, y) == 0
+        torch.cuda.synchronize()
+        first = y.cpu().numpy().copy()
+        assert A.spmv_repeat(1.0, y, 3) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(first, y.cpu().numpy())
+        # back to CSR: the caller's fp64 values are what they were
+        assert A.asCSR() == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(va.cpu().numpy(), val.astype(dtype))
+        A.destroy()
+        return first, info
+
+    # integer data (the reference CLI's): narrowed, equal to the plain run and to the oracle
+    val_i, x_i = M.fill_values(mat.nnz, mat.n, np.float64, seed=3, mode="int")
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val_i, x_i)
+    y0, i0 = run(val_i, x_i, 0)
+    y1, i1 = run(val_i, x_i, 1)
+    assert i0.slab_hot == 1 and i0.slab_values_narrowed == 0 and i1.slab_values_narrowed == 1
+    assert np.array_equal(y0[has], ref[has]) and np.array_equal(y1, y0)
+    y2, i2 = run(val_i, x_i, 1, toggle_after=True)
+    assert i2.slab_values_narrowed == 1 and np.array_equal(y2, y0)
+    # non-integer but fp32-exact values, real x: still bit-identical to the fp64 stream
+    val_q = rng.integers(-80, 81, mat.nnz).astype(np.float64) / 8.0
+    val_q[::7] *= 2.0 ** -100  # tiny but normal in fp32
+    val_q[3::11] = -0.0
+    x_r = rng.standard_normal(mat.n)
+    ya, ia = run(val_q, x_r, 0)
+    yb, ib = run(val_q, x_r, 1)
+    assert ib.slab_values_narrowed == 1 and np.array_equal(ya.view(np.uint64), yb.view(np.uint64))
+    # one value that fp32 cannot hold (or only as a denormal): the fp64 stream stays
+    for bad in (0.1, 2.0 ** -140, 1e300):
+        val_b = val_q.copy()
+        val_b[mat.nnz // 2] = bad
+        yc, ic = run(val_b, x_r, 1)
+        yd, _ = run(val_b, x_r, 0)
+        assert ic.slab_values_narrowed == 0 and np.array_equal(yc.view(np.uint64), yd.view(np.uint64))
+    # fp32 handles and handles without a hot table ignore the option
+    _, i32 = run(val_i, x_i, 1, dtype=np.float32)
+    _, inohot = run(val_i, x_i, 1, hot=0)
+    assert i32.slab_values_narrowed == 0 and inohot.slab_values_narrowed == 0

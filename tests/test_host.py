@@ -324,9 +324,12 @@ def test_new_option_keys_and_multi_handle_argument_checks():
     assert lib.csr5hip_get_info(h, C.byref(info)) == 0 and info.column_slabs == 0 and info.slab_hot == 0
     assert info.x_snapshot == 1 and info.slab_x_permuted == 0 and info.slab_cold_entries == 0
     assert lib.csr5hip_set_option(h, _capi.OPT_X_SNAPSHOT, 0) == 0
+    assert lib.csr5hip_set_option(h, _capi.OPT_NARROW_VALUES, 2) == _capi.INVALID_ARGUMENT
+    assert lib.csr5hip_set_option(h, _capi.OPT_NARROW_VALUES, 1) == 0  # (no conversion yet: only remembered)
+    assert lib.csr5hip_set_option(h, _capi.OPT_NARROW_VALUES, 0) == 0
     # the Python constants are the header's
     hdr = open(os.path.join(ROOT, "include", "csr5hip.h")).read()
-    for name, val in (("CSR5HIP_OPT_X_SNAPSHOT", _capi.OPT_X_SNAPSHOT), ("CSR5HIP_MULTI_OPT_OWN_REPLICAS", _capi.MULTI_OPT_OWN_REPLICAS),
+    for name, val in (("CSR5HIP_OPT_NARROW_VALUES", _capi.OPT_NARROW_VALUES), ("CSR5HIP_OPT_X_SNAPSHOT", _capi.OPT_X_SNAPSHOT), ("CSR5HIP_MULTI_OPT_OWN_REPLICAS", _capi.MULTI_OPT_OWN_REPLICAS),
                       ("CSR5HIP_OPT_SLAB_MEMORY_MIB", _capi.OPT_SLAB_MEMORY_MIB)):
         assert f"#define {name} {val}" in " ".join(hdr.split()), name
     assert lib.csr5hip_spmv_repeat(h, 1.0, C.c_void_p(8), 3) == _capi.UNSUPPORTED_CSR_SPMV
