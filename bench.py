@@ -123,6 +123,8 @@ def parse_args():
                     help="skip the cold-cache protocol that a cache-sized working set gets by default (profiling runs: one protocol per trace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-configs", action="store_true", help="skip the per-config array (N = 1)")
+    ap.add_argument("--no-side-figures", action="store_true",
+                    help="skip roofline.x_live / roofline.narrowed_values (profiling runs: only the headline protocol's kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -580,7 +582,7 @@ def main():
                 roof = cold_is_the_number(prob, roof, ev_per_step, ms_per_step, cold_ms, k, cs)
             else:
                 roof["cold"] = cold_dict(prob, cold_ms, k, cs)
-        if world == 1 and info.slab_x_permuted and info.x_snapshot:
+        if world == 1 and info.slab_x_permuted and info.x_snapshot and not args.no_side_figures:
             # the same workload with the library default: the permuted copy of x is re-taken by every spmv() (x read live)
             _ck(prob.A.setXSnapshot(0), "setXSnapshot")
             lsteps = max(5, steps // 4)
@@ -592,7 +594,8 @@ def main():
                                       "(a caller may overwrite x between spmv() calls without calling setX again); the "
                                       "headline uses the reference CLI's protocol -- setX once, then the timed loop -- with "
                                       "the copy taken once per setX"}
-        if world == 1 and info.slab_hot and dtype_name == "f64" and not info.slab_values_narrowed and hasattr(prob.A, "setNarrowValues"):
+        if (world == 1 and info.slab_hot and dtype_name == "f64" and not info.slab_values_narrowed and hasattr(prob.A, "setNarrowValues")
+                and not args.no_side_figures):
             # the same workload with CSR5HIP_OPT_NARROW_VALUES: the reference CLI's rand() % 10 values are exact in fp32, so
             # the slab kernel may stream them as fp32 (same result bit for bit).  NOT the headline: the roofline's algorithmic
             # bytes count the 8-byte value stream.

@@ -10,12 +10,12 @@ cd /tmp && export TMPDIR=/tmp
 run() { # tag, bench args
   tag=$1; shift
   d=/tmp/prof_$tag; rm -rf $d; mkdir -p $d
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -o t -- python $REPO/bench.py --no-cpu-baseline --no-sub-configs "$@" > $d/bench_under_rocprof.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $d/trace -o t -- python $REPO/bench.py --no-cpu-baseline --no-sub-configs --no-side-figures "$@" > $d/bench_under_rocprof.log 2>&1
   grep '"metric"' $d/bench_under_rocprof.log | tail -1 > $OUT/${tag}_bench_line.json
   cp $(find $d/trace -name "*kernel_stats.csv" | head -1) $OUT/${tag}_kernel_stats.csv 2>/dev/null
   for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
     n=$(echo $c | tr ' ' '_')
-    timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d/pmc_$n -o p -- python $REPO/bench.py --no-cpu-baseline --no-sub-configs --steps 10 --warmup 2 "$@" > $d/pmc_$n.log 2>&1
+    timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d/pmc_$n -o p -- python $REPO/bench.py --no-cpu-baseline --no-sub-configs --no-side-figures --steps 10 --warmup 2 "$@" > $d/pmc_$n.log 2>&1
   done
   python3 $REPO/scripts/profile_parse.py $tag $d $OUT
   rm -rf $d

@@ -29,7 +29,7 @@ def _device_csr(mat, val, dtype):
 
 
 def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None, nt=None,
-         slabs=None, slab_shift=None, zero_empty=None, info_out=None, hot=None, x_snapshot=None):
+         slabs=None, slab_shift=None, zero_empty=None, info_out=None, hot=None, x_snapshot=None, narrow=None):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
@@ -55,6 +55,8 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         assert A.setSlabHot(hot) == 0
     if x_snapshot is not None:
         assert A.setXSnapshot(x_snapshot) == 0
+    if narrow is not None:
+        assert A.setNarrowValues(narrow) == 0
     assert A.spmv(1.0, yd) == H.ANONYMOUSLIB_UNSUPPORTED_CSR_SPMV  # still CSR (anonymouslib_cuda.h:268-271)
     assert A.asCSR5() == 0, _capi.last_error()
     arrays = A.csr5_arrays()
@@ -498,9 +500,10 @@ def test_seeded_fuzz_against_oracle(oracle):
         slabs = int(rng.choice([2, 4, 8, 16, 32, 64])) if case % 5 in (1, 3) else 0
         hot = int(rng.choice([0, 2])) if slabs % 8 == 0 and slabs and mode == H.SPMV_FUSED else 0
         snap = (case // 5) % 2 if hot else None  # permuted copy of x per spmv (default) or per setX
+        narrow = (case // 10) % 2 if hot else None  # fp64: the (integer) values streamed as fp32; fp32 handles ignore it
         fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
         arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, dtype=dtype, xwin=xwin, ldsy=ldsy, nt=nt, repeat=2,
-                                        slabs=slabs, hot=hot, x_snapshot=snap)
+                                        slabs=slabs, hot=hot, x_snapshot=snap, narrow=narrow)
         _check_format(arrays, col_t, val_t, fmt)
         exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
         for y in ys:
