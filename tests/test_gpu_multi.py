@@ -24,7 +24,7 @@ def _devices(G):
     return [g % n for g in range(G)] if n >= 2 else [0] * G
 
 
-def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None, row_weight=None, own_replicas=False):
+def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None, row_weight=None, own_replicas=False, narrow=None):
     rp = torch.from_numpy(mat.row_ptr.astype(np.int32)).to(DEV)
     ci = torch.from_numpy(mat.col.astype(np.int32)).to(DEV)
     va = torch.from_numpy(val.astype(dtype)).to(DEV)
@@ -36,7 +36,15 @@ def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None, row_weigh
     assert A.setSigma(sigma) == 0
     if slabs is not None:
         assert A.setOption(6, slabs) == 0
+    if narrow == "before":
+        assert A.setOption(_capi.OPT_NARROW_VALUES, 1) == 0
     assert A.asCSR5() == 0
+    if narrow == "after":  # every shard rebuilds its slab structure
+        assert A.setOption(_capi.OPT_NARROW_VALUES, 1) == 0
+    if narrow is not None:
+        narrowed = [A.shard_info(g).slab_values_narrowed for g in range(G)]
+        hot = [A.shard_info(g).slab_hot for g in range(G)]
+        assert narrowed == hot, "integer data: every shard with a hot table streams fp32 values"
     if own_replicas:
         assert A.setOption(_capi.MULTI_OPT_OWN_REPLICAS, 1) == 0
     assert A.setX(xd) == 0
@@ -113,9 +121,9 @@ def test_multi_rmat20_eight_row_blocks_on_one_device(oracle):
     val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=8, mode="int")
     ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
     nonempty = np.diff(mat.row_ptr) > 0
-    for slabs in (0, 1):
-        y, cuts, nnzs, _, _ = _run_multi(mat, val, x, 8, slabs=slabs)
-        assert np.array_equal(y[nonempty], ref[nonempty]), slabs
+    for slabs, narrow in ((0, None), (1, None), (1, "before"), (8, "after")):
+        y, cuts, nnzs, _, _ = _run_multi(mat, val, x, 8, slabs=slabs, narrow=narrow)
+        assert np.array_equal(y[nonempty], ref[nonempty]), (slabs, narrow)
         cost = np.asarray(nnzs) + S.ROW_WEIGHT * np.diff(cuts)
         assert cost.max() <= 1.1 * cost.sum() / 8, "row blocks are balanced by non-zeros + ROW_WEIGHT * rows (power-law rows)"
         assert max(nnzs) <= 1.25 * mat.nnz / 8
