@@ -49,6 +49,9 @@ def main():
         ck(A.asCSR5(), "asCSR5")
         i = A.info()
         ck(A.spmv_repeat(1.0, y, 10), "spmv_repeat")
+        # the graph of the timed call (one graph per count) is captured and instantiated HERE, not inside the timed region
+        # (until round 4's last day it was: +10-12 us per step on these 170-us steps)
+        ck(A.spmv_repeat(1.0, y, args.steps), "spmv_repeat")
         torch.cuda.synchronize()
         A.timer_start()
         ck(A.spmv_repeat(1.0, y, args.steps), "spmv_repeat")
