@@ -51,6 +51,7 @@ def main():
         ck(A.asCSR5(), "asCSR5")
         i = A.info()
         ck(A.spmv_repeat(1.0, y, 10), "spmv_repeat")
+        ck(A.spmv_repeat(1.0, y, 50), "spmv_repeat")  # instantiates the timed call's graph outside the timed region
         torch.cuda.synchronize()
         A.timer_start()
         ck(A.spmv_repeat(1.0, y, 50), "spmv_repeat")
