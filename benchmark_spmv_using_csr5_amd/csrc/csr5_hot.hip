@@ -222,12 +222,7 @@ k_spmv_range(Geometry g, const ST *__restrict__ val, const uint32_t *__restrict_
                 const int stop = __builtin_popcount(flags & 0x7FFFFFFFu);
                 int segn = stop - (f0 ? 0 : 1) + (present ? 1 : 0);
                 segn = segn > 0 ? segn : 0;
-                int incl = segn;
-#pragma unroll
-                for (int d_ = 1; d_ < OMEGA; d_ <<= 1) {
-                    const int up = __shfl_up(incl, d_, OMEGA);
-                    incl += lane >= d_ ? up : 0;
-                }
+                const int incl = wave_scan_incl(segn); // DPP, no LDS crossbar trips
                 y_off = lane ? incl - segn - 1 : 0;
             }
             if (open.row < 0)

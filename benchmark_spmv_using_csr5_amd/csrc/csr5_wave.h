@@ -79,6 +79,18 @@ __device__ __forceinline__ VT head_sum(VT v, int count)
     }
     return wave_sum(v);
 }
+// inclusive prefix sum over the lanes (lane l gets v[0] + ... + v[l]): six DPP adds -- four Hillis-Steele steps inside the
+// rows of 16 (row_shr fills with zeros), then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3
+__device__ __forceinline__ int wave_scan_incl(int v)
+{
+    v += dpp_word<DPP_ROW_SHR1>(v);
+    v += dpp_word<DPP_ROW_SHR2>(v);
+    v += dpp_word<DPP_ROW_SHR4>(v);
+    v += dpp_word<DPP_ROW_SHR8>(v);
+    v += dpp_word<DPP_ROW_BCAST15, 0xA>(v);
+    v += dpp_word<DPP_ROW_BCAST31, 0xC>(v);
+    return v;
+}
 // value of lane l+1 (lane 63 receives 0)
 template <typename VT>
 __device__ __forceinline__ VT lane_above(VT v)
