@@ -33,6 +33,10 @@ VARIANTS = {
     "rowscan_noflag": [("        atomicOr(&tile_desc[loc], 1u << (31 - (gbit & 31)));", "        if (gbit == -77) atomicOr(&tile_desc[loc], 1u << (31 - (gbit & 31)));")],
     "rowscan_noempty": [("        atomicOr(&tile_ptr[target], 0x80000000u);", "        if (before == -77) atomicOr(&tile_ptr[target], 0x80000000u);")],
     "rowscan_notileptr": [("        atomicOr(&tile_ptr[t0], (uint32_t)r);\n", "        if (r == -77) atomicOr(&tile_ptr[t0], (uint32_t)r);\n")],
+    # (candidates) the combine's partial-sum / row-byte loads with the non-temporal hint (P is dead after the combine)
+    "combine_nt": [("                part[q] = P[j];\n                idx[q] = rowidx[j];",
+                    "                part[q] = __builtin_nontemporal_load(P + j);\n                idx[q] = __builtin_nontemporal_load(rowidx + j);")],
+    "combine_ntP": [("                part[q] = P[j];", "                part[q] = __builtin_nontemporal_load(P + j);")],
     "notable": [("            return __builtin_bit_cast(word_t, hot[cw < 0 ? (unsigned)cw & 0x7FFFFFFFu : 0u]);",
                  "            return (word_t)(unsigned)cw;")],
 }
