@@ -15,6 +15,15 @@
 #define WORK 60
 #endif
 constexpr int SIGMA = 8, T = 64 * SIGMA, TABLE = 8160, WAVES = 8, STAGE = T * 12; // 6 KB per tile
+// -DINTERLEAVE: ONE array of 6-KB tile records [512 column words | 512 values] instead of two arrays (a wavefront then reads one
+// sequential stream instead of two)
+#ifdef INTERLEAVE
+__host__ __device__ inline const int *col_of(const int *col, const double *, size_t tt) { return reinterpret_cast<const int *>(reinterpret_cast<const char *>(col) + tt * STAGE); }
+__host__ __device__ inline const double *val_of(const int *col, const double *, size_t tt) { return reinterpret_cast<const double *>(reinterpret_cast<const char *>(col) + tt * STAGE + T * 4); }
+#else
+__host__ __device__ inline const int *col_of(const int *col, const double *, size_t tt) { return col + tt * T; }
+__host__ __device__ inline const double *val_of(const int *, const double *val, size_t tt) { return val + tt * T; }
+#endif
 
 __global__ void k_fill(int *col, double *val, size_t n, int coldpct, int xcols)
 {
@@ -23,8 +32,8 @@ __global__ void k_fill(int *col, double *val, size_t n, int coldpct, int xcols)
         h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
         const bool cold = (int)(h % 100) < coldpct;
         const unsigned r = (unsigned)(h >> 20);
-        col[i] = cold ? (int)(r % (unsigned)xcols) : (int)(0x80000000u | (1u + r % (TABLE - 1)));
-        val[i] = 1.0;
+        const_cast<int *>(col_of(col, val, i / T))[i % T] = cold ? (int)(r % (unsigned)xcols) : (int)(0x80000000u | (1u + r % (TABLE - 1)));
+        const_cast<double *>(val_of(col, val, i / T))[i % T] = 1.0;
     }
 }
 
@@ -50,8 +59,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_probe(const int *__restrict__ co
     int c[SIGMA];
     double v[SIGMA];
     auto load_regs = [&](size_t tt) {
-        const int *ct = col + tt * T + lane;
-        const double *vt = val + tt * T + lane;
+        const int *ct = col_of(col, val, tt) + lane;
+        const double *vt = val_of(col, val, tt) + lane;
 #pragma unroll
         for (int i = 0; i < SIGMA; i++)
             c[i] = __builtin_nontemporal_load(ct + i * 64);
@@ -117,8 +126,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_probe(const int *__restrict__ co
         __builtin_amdgcn_sched_barrier(0);
         const size_t tn = t + 1 < t1 ? t + 1 : t;
         if (MODE == 0 || MODE == 3) { // next tile's streams into the second register set
-            const int *ct = col + tn * T + lane;
-            const double *vt = val + tn * T + lane;
+            const int *ct = col_of(col, val, tn) + lane;
+            const double *vt = val_of(col, val, tn) + lane;
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
                 cn[i] = __builtin_nontemporal_load(ct + i * 64);
@@ -324,8 +333,13 @@ int main(int argc, char **argv)
     int *col;
     double *val, *x, *out;
     const int xb = xkb * 1024;
+#ifdef INTERLEAVE
+    CK(hipMalloc(&col, nnz * 12));
+    val = nullptr;
+#else
     CK(hipMalloc(&col, nnz * 4));
     CK(hipMalloc(&val, nnz * 8));
+#endif
     CK(hipMalloc(&x, (size_t)xb * 8));
     CK(hipMemset(x, 0, (size_t)xb * 8));
     CK(hipMalloc(&out, (size_t)4096 * 64 * 8));
@@ -337,12 +351,16 @@ int main(int argc, char **argv)
         CK(hipStreamSynchronize(s));
         printf("## %zu elements, %zu tiles of %d, %d %% of the gather lanes cold (x region %d KB per XCD), 8 wavefronts per CU, WORK %d\n", nnz, ntiles, T, coldpct, xkb, WORK);
         if (run<0>("streams through registers + gathers", col, val, x, xb, ntiles, out, s, coldpct)) return 1;
+#ifndef INTERLEAVE
         if (run<1>("streams through LDS-DMA + gathers", col, val, x, xb, ntiles, out, s, coldpct)) return 1;
+#endif
         if (run<2>("no streams (codes computed) + gathers", col, val, x, xb, ntiles, out, s, coldpct)) return 1;
         if (run<3>("streams only (loaded and consumed, no gather instructions)", col, val, x, xb, ntiles, out, s, coldpct)) return 1;
+#ifndef INTERLEAVE
         if (run_split<2>("8 consumers + 2 producers (LDS-DMA, 2 buffers each)", col, val, x, xb, ntiles, out, s)) return 1;
         if (run_split<4>("8 consumers + 4 producers", col, val, x, xb, ntiles, out, s)) return 1;
         if (run_split<8>("8 consumers + 8 producers", col, val, x, xb, ntiles, out, s)) return 1;
+#endif
     }
     return 0;
 }
