@@ -1039,7 +1039,7 @@ static int build_slabs_impl(csr5hip_handle h)
         if (e == hipSuccess && !inexact) {
             e = h->b_val32.reserve((size_t)g.nnz * sizeof(float));
             if (e == hipSuccess)
-                e = launch_narrow((const double *)c->d.val, (size_t)g.nnz, (float *)h->b_val32.ptr, s);
+                e = launch_narrow((const double *)c->d.val, (size_t)g.nnz, (float *)h->b_val32.ptr, c->g.tile_elems, c->g.p - 1, s);
             if (e == hipSuccess)
                 e = hipStreamSynchronize(s);
             if (e == hipSuccess) {

@@ -729,9 +729,18 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_transpose_values(Geometry g, VT *
     // every load of the tile has returned before its first store goes out (the tile is private to this wavefront, but
     // lane A's store lands where lane B reads)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // lane-major 16-BYTE PIECES (not the reference's element-wise transposition: this array is internal to the slab child and
+    // only k_spmv_range reads it): piece q of lane l -- its elements q PER .. q PER + PER - 1 -- at (q * 64 + l) * PER, so the
+    // range kernel fetches a lane's sigma values with sigma / PER 16-byte loads instead of sigma narrow ones (same lines, half
+    // / a quarter of the vector-memory instructions: -1.8 % in the shape probe, profiles/r04_probes.txt)
 #pragma unroll
-    for (int i = 0; i < SIGMA; i++)
-        tile[i * OMEGA + lane] = v[i];
+    for (int q = 0; q < SIGMA / PER; q++) {
+        piece_t w;
+#pragma unroll
+        for (int e = 0; e < PER; e++)
+            w[e] = v[q * PER + e];
+        *reinterpret_cast<piece_t *>(tile + ((size_t)q * OMEGA + lane) * PER) = w;
+    }
 }
 
 static hipError_t transpose_launch(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c, bool values_all, hipStream_t s)
@@ -782,7 +791,7 @@ hipError_t launch_transpose_values(const Geometry &g, const DeviceArrays &d, int
         }
     }
 #undef CSR5_TV
-    return transpose_launch(g, d, value_type, true, true, s); // other sigmas: the LDS version
+    return hipErrorInvalidValue; // (a hot child's sigma is 8 or 16: csr5_internal.h hot_child_sigma)
 }
 
 // export_only: the matrix is a column-slab child served by the range kernel (csr5_hot.hip), which uses neither carry meta nor

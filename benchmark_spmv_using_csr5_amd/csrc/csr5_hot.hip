@@ -58,13 +58,16 @@ __device__ __forceinline__ void load_dwords(uint32_t *dst, const uint32_t *p)
 
 // every load of tile t: column codes first (the gathers wait for them only; they carry the tile's bit flags too: the
 // descriptor array of the reference format is not read), then the tile_ptr pair (scalar) and the values
-template <typename VT, int SIGMA, bool NT>
+// PER = values per 16-byte piece of the STORED type: the child's values lie in lane-major 16-byte pieces (k_transpose_values;
+// the fp32 copy of CSR5HIP_OPT_NARROW_VALUES in pieces of four: k_narrow)
+template <typename VT, int SIGMA, bool NT, int PER>
 __device__ __forceinline__ void range_load(TileRegs<VT, SIGMA> &r, const uint16_t *__restrict__ col_lo,
                                            const uint8_t *__restrict__ col_hi, const VT *__restrict__ val,
                                            const uint32_t *__restrict__ tile_ptr, int t, int lane)
 {
     constexpr int T = OMEGA * SIGMA;
-    const VT *vt = val + (size_t)t * T + lane;
+    typedef VT piece_t __attribute__((ext_vector_type(PER)));
+    const piece_t *vp = reinterpret_cast<const piece_t *>(val + (size_t)t * T) + lane;
     const size_t first = (size_t)t * T + (size_t)lane * SIGMA;
     load_dwords<SIGMA / 2, NT>(r.plo, reinterpret_cast<const uint32_t *>(col_lo + first));
     load_dwords<SIGMA / 4, NT>(r.phi, reinterpret_cast<const uint32_t *>(col_hi + first));
@@ -76,8 +79,12 @@ __device__ __forceinline__ void range_load(TileRegs<VT, SIGMA> &r, const uint16_
         r.tp1 = tpc[t + 1];
     }
 #pragma unroll
-    for (int i = 0; i < SIGMA; i++)
-        r.v[i] = NT ? __builtin_nontemporal_load(vt + i * OMEGA) : vt[i * OMEGA];
+    for (int q = 0; q < SIGMA / PER; q++) {
+        const piece_t w = NT ? __builtin_nontemporal_load(vp + q * OMEGA) : vp[q * OMEGA];
+#pragma unroll
+        for (int e = 0; e < PER; e++)
+            r.v[q * PER + e] = w[e];
+    }
 }
 
 // State of the row that is open at the current tile boundary (wave-uniform).
@@ -337,7 +344,7 @@ k_spmv_range(Geometry g, const ST *__restrict__ val, const uint32_t *__restrict_
         };
 
         auto load = [&](TileRegs<ST, SIGMA> &tr, int t) {
-            range_load<ST, SIGMA, NT>(tr, hp.col_lo, hp.col_hi, val, tile_ptr, t, lane);
+            range_load<ST, SIGMA, NT, 16 / (int)sizeof(ST)>(tr, hp.col_lo, hp.col_hi, val, tile_ptr, t, lane);
         };
         if constexpr (DEPTH == 1) {
             for (int t = tb; t < te; t++) {
@@ -627,10 +634,22 @@ __global__ void __launch_bounds__(256) k_fp32_exact(const double *__restrict__ v
     if (__ballot(bad) != 0ull && (threadIdx.x & (OMEGA - 1)) == 0)
         *flag = 1u;
 }
-__global__ void __launch_bounds__(256) k_narrow(const double *__restrict__ v, size_t n, float *__restrict__ o)
+// o = v as fp32.  v is the hot child's value array: tiles 0 .. tiles-1 of T = 64 sigma elements in lane-major pieces of TWO
+// doubles (k_transpose_values), then the CSR tail in CSR order; o gets the same elements in lane-major pieces of FOUR floats
+// (16 bytes again: the range kernel's load width), the tail unchanged.
+__global__ void __launch_bounds__(256) k_narrow(const double *__restrict__ v, size_t n, float *__restrict__ o, int T, size_t tiles)
 {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        o[i] = (float)v[i];
+    const size_t body = tiles * (size_t)T;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        size_t dst = i;
+        if (i < body) {
+            const size_t t = i / (size_t)T;
+            const int r = (int)(i % (size_t)T);
+            const int q = r / (2 * OMEGA), l = (r % (2 * OMEGA)) / 2, e = 2 * q + (r & 1); // element e of lane l
+            dst = t * (size_t)T + (size_t)((e / 4) * OMEGA + l) * 4 + (e & 3);
+        }
+        o[dst] = (float)v[i];
+    }
 }
 hipError_t launch_fp32_exact(const double *v, size_t n, unsigned *flag, hipStream_t s)
 {
@@ -641,12 +660,15 @@ hipError_t launch_fp32_exact(const double *v, size_t n, unsigned *flag, hipStrea
     hipLaunchKernelGGL(k_fp32_exact, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, v, n, flag);
     return hipGetLastError();
 }
-hipError_t launch_narrow(const double *v, size_t n, float *o, hipStream_t s)
+hipError_t launch_narrow(const double *v, size_t n, float *o, int tile_elems, int transposed_tiles, hipStream_t s)
 {
     if (n == 0)
         return hipSuccess;
+    if (tile_elems % (4 * OMEGA) != 0)
+        return hipErrorInvalidValue;
     const size_t want = (n + 255) / 256;
-    hipLaunchKernelGGL(k_narrow, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, v, n, o);
+    hipLaunchKernelGGL(k_narrow, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, s, v, n, o, tile_elems,
+                       (size_t)(transposed_tiles > 0 ? transposed_tiles : 0));
     return hipGetLastError();
 }
 

@@ -188,7 +188,7 @@ hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type,
 hipError_t launch_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, void *y,
                            const SpmvOptions &opt, hipStream_t s);
 hipError_t launch_fp32_exact(const double *v, size_t n, unsigned *flag, hipStream_t s);
-hipError_t launch_narrow(const double *v, size_t n, float *o, hipStream_t s);
+hipError_t launch_narrow(const double *v, size_t n, float *o, int tile_elems, int transposed_tiles, hipStream_t s);
 hipError_t launch_range_heads(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 // the permuted copy of x behind the packed codes of a hot child: xperm[i] = x[hot_cols[i]] for the table images,
 // xperm[slabs * capacity + i] = x[cold_cols[i]] for the cold region

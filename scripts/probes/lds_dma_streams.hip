@@ -64,9 +64,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_probe(const int *__restrict__ co
 #pragma unroll
         for (int i = 0; i < SIGMA; i++)
             c[i] = __builtin_nontemporal_load(ct + i * 64);
+#ifdef WIDE_VAL // four 16-byte loads per lane instead of eight 8-byte ones (same lines, half the vector-memory instructions)
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2 *vt2 = reinterpret_cast<const d2 *>(val_of(col, val, tt)) + lane;
+#pragma unroll
+        for (int i = 0; i < SIGMA / 2; i++) {
+            const d2 w = __builtin_nontemporal_load(vt2 + i * 64);
+            v[2 * i] = w.x, v[2 * i + 1] = w.y;
+        }
+#else
 #pragma unroll
         for (int i = 0; i < SIGMA; i++)
             v[i] = __builtin_nontemporal_load(vt + i * 64);
+#endif
     };
     // LDS-DMA: the tile's 2 KB of column words (2 wave loads of 16 B per lane) and 4 KB of values (4 wave loads)
     auto dma = [&](size_t tt) {
@@ -131,9 +141,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_probe(const int *__restrict__ co
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
                 cn[i] = __builtin_nontemporal_load(ct + i * 64);
+#ifdef WIDE_VAL
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const d2 *vt2 = reinterpret_cast<const d2 *>(val_of(col, val, tn)) + lane;
+#pragma unroll
+            for (int i = 0; i < SIGMA / 2; i++) {
+                const d2 w = __builtin_nontemporal_load(vt2 + i * 64);
+                vn[2 * i] = w.x, vn[2 * i + 1] = w.y;
+            }
+#else
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
                 vn[i] = __builtin_nontemporal_load(vt + i * 64);
+#endif
         }
         if (MODE == 1)
             dma(tn);
