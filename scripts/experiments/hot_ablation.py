@@ -37,6 +37,38 @@ VARIANTS = {
     "combine_nt": [("                part[q] = P[j];\n                idx[q] = rowidx[j];",
                     "                part[q] = __builtin_nontemporal_load(P + j);\n                idx[q] = __builtin_nontemporal_load(rowidx + j);")],
     "combine_ntP": [("                part[q] = P[j];", "                part[q] = __builtin_nontemporal_load(P + j);")],
+    # TIMING ONLY (wrong results: the elements land in the wrong lanes): k_spmv's column / value streams as 16-byte loads (what an
+    # in-register transposition of 4 x 4 / 2 x 2 blocks would allow) -- is the one-tile kernel sensitive to its load instruction count?
+    "widespmv": [("""#pragma unroll
+            for (int i = 0; i < SIGMA; i++)
+                c[i] = ct[i * OMEGA];""",
+                  """            {
+                constexpr int PC = SIGMA % 4 == 0 ? 4 : 2;
+                typedef int32_t cp_t __attribute__((ext_vector_type(PC)));
+                const cp_t *cp = reinterpret_cast<const cp_t *>(col + (size_t)t * T) + lane;
+#pragma unroll
+                for (int q = 0; q < SIGMA / PC; q++) {
+                    const cp_t w = cp[q * OMEGA];
+#pragma unroll
+                    for (int e = 0; e < PC; e++)
+                        c[q * PC + e] = w[e];
+                }
+            }"""),
+                 ("""#pragma unroll
+            for (int i = 0; i < SIGMA; i++)
+                v[i] = vt[i * OMEGA];""",
+                  """            {
+                constexpr int PV = (16 / (int)sizeof(VT)) <= SIGMA && SIGMA % (16 / (int)sizeof(VT)) == 0 ? 16 / (int)sizeof(VT) : 2;
+                typedef VT vp_t __attribute__((ext_vector_type(PV)));
+                const vp_t *vp = reinterpret_cast<const vp_t *>(val + (size_t)t * T) + lane;
+#pragma unroll
+                for (int q = 0; q < SIGMA / PV; q++) {
+                    const vp_t w = vp[q * OMEGA];
+#pragma unroll
+                    for (int e = 0; e < PV; e++)
+                        v[q * PV + e] = w[e];
+                }
+            }""")],
     "notable": [("            return __builtin_bit_cast(word_t, hot[cw < 0 ? (unsigned)cw & 0x7FFFFFFFu : 0u]);",
                  "            return (word_t)(unsigned)cw;")],
 }
@@ -51,7 +83,7 @@ def main():
                 shutil.copy(os.path.join(SRC, f), tmp)
         for old, new in VARIANTS[name]:
             # the file a pattern belongs to: csr5_hot.hip unless another source holds it
-            for fname in ("csr5_hot.hip", "csr5_format.hip", "csr5_slab.hip"):
+            for fname in ("csr5_hot.hip", "csr5_format.hip", "csr5_slab.hip", "csr5_spmv.hip"):
                 path = os.path.join(tmp, fname)
                 text = open(path).read()
                 if old in text:
