@@ -128,11 +128,35 @@ __global__ void __launch_bounds__(WAVES * 64) k_probe(const int *__restrict__ co
         }
         __builtin_amdgcn_sched_barrier(0);
         unsigned long long g[SIGMA];
+#ifdef COMPACT_GATHERS // the tile's cold lanes as FULL gather instructions (what a cross-lane compaction would issue): the same number
+                       // of cold lines, ceil(cold / 64) instructions instead of 8 -- timing only, the values go to arbitrary elements
+        {
+            int ncold = 0;
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++)
+                ncold += c[i] >= 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1)
+                ncold += __shfl_xor(ncold, d, 64);
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++) {
+                g[i] = 0ull;
+                if (i * 64 < ncold && MODE != 3) { // (wave-uniform)
+                    unsigned h = ((unsigned)t * 512u + i * 64 + lane) * 0x9E3779B1u; // a fresh pseudo-random entry of the region per lane:
+                    h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13;                       // as many distinct lines as the 8-instruction form
+                    const unsigned pick = __umulhi(h, (unsigned)(xbytes_per_xcd / 8));
+                    const unsigned off = i * 64 + lane < ncold ? pick * 8u : 0xFFFFFFFFu;
+                    g[i] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int i = 0; i < SIGMA; i++) {
             const unsigned off = (c[i] < 0 || MODE == 3) ? 0xFFFFFFFFu : (unsigned)c[i] * 8u;
             g[i] = MODE == 3 ? 0ull : __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const size_t tn = t + 1 < t1 ? t + 1 : t;
         if (MODE == 0 || MODE == 3) { // next tile's streams into the second register set
