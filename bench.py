@@ -107,6 +107,9 @@ def parse_args():
                     help="hot-table slab kernel: 1 (default) = its permuted copy of x is taken once per setX, as the reference CLI's "
                          "protocol allows (setX once, NUM_RUN spmv calls on the same x: CSR5_cuda/main.cu:63-99); 0 = by every "
                          "spmv (the library default: x is read live)")
+    ap.add_argument("--tile-walk", default="auto", choices=["auto", "off", "force"],
+                    help="plain path: the range-walking pipelined tile kernel (CSR5HIP_OPT_TILE_WALK)")
+    ap.add_argument("--walk-ranges", type=int, default=0, help="tile ranges of the walking kernel, 0 = default")
     ap.add_argument("--zero-empty", type=int, default=0, choices=[0, 1],
                     help="1 = rows without non-zeros are written as 0 (CSR5HIP_OPT_ZERO_EMPTY_ROWS; the coupled-iteration setting)")
     ap.add_argument("--scaling", default=None, choices=[None, "weak", "strong"],
@@ -235,6 +238,8 @@ class Problem:
         if args.slab_shift is not None:
             _ck(A.setSlabShift(args.slab_shift), "setSlabShift")
         _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
+        _ck(A.setTileWalk({"off": 0, "auto": 1, "force": 2}[getattr(args, "tile_walk", "auto")]), "setTileWalk")
+        _ck(A.setWalkRanges(int(getattr(args, "walk_ranges", 0))), "setWalkRanges")
         rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 1)))
         if rc != 0 and not os.environ.get("CSR5HIP_LIB"):  # (an older library build under A/B test does not know the option)
             _ck(rc, "setXSnapshot")

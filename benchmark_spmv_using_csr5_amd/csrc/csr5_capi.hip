@@ -114,7 +114,9 @@ struct csr5hip_handle_s {
     void *scan_tmp = nullptr;
     size_t scan_tmp_bytes = 0;
     uint32_t scalar_words[2] = {0, 0}; // landing zone of the two 4-byte reads of the conversion (checkpoint loading)
-    uint32_t *host_words = nullptr;    // 16 pinned, device-visible words the last conversion kernel exports into
+    uint32_t *host_words = nullptr;    // 32 pinned, device-visible words the last conversion kernels export into
+    int walk_request = 1;        // CSR5HIP_OPT_TILE_WALK: 0 off, 1 auto (default), 2 force
+    int walk_ranges_request = 0; // CSR5HIP_OPT_WALK_RANGES: 0 = default
     double wall_clock_khz = 0;         // rate of the device's constant wall clock (phase stamps)
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -216,6 +218,19 @@ static int nt_decision(const csr5hip_handle_s *h)
         return 0;
     const long long stream_bytes = (long long)h->g.nnz * (4 + (long long)h->vsize());
     return stream_bytes > 256LL * 1024 * 1024;
+}
+
+// The range-walking pipelined kernel (csr5_walk.hip) instead of one tile per wavefront: forced, or (auto) when every range
+// gets enough tiles for the pipeline to pay -- with fewer, all tiles are resident at once anyway and the one-tile kernel's
+// short-spill ownership saves the ranges' arrival atomics.
+static int walk_decision(const csr5hip_handle_s *h)
+{
+    if (h->walk_request == 0 || h->is_child || h->d.walk_ranges <= 0 || h->opt.mode != 1 ||
+        !walk_supported(h->g, (int)h->vsize(), h->opt.x_window))
+        return 0;
+    if (h->walk_request == 2)
+        return 1;
+    return (long long)(h->g.p - 1) >= (long long)WALK_AUTO_MIN_TILES_PER_RANGE * h->d.walk_ranges;
 }
 
 extern "C" {
@@ -329,6 +344,7 @@ int csr5hip_set_sigma(csr5hip_handle h, int sigma)
 
 static int build_slabs(csr5hip_handle h);
 static int build_slabs_impl(csr5hip_handle h);
+static hipError_t build_walk_tables(csr5hip_handle h);
 
 int csr5hip_set_option(csr5hip_handle h, int option, int value)
 {
@@ -339,6 +355,8 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         if (value != 0 && value != 1)
             return CSR5HIP_INVALID_ARGUMENT;
         h->opt.mode = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5)
+            h->opt.walk = walk_decision(h);
         if (h->slab_S > 0 && h->slab_child->hot_enabled && value != 1) {
             // the hot table exists for the fused kernel only and its column words are encoded: rebuild without it
             h->drop_graphs();
@@ -366,8 +384,10 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         if (value < 0 || value > 2)
             return CSR5HIP_INVALID_ARGUMENT;
         h->xwin_request = value;
-        if (h->format == CSR5HIP_FORMAT_CSR5)
+        if (h->format == CSR5HIP_FORMAT_CSR5) {
             h->opt.x_window = xwin_decision(h);
+            h->opt.walk = walk_decision(h);
+        }
         break;
     case CSR5HIP_OPT_COLUMN_SLABS:
         if (value < 0 || value > 64 || (value & (value - 1)))
@@ -414,6 +434,26 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
                 h->drop_graphs();
                 return build_slabs(h);
             }
+        }
+        break;
+    case CSR5HIP_OPT_TILE_WALK:
+        if (value < 0 || value > 2)
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->walk_request = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5)
+            h->opt.walk = walk_decision(h);
+        break;
+    case CSR5HIP_OPT_WALK_RANGES:
+        if (value < 0 || value > WALK_MAX_RANGES)
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->walk_ranges_request = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5 && h->g.p > 1 && !h->is_child) {
+            // the ranges change: their tables again (no partial is parked between SpMVs, so the arrival words are all zero)
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(build_walk_tables(h));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            h->opt.walk_long_runs = h->d.walk_ranges > 0 && h->host_words[16] != 0;
+            h->opt.walk = walk_decision(h);
         }
         break;
     case CSR5HIP_OPT_SLAB_MEMORY_MIB:
@@ -480,8 +520,13 @@ static int reserve_aux(csr5hip_handle h)
     // zero-initialised part first
     const size_t o_desc = take(desc_words * 4), o_offp = take(p1 * 4), o_cal = take(p1 * h->vsize()),
                  o_acc = take(p1 * h->vsize()), o_cnt = take(p1 * 4), o_counters = take(COUNTER_WORDS * 4), o_tp = take(p1 * 4), o_offset = take(offset_cap * 4);
+    // range-walking kernel (csr5_walk.hip): arrival words of the ranges (zero between launches), then its tables
+    const bool walk_tables = !h->is_child;
+    const size_t wr = walk_tables ? (size_t)WALK_MAX_RANGES + 2 : 0;
+    const size_t o_wacc = take(wr * h->vsize()), o_wcnt = take(wr * 4);
     const size_t zero_bytes = off;
     const size_t o_meta = take(p1 * 16), o_hdr = take(p1 * 32), o_scan = take(h->scan_tmp_bytes);
+    const size_t o_wrow = take(wr * 4), o_wmeta = take(wr * 16), o_wlead = take(wr * h->vsize()), o_xwin = take(p1 * 4);
     HIP_TRY(h->b_arena.reserve(off));
     char *base = (char *)h->b_arena.ptr;
     h->d.tile_desc = (uint32_t *)(base + o_desc);
@@ -495,6 +540,13 @@ static int reserve_aux(csr5hip_handle h)
     h->d.carry_meta = (uint32_t *)(base + o_meta);
     h->d.tile_hdr = (uint32_t *)(base + o_hdr);
     h->scan_tmp = base + o_scan;
+    h->d.walk_ranges = 0;
+    h->d.walk_acc = walk_tables ? base + o_wacc : nullptr;
+    h->d.walk_cnt = walk_tables ? (uint32_t *)(base + o_wcnt) : nullptr;
+    h->d.walk_row = walk_tables ? (uint32_t *)(base + o_wrow) : nullptr;
+    h->d.walk_meta = walk_tables ? (uint32_t *)(base + o_wmeta) : nullptr;
+    h->d.walk_lead = walk_tables ? base + o_wlead : nullptr;
+    h->d.xwin_base = (int32_t *)(base + o_xwin);
     HIP_TRY(hipMemsetAsync(base, 0, zero_bytes, s));
     return CSR5HIP_SUCCESS; // stream-ordered: the conversion kernels follow on the same stream
 }
@@ -522,14 +574,34 @@ static void finish_format_scalars(csr5hip_handle h)
     h->num_offsets = (int)h->scalar_words[1];
 }
 
+// the range-walking kernel's tables (csr5_walk.hip): how many ranges the tiles 0 .. p-2 are dealt to, and the arrival protocol
+// of those ranges.  Stream-ordered; host_words[16] = number of rows spanning more than RUN_SERIAL_MAX ranges, valid after the
+// next synchronisation.
+static int walk_ranges_for(const csr5hip_handle_s *h)
+{
+    if (h->is_child || !h->d.walk_row || h->g.p <= 1)
+        return 0;
+    int want = h->walk_ranges_request > 0 ? h->walk_ranges_request : WALK_DEFAULT_RANGES;
+    want = want > WALK_MAX_RANGES ? WALK_MAX_RANGES : want;
+    return want < h->g.p - 1 ? want : h->g.p - 1;
+}
+static hipError_t build_walk_tables(csr5hip_handle h)
+{
+    h->d.walk_ranges = walk_ranges_for(h);
+    if (h->d.walk_ranges <= 0)
+        return hipSuccess;
+    h->host_words[16] = 0;
+    return launch_walk_tables(h->g, h->d, h->host_words + 16, h->stream);
+}
+
 // what the fused kernel needs on top of the reference's format arrays: carry meta, x windows, tile headers
 static int derive_kernel_tables(csr5hip_handle h)
 {
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
     if (!h->host_words) {
-        HIP_TRY(hipHostMalloc((void **)&h->host_words, 64, hipHostMallocDefault));
-        memset(h->host_words, 0, 64);
+        HIP_TRY(hipHostMalloc((void **)&h->host_words, 128, hipHostMallocDefault));
+        memset(h->host_words, 0, 128);
         int dev = 0, khz = 0;
         if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0)
@@ -539,7 +611,9 @@ static int derive_kernel_tables(csr5hip_handle h)
     }
     // carry_meta + x-windows + fused-kernel headers in one launch, then the export of the host's words
     HIP_TRY(launch_tile_tables(g, h->d, (int)h->vsize(), h->host_words, h->is_child && h->hot_enabled, s));
+    HIP_TRY(build_walk_tables(h)); // (the same synchronisation covers its one exported word)
     HIP_TRY(hipStreamSynchronize(s));
+    h->opt.walk_long_runs = h->d.walk_ranges > 0 && h->host_words[16] != 0;
     const uint32_t *w = h->host_words;
     h->scalar_words[0] = w[0];
     h->scalar_words[1] = w[1];
@@ -588,6 +662,7 @@ static void resolve_variants(csr5hip_handle h)
     h->opt.lds_y = ldsy_decision(h);
     h->opt.stream_nt = nt_decision(h);
     h->opt.hot = h->hot_enabled ? 1 : 0;
+    h->opt.walk = walk_decision(h);
 }
 
 int csr5hip_as_csr5(csr5hip_handle h)
@@ -1584,6 +1659,8 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_cold_entries = info->slab_x_permuted ? h->cold_total : 0;
     info->x_snapshot = h->x_snapshot;
     info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
+    info->tile_walk = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.walk ? 1 : 0;
+    info->walk_ranges = h->format == CSR5HIP_FORMAT_CSR5 ? h->d.walk_ranges : 0;
     long long bytes = (long long)h->b_arena.cap;
     for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_val32, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
                             &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_range_head, &h->b_slab_tmp,

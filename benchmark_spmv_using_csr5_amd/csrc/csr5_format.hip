@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
                                                        const int32_t *__restrict__ col,
                                                        uint4 *__restrict__ carry_meta, uint32_t *__restrict__ hdr,
                                                        uint32_t *__restrict__ counters, int XWIN_ELEMS,
-                                                       int line_shift)
+                                                       int line_shift, int32_t *__restrict__ xwin_base)
 {
     stamp_phase(counters, 3);
     uint32_t *const long_run_counter = counters + 2;
@@ -474,7 +474,10 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
         auto window_of = [&](int centre) {
             int lo = centre - XWIN_ELEMS / 2;
             lo = lo < 0 ? 0 : (lo > hi_limit ? hi_limit : lo);
-            return lo & ~3;
+            // bases are multiples of an eighth of a window: consecutive tiles whose columns drift slowly (banded matrices)
+            // then ask for the SAME slice of x, which the range-walking kernel keeps staged (csr5_walk.hip)
+            const int quantum = XWIN_ELEMS / 8;
+            return lo / quantum * quantum;
         };
         // score every lane's candidate on the 64 samples (v_readlane broadcasts, no LDS shuffles)
         const int my_lo = window_of(sample);
@@ -521,6 +524,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
     }
     if (lane == 0) {
         meta.w = window;
+        xwin_base[t] = (int)window - 1; // dense copy for the range-walking kernel: one scalar load per tile
         carry_meta[t] = meta;
         reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t] = meta;
         reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t + 1] = make_uint4(next_x, tile_ptr[t], tile_ptr[t + 1], stats);
@@ -809,7 +813,7 @@ hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int valu
     }
     hipLaunchKernelGGL(k_tile_tables, dim3(div_up(g.p, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
                        d.tile_ptr, d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.tile_hdr, d.counters,
-                       xwin_elems(value_size), value_size == 8 ? 4 : 5);
+                       xwin_elems(value_size), value_size == 8 ? 4 : 5, d.xwin_base);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;

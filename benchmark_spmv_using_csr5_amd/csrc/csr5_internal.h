@@ -89,6 +89,14 @@ struct DeviceArrays {
     int cold_total;
     // CSR5HIP_OPT_NARROW_VALUES: the hot child's values (tile order, like val) as fp32 -- every one of them exactly; else nullptr
     const float *val32;
+    // range-walking tile kernel on the plain format (csr5_walk.hip): tiles 0 .. p-2 dealt to walk_ranges contiguous ranges
+    int walk_ranges;           // 0 = tables not built
+    uint32_t *walk_row;        // [walk_ranges + 1] first row of every range | WALK_EXACT; the last entry = the CSR tail
+    uint32_t *walk_meta;       // [walk_ranges + 1] x uint4: arrival protocol of the ranges (layout of carry_meta)
+    void *walk_lead;           // [walk_ranges + 1] of vT: parked leading partials
+    void *walk_acc;            // [walk_ranges + 1] of vT: parked closing partials / exchange words, all zero between launches
+    uint32_t *walk_cnt;        // [walk_ranges + 1] arrival counters, all zero between launches
+    int32_t *xwin_base;        // [p] x-window base of every tile (-1 = none): dense copy of carry_meta[t].w - 1
 };
 
 // ---- conversion (csr5_format.hip) ----
@@ -147,7 +155,13 @@ struct SpmvOptions {
     int stream_nt;   // resolved: 1 = column/value streams use non-temporal loads
     int long_runs;   // resolved: the matrix has rows spanning > RUN_SERIAL_MAX tiles (fused mode adds k_calibrate)
     int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_range + k_range_finish
+    int walk;        // resolved: 1 = the range-walking pipelined kernel (csr5_walk.hip) instead of one tile per wavefront
+    int walk_long_runs; // resolved: some row spans > RUN_SERIAL_MAX ranges (the walking kernel adds k_calibrate)
 };
+constexpr int WALK_MAX_SIGMA = 16;          // one descriptor packet per lane, two register sets of sigma elements
+constexpr int WALK_MAX_RANGES = 16384;      // upper bound of CSR5HIP_OPT_WALK_RANGES (k_walk_tables: one workgroup)
+constexpr int WALK_DEFAULT_RANGES = 2048;   // 8 wavefronts per CU
+constexpr int WALK_AUTO_MIN_TILES_PER_RANGE = 4; // auto: the walking kernel runs when every range gets at least this many tiles
 constexpr int HOT_LDS_BYTES = 128 * 1024;  // upper bound of the LDS table of hot x entries per workgroup (k_spmv_range)
 constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_range
 // Wavefronts of the persistent workgroup (one workgroup per CU).  The kernel is bound by the L1's outstanding requests,
@@ -184,6 +198,16 @@ struct HotParams {
 constexpr int hot_child_sigma(int value_size) { return HOT_WAVE_LDS / (OMEGA * value_size); }
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s);
+// csr5_walk.hip: range-walking pipelined kernel on the plain format arrays
+bool walk_supported(const Geometry &g, int value_size, int x_window);
+hipError_t launch_walk_tables(const Geometry &g, const DeviceArrays &d, uint32_t *long_runs_out, hipStream_t s);
+hipError_t launch_spmv_walk_f64(const Geometry &g, const DeviceArrays &d, const void *x, void *y, const SpmvOptions &opt,
+                                hipStream_t s);
+hipError_t launch_spmv_walk_f32(const Geometry &g, const DeviceArrays &d, const void *x, void *y, const SpmvOptions &opt,
+                                hipStream_t s);
+// csr5_spmv.hip: k_calibrate on `count` parties whose runs longer than RUN_SERIAL_MAX only parked their partials
+hipError_t launch_calibrate_long(int count, int m, int value_type, const uint32_t *party_row, const uint32_t *meta,
+                                 const void *parked_lead, const void *parked_closing, void *y, hipStream_t s);
 // csr5_hot.hip: the slab child's SpMV when its column words are hot-encoded (persistent range kernel + finish)
 hipError_t launch_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, void *y,
                            const SpmvOptions &opt, hipStream_t s);

@@ -156,6 +156,15 @@ class anonymouslibHandle:
         for bit, 4 bytes less per non-zero); 0 (default) = off; csr5hip.h CSR5HIP_OPT_NARROW_VALUES"""
         return self.setOption(_capi.OPT_NARROW_VALUES, int(value))
 
+    def setTileWalk(self, value: int) -> int:
+        """plain path: 0 = one tile per wavefront, 1 = auto (default), 2 = force the range-walking pipelined kernel
+        (csr5hip.h CSR5HIP_OPT_TILE_WALK)"""
+        return self.setOption(_capi.OPT_TILE_WALK, int(value))
+
+    def setWalkRanges(self, value: int) -> int:
+        """tile ranges (= wavefronts) of the walking kernel, 0 = default (csr5hip.h CSR5HIP_OPT_WALK_RANGES)"""
+        return self.setOption(_capi.OPT_WALK_RANGES, int(value))
+
     def setZeroEmptyRows(self, value: int) -> int:
         """1 = spmv() also stores 0 into rows without non-zeros (solver coupling); 0 = reference behaviour"""
         return self.setOption(_capi.OPT_ZERO_EMPTY_ROWS, int(value))

@@ -108,6 +108,16 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       8-byte one the roofline's algorithmic bytes count.  csr5hip_info.slab_values_narrowed
                                       says what happened.  +4 bytes per non-zero of device memory. */
 
+#define CSR5HIP_OPT_TILE_WALK 13  /* fused mode, plain (non-slab) path: the range-walking, software-pipelined tile kernel -- one wavefront
+                                      owns a contiguous range of tiles, the next tile's streams are requested before this tile's
+                                      gathers, the open row stays in registers, one leading partial per RANGE goes through the
+                                      arrival protocol -- instead of one tile per wavefront.  Same format arrays, same results up to
+                                      the association of cut rows' partial sums (bit-reproducible run to run either way).
+                                      0 = off, 1 = auto (default: on when every range gets >= 4 tiles and sigma <= 16), 2 = force
+                                      (still needs sigma in 4..16) */
+#define CSR5HIP_OPT_WALK_RANGES 14 /* number of tile ranges (= wavefronts) of the walking kernel: 0 = default (2 048 = 8 per CU),
+                                      else 1 .. 16 384; never more than p - 1 */
+
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
 /* Host-visible snapshot of the handle's private state (anonymouslib_cuda.h:27-52). */
@@ -147,6 +157,8 @@ typedef struct csr5hip_info {
     int slab_cold_entries;         /* entries of that copy behind the table images (columns gathered from memory)        */
     int x_snapshot;                /* CSR5HIP_OPT_X_SNAPSHOT as set                                                      */
     int slab_values_narrowed;      /* 1 = CSR5HIP_OPT_NARROW_VALUES took effect: the slab kernel streams fp32 values       */
+    int tile_walk;                 /* 1 = spmv() launches the range-walking pipelined kernel (CSR5HIP_OPT_TILE_WALK)           */
+    int walk_ranges;               /* tile ranges (wavefronts) of that kernel; 0 = its tables were not built                   */
 } csr5hip_info;
 
 /* anonymouslibHandle(m, n) -- anonymouslib_cuda.h:15.  Uses the current HIP device. */

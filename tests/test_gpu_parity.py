@@ -29,7 +29,8 @@ def _device_csr(mat, val, dtype):
 
 
 def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None, nt=None,
-         slabs=None, slab_shift=None, zero_empty=None, info_out=None, hot=None, x_snapshot=None, narrow=None):
+         slabs=None, slab_shift=None, zero_empty=None, info_out=None, hot=None, x_snapshot=None, narrow=None,
+         walk=None, walk_ranges=None):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
@@ -57,6 +58,10 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         assert A.setXSnapshot(x_snapshot) == 0
     if narrow is not None:
         assert A.setNarrowValues(narrow) == 0
+    if walk is not None:
+        assert A.setTileWalk(walk) == 0
+    if walk_ranges is not None:
+        assert A.setWalkRanges(walk_ranges) == 0
     assert A.spmv(1.0, yd) == H.ANONYMOUSLIB_UNSUPPORTED_CSR_SPMV  # still CSR (anonymouslib_cuda.h:268-271)
     assert A.asCSR5() == 0, _capi.last_error()
     arrays = A.csr5_arrays()
@@ -64,7 +69,8 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         i = A.info()
         info_out.update(column_slabs=i.column_slabs, slab_segments=i.slab_segments, slab_sigma=i.slab_sigma,
                         slab_tiles=i.slab_tiles, sigma=i.sigma, slab_hot=i.slab_hot,
-                        slab_hot_cover_pct=i.slab_hot_cover_pct)
+                        slab_hot_cover_pct=i.slab_hot_cover_pct, tile_walk=i.tile_walk, walk_ranges=i.walk_ranges,
+                        p=i.p, x_window_active=i.x_window_active)
     col_t = ci.cpu().numpy().copy()
     val_t = va.cpu().numpy().copy()
     ys = []
@@ -501,13 +507,17 @@ def test_seeded_fuzz_against_oracle(oracle):
         hot = int(rng.choice([0, 2])) if slabs % 8 == 0 and slabs and mode == H.SPMV_FUSED else 0
         snap = (case // 5) % 2 if hot else None  # permuted copy of x per spmv (default) or per setX
         narrow = (case // 10) % 2 if hot else None  # fp64: the (integer) values streamed as fp32; fp32 handles ignore it
+        # the range-walking kernel (forced; it runs when sigma is in 4..16, fused mode, no slabs) with few / default ranges
+        walk = int(rng.choice([0, 2])) if mode == H.SPMV_FUSED else None
+        walk_ranges = int(rng.choice([0, 1, 2, 3, 7, 40])) if walk else None
         fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
         arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, dtype=dtype, xwin=xwin, ldsy=ldsy, nt=nt, repeat=2,
-                                        slabs=slabs, hot=hot, x_snapshot=snap, narrow=narrow)
+                                        slabs=slabs, hot=hot, x_snapshot=snap, narrow=narrow, walk=walk,
+                                        walk_ranges=walk_ranges)
         _check_format(arrays, col_t, val_t, fmt)
         exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
         for y in ys:
-            assert np.array_equal(y, exp), (case, m, n, sigma, mode, xwin, ldsy, nt, slabs, hot, dtype,
+            assert np.array_equal(y, exp), (case, m, n, sigma, mode, xwin, ldsy, nt, slabs, hot, dtype, walk, walk_ranges,
                                             np.flatnonzero(y != exp)[:5])
 
 
@@ -523,7 +533,7 @@ def test_multi_tile_rows_stress_cross_xcd_protocol(oracle):
     for dtype, sigma in ((np.float64, 4), (np.float64, 16), (np.float32, 8)):
         val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=3, mode="real")
         _, _, _, y2 = _run(mat, val, x, sigma, H.SPMV_TWO_PASS, dtype=dtype)
-        _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, repeat=25)
+        _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, repeat=25, walk=0)
         long_rows = np.diff(mat.row_ptr) > 64 * sigma * 2  # certainly resolved by the arrival protocol
         for k, y in enumerate(ys):
             assert np.array_equal(y[long_rows], y2[0][long_rows]), (dtype, sigma, k)
@@ -674,7 +684,7 @@ def test_fused_long_run_path_deterministic(oracle, sigma, dtype):
                 fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
                 exp = _expected_y(oracle, fmt, mat, x, 0.0).astype(np.float64)
             scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val).astype(np.float64), np.abs(x).astype(np.float64))
-            _, _, _, yf = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, y0=0.0, repeat=2, slabs=0)
+            _, _, _, yf = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, y0=0.0, repeat=2, slabs=0, walk=0)
             _, _, _, yt = _run(mat, val, x, sigma, H.SPMV_TWO_PASS, dtype=dtype, y0=0.0, slabs=0)
             assert np.array_equal(yf[0], yf[1]) and np.array_equal(yf[0], yt[0]), (k, fill, "fused == two-pass, bit for bit")
             tol = (1e-12 if dtype == np.float64 else 2e-5) * np.maximum(scale, 1.0)
