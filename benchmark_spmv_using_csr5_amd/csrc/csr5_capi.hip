@@ -1135,21 +1135,27 @@ static int build_slabs_impl(csr5hip_handle h)
     return CSR5HIP_SUCCESS;
 }
 
+static bool stream_is_capturing(hipStream_t s)
+{
+    if (s == nullptr)
+        return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
+        (void)hipGetLastError(); // (the query itself failed: treat the stream as not capturing)
+        return false;
+    }
+    return cap != hipStreamCaptureStatusNone;
+}
+
 // CSR5HIP_OPT_X_SNAPSHOT: the permuted copy of x is taken once per setX -- here, on stream s, in front of the first SpMV
 // (or graph capture) that needs it
 static hipError_t ensure_x_snapshot(csr5hip_handle h, hipStream_t s)
 {
     if (!h->x_snapshot || h->xperm_valid || h->slab_S <= 0 || !h->slab_child->hot_enabled)
         return hipSuccess;
-    // a caller capturing its own graph gets the copy recorded with every spmv() (enqueue_spmv: the copy is not there yet
-    // while the graph is only being built)
-    if (s != nullptr) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &cap) != hipSuccess)
-            (void)hipGetLastError(); // (the query itself failed: treat the stream as not capturing)
-        else if (cap != hipStreamCaptureStatusNone)
-            return hipSuccess;
-    }
+    // a caller capturing its own graph gets the copy recorded with every spmv() (enqueue_spmv)
+    if (stream_is_capturing(s))
+        return hipSuccess;
     hipError_t e = launch_x_permute(h->slab_child->d, h->value_type, h->x, s);
     if (e == hipSuccess)
         h->xperm_valid = true;
@@ -1157,13 +1163,18 @@ static hipError_t ensure_x_snapshot(csr5hip_handle h, hipStream_t s)
 }
 
 // one SpMV on stream s: the tile kernel on the matrix itself, or -- with column slabs -- on the stacked matrix
-// followed by the combine kernel
-static hipError_t enqueue_spmv(csr5hip_handle h, void *d_y, hipStream_t s)
+// followed by the combine kernel.  own_graph: s is the private capture stream of spmv_repeat / spmv_rotate, whose graphs
+// set_x drops; otherwise s is the caller's stream, which may itself be capturing.
+static hipError_t enqueue_spmv(csr5hip_handle h, void *d_y, hipStream_t s, bool own_graph)
 {
     if (h->slab_S > 0) {
         csr5hip_handle c = h->slab_child;
         hipError_t e = hipSuccess;
-        if (c->hot_enabled && !(h->x_snapshot && h->xperm_valid)) {
+        // CSR5HIP_OPT_X_SNAPSHOT: the copy taken at the last setX may be reused -- except inside a graph the CALLER is
+        // capturing: that graph outlives this setX (the handle cannot drop it), so it must carry the copy itself; a replay
+        // after the caller rewrote x and called setX again would otherwise read the old copy
+        const bool reuse = h->x_snapshot && h->xperm_valid && (own_graph || !stream_is_capturing(s));
+        if (c->hot_enabled && !reuse) {
             // the packed codes index the permuted copy of x: taken by every spmv() (x is read live, as the reference reads
             // it), or -- CSR5HIP_OPT_X_SNAPSHOT -- once per setX
             e = launch_x_permute(c->d, c->value_type, h->x, s);
@@ -1428,7 +1439,7 @@ int csr5hip_spmv(csr5hip_handle h, double alpha, void *d_y)
     if (!h->x)
         return CSR5HIP_INVALID_ARGUMENT;
     HIP_TRY(ensure_x_snapshot(h, h->stream));
-    HIP_TRY(enqueue_spmv(h, d_y, h->stream));
+    HIP_TRY(enqueue_spmv(h, d_y, h->stream, false));
     return CSR5HIP_SUCCESS;
 }
 
@@ -1456,7 +1467,7 @@ int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count)
         int rc = CSR5HIP_SUCCESS;
         if (e == hipSuccess) {
             for (int i = 0; i < count && e == hipSuccess; i++)
-                e = enqueue_spmv(h, d_y, cs);
+                e = enqueue_spmv(h, d_y, cs, true);
             hipError_t e2 = hipStreamEndCapture(cs, &graph);
             if (e == hipSuccess)
                 e = e2;
@@ -1496,8 +1507,21 @@ int csr5hip_spmv_rotate(csr5hip_handle *hs, void **d_ys, int k, double alpha, in
     if (count == 0)
         return CSR5HIP_SUCCESS;
     csr5hip_handle h0 = hs[0];
-    for (int i = 0; i < k; i++)
-        HIP_TRY(ensure_x_snapshot(hs[i], h0->stream));
+    for (int i = 0; i < k; i++) {
+        // every handle's snapshot on its OWN stream (a later spmv(hs[i]) there is ordered behind it); the rotating graph,
+        // launched on hs[0]'s stream, waits for the foreign ones
+        const bool pending = hs[i]->x_snapshot && !hs[i]->xperm_valid;
+        HIP_TRY(ensure_x_snapshot(hs[i], hs[i]->stream));
+        if (pending && hs[i]->stream != h0->stream) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            hipError_t e = hipEventRecord(ev, hs[i]->stream);
+            if (e == hipSuccess)
+                e = hipStreamWaitEvent(h0->stream, ev, 0);
+            (void)hipEventDestroy(ev);
+            HIP_TRY(e);
+        }
+    }
     std::vector<void *> key;
     key.push_back((void *)(intptr_t)count);
     for (int i = 0; i < k; i++) {
@@ -1518,7 +1542,7 @@ int csr5hip_spmv_rotate(csr5hip_handle *hs, void **d_ys, int k, double alpha, in
         hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
             for (int i = 0; i < count && e == hipSuccess; i++)
-                e = enqueue_spmv(hs[i % k], d_ys[i % k], cs);
+                e = enqueue_spmv(hs[i % k], d_ys[i % k], cs, true);
             hipError_t e2 = hipStreamEndCapture(cs, &graph);
             if (e == hipSuccess)
                 e = e2;

@@ -18,6 +18,10 @@
 //     offset[] (requested together with the gathers, so the stores do not wait for a further round trip).
 #include "csr5_carry.h"
 
+#ifndef CSR5_WALK_ORDER
+#define CSR5_WALK_ORDER 1
+#endif
+
 namespace csr5 {
 
 constexpr uint32_t WALK_EXACT = 0x80000000u; // walk_row bit: the range's first row BEGINS with the range's first element
@@ -246,10 +250,10 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     // gathers of tile `tr` (window base wl, -1 = none): in-window lanes read LDS, the others x through a range-checked buffer
     // load (in-window lanes carry an out-of-range offset there: "return 0, touch no memory"); a bitwise OR merges the two
     auto gather = [&](const WalkTile<VT, SIGMA> &tr, int wl, word_t (&xg)[SIGMA], int32_t (&offv)[SIGMA]) {
-        const int wbase = (XWIN && wl >= 0) ? wl : -0x40000000;
+        const unsigned wbase = (XWIN && wl >= 0) ? (unsigned)wl : 0xC0000000u; // (no window: every column is "outside")
 #pragma unroll
         for (int i = 0; i < SIGMA; i++) {
-            const unsigned dlt = (unsigned)(tr.c[i] - wbase);
+            const unsigned dlt = (unsigned)tr.c[i] - wbase;
             const unsigned off = (XWIN && dlt < (unsigned)XWIN_ELEMS) ? 0xFFFFFFFFu : (unsigned)tr.c[i] * (unsigned)sizeof(VT);
             if constexpr (sizeof(VT) == 8)
                 xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
@@ -275,10 +279,10 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     auto compute = [&](const WalkTile<VT, SIGMA> &tr, int wl, const word_t (&xg)[SIGMA], const int32_t (&offv)[SIGMA]) {
         VT mx[SIGMA];
         if constexpr (XWIN) {
-            const int wbase = wl >= 0 ? wl : -0x40000000;
+            const unsigned wbase = wl >= 0 ? (unsigned)wl : 0xC0000000u;
 #pragma unroll
             for (int i = 0; i < SIGMA; i++) {
-                const unsigned dlt = (unsigned)(tr.c[i] - wbase);
+                const unsigned dlt = (unsigned)tr.c[i] - wbase;
                 const word_t lw = __builtin_bit_cast(word_t, win[dlt < (unsigned)XWIN_ELEMS ? dlt : (unsigned)XWIN_ELEMS]);
                 mx[i] = __builtin_bit_cast(VT, (word_t)(xg[i] | lw));
             }
@@ -429,6 +433,8 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
         win_commit();
     }
     int t = tb;
+#if CSR5_WALK_ORDER == 0
+    // streams of the next tile FIRST, this tile's gathers behind them (the range kernel's order, csr5_hot.hip)
     for (; t + 1 < te; t += 2) {
         int wl2 = -1, wl3 = -1;
         if constexpr (XWIN) {
@@ -460,6 +466,41 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
         __builtin_amdgcn_sched_barrier(0);
         compute(a, wl_cur, xg, offv);
     }
+#else
+    // this tile's gathers FIRST (vector loads return in order: they must not queue behind 12 KB of streams), then the next
+    // tile's window slice and streams, which stay in flight while this tile computes
+    for (; t + 1 < te; t += 2) {
+        int wl2 = -1, wl3 = -1;
+        if constexpr (XWIN) {
+            wl2 = xwc[t + 2 < te ? t + 2 : t + 1];
+            wl3 = xwc[t + 3 < te ? t + 3 : (t + 2 < te ? t + 2 : t + 1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        gather(a, wl_cur, xg, offv);
+        __builtin_amdgcn_sched_barrier(0);
+        win_fetch(wl_next);
+        load(b, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a, wl_cur, xg, offv);
+        win_commit();
+        __builtin_amdgcn_sched_barrier(0);
+        gather(b, wl_next, xg, offv);
+        __builtin_amdgcn_sched_barrier(0);
+        win_fetch(wl2);
+        load(a, t + 2 < te ? t + 2 : t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(b, wl_next, xg, offv);
+        win_commit();
+        wl_cur = wl2;
+        wl_next = wl3;
+    }
+    if (t < te) {
+        __builtin_amdgcn_sched_barrier(0);
+        gather(a, wl_cur, xg, offv);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(a, wl_cur, xg, offv);
+    }
+#endif
 
     // ---- the seams of this range: its lead, and the row that is open at its end --------------------------------------------
     if (open_is_lead)

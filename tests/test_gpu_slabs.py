@@ -434,6 +434,25 @@ def test_permuted_x_live_and_snapshot(oracle):
         y.zero_()
         graph.replay()
         check(2, "snapshot, caller-captured graph")
+        # ... and when an EAGER spmv() ran first (the snapshot is valid while the caller captures): the captured graph must
+        # still carry the copy, or a replay after the caller rewrote x and called setX() would read the old one
+        with torch.cuda.stream(side):
+            assert A.spmv(1.0, y) == 0
+        side.synchronize()
+        graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph2, stream=side):
+                assert A.spmv(1.0, y) == 0
+        xd.mul_(2)
+        torch.cuda.synchronize()
+        assert A.setX(xd) == 0  # same pointer, new contents
+        y.zero_()
+        graph2.replay()
+        check(4, "snapshot, caller-captured graph replayed after x changed + setX")
+        xd.div_(2)
+        torch.cuda.synchronize()
+        assert A.setX(xd) == 0
+        del graph2
         xd.div_(2)
         torch.cuda.synchronize()
         assert A.setStream(torch.cuda.current_stream(DEV)) == 0 and A.setX(xd) == 0
