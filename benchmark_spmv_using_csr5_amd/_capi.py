@@ -65,6 +65,8 @@ class Csr5Info(C.Structure):
         ("slab_values_narrowed", C.c_int),
         ("tile_walk", C.c_int),
         ("walk_ranges", C.c_int),
+        ("walk_x_window", C.c_int),
+        ("walk_x_window_cover_pct", C.c_int),
     ]
 
 

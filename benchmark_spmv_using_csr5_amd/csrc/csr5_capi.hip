@@ -117,6 +117,8 @@ struct csr5hip_handle_s {
     uint32_t *host_words = nullptr;    // 32 pinned, device-visible words the last conversion kernels export into
     int walk_request = 1;        // CSR5HIP_OPT_TILE_WALK: 0 off, 1 auto (default), 2 force
     int walk_ranges_request = 0; // CSR5HIP_OPT_WALK_RANGES: 0 = default
+    int walk_xwin_tiles = 0;     // tiles that got one of the walking kernel's (16-KB) x-windows at conversion
+    long long walk_xwin_covered = 0; // non-zeros inside those windows
     double wall_clock_khz = 0;         // rate of the device's constant wall clock (phase stamps)
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -218,19 +220,6 @@ static int nt_decision(const csr5hip_handle_s *h)
         return 0;
     const long long stream_bytes = (long long)h->g.nnz * (4 + (long long)h->vsize());
     return stream_bytes > 256LL * 1024 * 1024;
-}
-
-// The range-walking pipelined kernel (csr5_walk.hip) instead of one tile per wavefront: forced, or (auto) when every range
-// gets enough tiles for the pipeline to pay -- with fewer, all tiles are resident at once anyway and the one-tile kernel's
-// short-spill ownership saves the ranges' arrival atomics.
-static int walk_decision(const csr5hip_handle_s *h)
-{
-    if (h->walk_request == 0 || h->is_child || h->d.walk_ranges <= 0 || h->opt.mode != 1 ||
-        !walk_supported(h->g, (int)h->vsize(), h->opt.x_window))
-        return 0;
-    if (h->walk_request == 2)
-        return 1;
-    return (long long)(h->g.p - 1) >= (long long)WALK_AUTO_MIN_TILES_PER_RANGE * h->d.walk_ranges;
 }
 
 extern "C" {
@@ -344,7 +333,7 @@ int csr5hip_set_sigma(csr5hip_handle h, int sigma)
 
 static int build_slabs(csr5hip_handle h);
 static int build_slabs_impl(csr5hip_handle h);
-static hipError_t build_walk_tables(csr5hip_handle h);
+static int prepare_walk(csr5hip_handle h);
 
 int csr5hip_set_option(csr5hip_handle h, int option, int value)
 {
@@ -355,8 +344,11 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         if (value != 0 && value != 1)
             return CSR5HIP_INVALID_ARGUMENT;
         h->opt.mode = value;
-        if (h->format == CSR5HIP_FORMAT_CSR5)
-            h->opt.walk = walk_decision(h);
+        if (h->format == CSR5HIP_FORMAT_CSR5) {
+            const int rc = prepare_walk(h);
+            if (rc != CSR5HIP_SUCCESS)
+                return rc;
+        }
         if (h->slab_S > 0 && h->slab_child->hot_enabled && value != 1) {
             // the hot table exists for the fused kernel only and its column words are encoded: rebuild without it
             h->drop_graphs();
@@ -386,7 +378,9 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         h->xwin_request = value;
         if (h->format == CSR5HIP_FORMAT_CSR5) {
             h->opt.x_window = xwin_decision(h);
-            h->opt.walk = walk_decision(h);
+            const int rc = prepare_walk(h);
+            if (rc != CSR5HIP_SUCCESS)
+                return rc;
         }
         break;
     case CSR5HIP_OPT_COLUMN_SLABS:
@@ -437,23 +431,20 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         }
         break;
     case CSR5HIP_OPT_TILE_WALK:
-        if (value < 0 || value > 2)
-            return CSR5HIP_INVALID_ARGUMENT;
-        h->walk_request = value;
-        if (h->format == CSR5HIP_FORMAT_CSR5)
-            h->opt.walk = walk_decision(h);
-        break;
     case CSR5HIP_OPT_WALK_RANGES:
-        if (value < 0 || value > WALK_MAX_RANGES)
-            return CSR5HIP_INVALID_ARGUMENT;
-        h->walk_ranges_request = value;
-        if (h->format == CSR5HIP_FORMAT_CSR5 && h->g.p > 1 && !h->is_child) {
-            // the ranges change: their tables again (no partial is parked between SpMVs, so the arrival words are all zero)
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            HIP_TRY(build_walk_tables(h));
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            h->opt.walk_long_runs = h->d.walk_ranges > 0 && h->host_words[16] != 0;
-            h->opt.walk = walk_decision(h);
+        if (option == CSR5HIP_OPT_TILE_WALK) {
+            if (value < 0 || value > 2)
+                return CSR5HIP_INVALID_ARGUMENT;
+            h->walk_request = value;
+        } else {
+            if (value < 0 || value > WALK_MAX_RANGES)
+                return CSR5HIP_INVALID_ARGUMENT;
+            h->walk_ranges_request = value;
+        }
+        if (h->format == CSR5HIP_FORMAT_CSR5) {
+            const int rc = prepare_walk(h);
+            if (rc != CSR5HIP_SUCCESS)
+                return rc;
         }
         break;
     case CSR5HIP_OPT_SLAB_MEMORY_MIB:
@@ -526,7 +517,8 @@ static int reserve_aux(csr5hip_handle h)
     const size_t o_wacc = take(wr * h->vsize()), o_wcnt = take(wr * 4);
     const size_t zero_bytes = off;
     const size_t o_meta = take(p1 * 16), o_hdr = take(p1 * 32), o_scan = take(h->scan_tmp_bytes);
-    const size_t o_wrow = take(wr * 4), o_wmeta = take(wr * 16), o_wlead = take(wr * h->vsize()), o_xwin = take(p1 * 4);
+    const size_t o_wrow = take(wr * 4), o_wmeta = take(wr * 16), o_wlead = take(wr * h->vsize()),
+                 o_xwin = take(walk_tables ? p1 * 4 : 0), o_xcov = take(walk_tables ? p1 * 4 : 0);
     HIP_TRY(h->b_arena.reserve(off));
     char *base = (char *)h->b_arena.ptr;
     h->d.tile_desc = (uint32_t *)(base + o_desc);
@@ -546,7 +538,8 @@ static int reserve_aux(csr5hip_handle h)
     h->d.walk_row = walk_tables ? (uint32_t *)(base + o_wrow) : nullptr;
     h->d.walk_meta = walk_tables ? (uint32_t *)(base + o_wmeta) : nullptr;
     h->d.walk_lead = walk_tables ? base + o_wlead : nullptr;
-    h->d.xwin_base = (int32_t *)(base + o_xwin);
+    h->d.xwin_base = walk_tables ? (int32_t *)(base + o_xwin) : nullptr;
+    h->d.xwin_cover = walk_tables ? (int32_t *)(base + o_xcov) : nullptr;
     HIP_TRY(hipMemsetAsync(base, 0, zero_bytes, s));
     return CSR5HIP_SUCCESS; // stream-ordered: the conversion kernels follow on the same stream
 }
@@ -574,24 +567,67 @@ static void finish_format_scalars(csr5hip_handle h)
     h->num_offsets = (int)h->scalar_words[1];
 }
 
-// the range-walking kernel's tables (csr5_walk.hip): how many ranges the tiles 0 .. p-2 are dealt to, and the arrival protocol
-// of those ranges.  Stream-ordered; host_words[16] = number of rows spanning more than RUN_SERIAL_MAX ranges, valid after the
-// next synchronisation.
+// ---- the range-walking pipelined kernel (csr5_walk.hip) ------------------------------------------------------------------
+// its x-window variant: forced with the one-tile kernel's (CSR5HIP_OPT_X_WINDOW = 2), or (auto) when the 16-KB windows found at
+// conversion cover at least 70 % of the non-zeros of tiles 0 .. p-2.  No sigma / spread conditions as for the one-tile kernel: a
+// walking wavefront restages its slice of x once per range or so, not once per tile.
+static int walk_xwin_decision(const csr5hip_handle_s *h)
+{
+    if (h->xwin_request == 2)
+        return 1;
+    if (h->xwin_request != 1 || h->walk_xwin_tiles <= 0)
+        return 0;
+    return h->walk_xwin_covered * 100 >= (long long)(h->g.p - 1) * h->g.tile_elems * 70;
+}
+// how many ranges (= wavefronts, one per workgroup) the tiles 0 .. p-2 are dealt to: as set, or 8 per CU -- fewer when the
+// wavefronts' LDS (y-compaction region + 16-KB slice of x) does not let eight of them share a CU's 160 KB
 static int walk_ranges_for(const csr5hip_handle_s *h)
 {
-    if (h->is_child || !h->d.walk_row || h->g.p <= 1)
-        return 0;
-    int want = h->walk_ranges_request > 0 ? h->walk_ranges_request : WALK_DEFAULT_RANGES;
+    int want = h->walk_ranges_request;
+    if (want <= 0) {
+        static int cus = 0; // (written once with the same value by whoever comes first)
+        if (cus <= 0) {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                n = 256;
+            cus = n;
+        }
+        const int lds = walk_wave_lds_bytes(h->g.sigma, (int)h->vsize(), h->opt.walk_x_window);
+        int per_cu = (160 * 1024) / (lds > 0 ? lds : 1);
+        per_cu = per_cu > WALK_DEFAULT_WAVES_PER_CU ? WALK_DEFAULT_WAVES_PER_CU : (per_cu < 1 ? 1 : per_cu);
+        want = cus * per_cu;
+    }
     want = want > WALK_MAX_RANGES ? WALK_MAX_RANGES : want;
     return want < h->g.p - 1 ? want : h->g.p - 1;
 }
-static hipError_t build_walk_tables(csr5hip_handle h)
+// Decides whether spmv() runs the walking kernel and, if so, builds its range tables (one small kernel + one synchronisation:
+// the number of rows spanning more than RUN_SERIAL_MAX ranges comes back in host_words[16]).  Forced, or (auto) when every
+// range gets enough tiles for the pipeline to pay -- with fewer, all tiles are resident at once anyway and the one-tile
+// kernel's short-spill ownership saves the ranges' arrival atomics.  No partial is parked between SpMVs, so the arrival words
+// are all zero whenever the ranges change.
+static int prepare_walk(csr5hip_handle h)
 {
-    h->d.walk_ranges = walk_ranges_for(h);
-    if (h->d.walk_ranges <= 0)
-        return hipSuccess;
+    h->opt.walk = 0;
+    h->opt.walk_long_runs = 0;
+    h->opt.walk_x_window = 0;
+    h->d.walk_ranges = 0;
+    if (h->walk_request == 0 || h->is_child || h->slab_S > 0 || !h->d.walk_row || h->opt.mode != 1 || h->opt.hot ||
+        !walk_supported(h->g, (int)h->vsize()))
+        return CSR5HIP_SUCCESS;
+    h->opt.walk_x_window = walk_xwin_decision(h);
+    const int ranges = walk_ranges_for(h);
+    if (ranges <= 0)
+        return CSR5HIP_SUCCESS;
+    if (h->walk_request != 2 && (long long)(h->g.p - 1) < (long long)WALK_AUTO_MIN_TILES_PER_RANGE * ranges)
+        return CSR5HIP_SUCCESS;
+    h->d.walk_ranges = ranges;
     h->host_words[16] = 0;
-    return launch_walk_tables(h->g, h->d, h->host_words + 16, h->stream);
+    HIP_TRY(launch_walk_tables(h->g, h->d, h->host_words + 16, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->opt.walk_long_runs = h->host_words[16] != 0;
+    h->opt.walk = 1;
+    h->drop_graphs();
+    return CSR5HIP_SUCCESS;
 }
 
 // what the fused kernel needs on top of the reference's format arrays: carry meta, x windows, tile headers
@@ -611,9 +647,7 @@ static int derive_kernel_tables(csr5hip_handle h)
     }
     // carry_meta + x-windows + fused-kernel headers in one launch, then the export of the host's words
     HIP_TRY(launch_tile_tables(g, h->d, (int)h->vsize(), h->host_words, h->is_child && h->hot_enabled, s));
-    HIP_TRY(build_walk_tables(h)); // (the same synchronisation covers its one exported word)
     HIP_TRY(hipStreamSynchronize(s));
-    h->opt.walk_long_runs = h->d.walk_ranges > 0 && h->host_words[16] != 0;
     const uint32_t *w = h->host_words;
     h->scalar_words[0] = w[0];
     h->scalar_words[1] = w[1];
@@ -622,6 +656,8 @@ static int derive_kernel_tables(csr5hip_handle h)
     h->xwin_covered = (long long)w[3];
     h->opt.long_runs = w[4] != 0;
     h->xwin_lines = (long long)w[5];
+    h->walk_xwin_tiles = (int)w[6];
+    h->walk_xwin_covered = (long long)w[7];
     // phase times from the kernels' wall-clock stamps (k_row_scan, k_tile_desc, k_transpose, k_tile_tables); a phase
     // whose kernel did not run (single-tile matrices) has no stamp and takes the next one's
     unsigned long long st[4];
@@ -662,7 +698,6 @@ static void resolve_variants(csr5hip_handle h)
     h->opt.lds_y = ldsy_decision(h);
     h->opt.stream_nt = nt_decision(h);
     h->opt.hot = h->hot_enabled ? 1 : 0;
-    h->opt.walk = walk_decision(h);
 }
 
 int csr5hip_as_csr5(csr5hip_handle h)
@@ -722,7 +757,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
     }
     resolve_variants(h);
     h->format = CSR5HIP_FORMAT_CSR5;
-    rc = build_slabs(h);
+    rc = build_slabs(h); // (ends with prepare_walk when the plain path serves spmv())
     if (rc != CSR5HIP_SUCCESS) {
         // only when the structure was requested explicitly: a failed asCSR5 leaves CSR, as in the reference
         // (anonymouslib_cuda.h:105-220 returns before _format changes)
@@ -818,15 +853,17 @@ static int build_slabs(csr5hip_handle h)
 {
     h->slab_fallback = false;
     const int rc = build_slabs_impl(h);
-    if (rc == CSR5HIP_SUCCESS)
-        return rc;
+    if (rc == CSR5HIP_SUCCESS) // (the plain path serves spmv() when no structure is active: its walking kernel's tables, if wanted)
+        return h->slab_S > 0 || h->is_child ? rc : prepare_walk(h);
     const std::string why = g_last_error;
     (void)hipGetLastError(); // clear a sticky allocation error
     release_slabs(h);
     h->slab_fallback = true;
     h->drop_graphs();
     g_last_error = "column slabs not built, plain tile kernel in use: " + why;
-    return h->slab_request >= 2 ? rc : CSR5HIP_SUCCESS;
+    if (h->slab_request >= 2)
+        return rc;
+    return prepare_walk(h);
 }
 
 static int build_slabs_impl(csr5hip_handle h)
@@ -1398,7 +1435,7 @@ int csr5hip_load(const char *path, csr5hip_handle *out, csr5hip_csr *arrays)
     fclose(f);
     resolve_variants(h);
     h->format = CSR5HIP_FORMAT_CSR5;
-    rc = build_slabs(h);
+    rc = build_slabs(h); // (ends with prepare_walk when the plain path serves spmv())
     if (rc != CSR5HIP_SUCCESS) {
         csr5hip_free(h);
         csr5hip_csr_release(arrays);
@@ -1685,6 +1722,11 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
     info->tile_walk = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.walk ? 1 : 0;
     info->walk_ranges = h->format == CSR5HIP_FORMAT_CSR5 ? h->d.walk_ranges : 0;
+    info->walk_x_window = info->tile_walk && h->opt.walk_x_window ? 1 : 0;
+    {
+        const long long body = (long long)(h->g.p > 1 ? h->g.p - 1 : 0) * h->g.tile_elems;
+        info->walk_x_window_cover_pct = h->format == CSR5HIP_FORMAT_CSR5 && body > 0 ? (int)(h->walk_xwin_covered * 100 / body) : 0;
+    }
     long long bytes = (long long)h->b_arena.cap;
     for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_val32, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
                             &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_range_head, &h->b_slab_tmp,

@@ -451,7 +451,8 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
                                                        const int32_t *__restrict__ col,
                                                        uint4 *__restrict__ carry_meta, uint32_t *__restrict__ hdr,
                                                        uint32_t *__restrict__ counters, int XWIN_ELEMS,
-                                                       int line_shift, int32_t *__restrict__ xwin_base)
+                                                       int line_shift, int WALK_XWIN_ELEMS,
+                                                       int32_t *__restrict__ xwin_base, int32_t *__restrict__ xwin_cover)
 {
     stamp_phase(counters, 3);
     uint32_t *const long_run_counter = counters + 2;
@@ -468,23 +469,22 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
         meta = tile_carry_meta(g, row_ptr, tile_ptr, t + lane, lane == 0 ? long_run_counter : nullptr);
     const unsigned next_x = (unsigned)__builtin_amdgcn_readlane((int)meta.x, 1);
 
-    unsigned window = 0, stats = 0;
-    if (windowed) {
-        const int hi_limit = g.n > XWIN_ELEMS ? g.n - XWIN_ELEMS : 0;
+    // window selection for XE columns: {first column, non-zeros inside} of the best candidate, {-1, 0} if it covers less than
+    // XWIN_MIN_COVER_PCT % of the tile.  quantum > 1: bases are multiples of it, so that consecutive tiles whose columns drift
+    // slowly (banded matrices) ask for the SAME slice of x, which the range-walking kernel keeps staged (csr5_walk.hip).
+    auto pick_window = [&](int XE, int quantum, int *inside_out) -> int {
+        const int hi_limit = g.n > XE ? g.n - XE : 0;
         auto window_of = [&](int centre) {
-            int lo = centre - XWIN_ELEMS / 2;
+            int lo = centre - XE / 2;
             lo = lo < 0 ? 0 : (lo > hi_limit ? hi_limit : lo);
-            // bases are multiples of an eighth of a window: consecutive tiles whose columns drift slowly (banded matrices)
-            // then ask for the SAME slice of x, which the range-walking kernel keeps staged (csr5_walk.hip)
-            const int quantum = XWIN_ELEMS / 8;
-            return lo / quantum * quantum;
+            return quantum > 1 ? lo / quantum * quantum : lo & ~3;
         };
         // score every lane's candidate on the 64 samples (v_readlane broadcasts, no LDS shuffles)
         const int my_lo = window_of(sample);
         int score = 0;
 #pragma unroll
         for (int j = 0; j < OMEGA; j++)
-            score += (unsigned)(__builtin_amdgcn_readlane(sample, j) - my_lo) < (unsigned)XWIN_ELEMS;
+            score += (unsigned)(__builtin_amdgcn_readlane(sample, j) - my_lo) < (unsigned)XE;
         // best candidate: highest score, lowest lane on ties (deterministic)
         int best = score * OMEGA + (OMEGA - 1 - lane);
 #pragma unroll
@@ -494,37 +494,54 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
         }
         const int best_all = __builtin_amdgcn_readfirstlane(best);
         const int lo = __builtin_amdgcn_readlane(my_lo, OMEGA - 1 - (best_all % OMEGA));
+        *inside_out = 0;
         // The 64 samples are every sigma-th element of the tile.  A window that holds fewer than a quarter of the samples
         // it would need cannot cover XWIN_MIN_COVER_PCT % of the tile: such tiles (every tile of a matrix with scattered
         // columns) are left without reading their other column words -- 1 GB and 0.3 ms of this pass on R-MAT 24.
-        if ((best_all / OMEGA) * 400 >= OMEGA * XWIN_MIN_COVER_PCT) {
-            int inside = 0;
-            for (int i = 0; i < g.sigma; i++)
-                inside += (unsigned)(c[i * OMEGA] - lo) < (unsigned)XWIN_ELEMS;
-            inside = wave_sum_i32(inside);
-            if (inside * 100 >= g.tile_elems * XWIN_MIN_COVER_PCT) {
-                // How many distinct 128-byte lines of x do the in-window lanes of ONE gather instruction (the 64 samples)
-                // touch?  That is what the window replaces: a gather spread over 30+ lines costs 60+ clk in the
-                // vector-memory path, one that sits on a handful of lines is cheap and the staging would cost more than
-                // it saves.
-                const bool in_win = (unsigned)(sample - lo) < (unsigned)XWIN_ELEMS;
-                const int line = sample >> line_shift;
-                bool first = in_win;
+        if ((best_all / OMEGA) * 400 < OMEGA * XWIN_MIN_COVER_PCT)
+            return -1;
+        int inside = 0;
+        for (int i = 0; i < g.sigma; i++)
+            inside += (unsigned)(c[i * OMEGA] - lo) < (unsigned)XE;
+        inside = wave_sum_i32(inside);
+        if (inside * 100 < g.tile_elems * XWIN_MIN_COVER_PCT)
+            return -1;
+        *inside_out = inside;
+        return lo;
+    };
+    unsigned window = 0, stats = 0;
+    int walk_lo = -1, walk_inside = 0;
+    if (windowed) {
+        int inside = 0;
+        const int lo = pick_window(XWIN_ELEMS, 1, &inside);
+        if (lo >= 0) {
+            // How many distinct 128-byte lines of x do the in-window lanes of ONE gather instruction (the 64 samples)
+            // touch?  That is what the window replaces: a gather spread over 30+ lines costs 60+ clk in the
+            // vector-memory path, one that sits on a handful of lines is cheap and the staging would cost more than
+            // it saves.
+            const bool in_win = (unsigned)(sample - lo) < (unsigned)XWIN_ELEMS;
+            const int line = sample >> line_shift;
+            bool first = in_win;
 #pragma unroll
-                for (int j = 0; j < OMEGA - 1; j++) {
-                    const int other = __builtin_amdgcn_readlane(line, j);
-                    const bool other_in = (__builtin_amdgcn_readlane((int)in_win, j) != 0);
-                    first = first && !(j < lane && other_in && other == line);
-                }
-                const int lines = __popcll(__ballot(first));
-                window = (unsigned)lo + 1u;
-                stats = (unsigned)inside | ((unsigned)lines << 16);
+            for (int j = 0; j < OMEGA - 1; j++) {
+                const int other = __builtin_amdgcn_readlane(line, j);
+                const bool other_in = (__builtin_amdgcn_readlane((int)in_win, j) != 0);
+                first = first && !(j < lane && other_in && other == line);
             }
+            const int lines = __popcll(__ballot(first));
+            window = (unsigned)lo + 1u;
+            stats = (unsigned)inside | ((unsigned)lines << 16);
         }
+        // the range-walking kernel's own, larger window (a wavefront that walks a range of tiles restages rarely)
+        if (xwin_base)
+            walk_lo = pick_window(WALK_XWIN_ELEMS, WALK_XWIN_ELEMS / 8, &walk_inside);
     }
     if (lane == 0) {
         meta.w = window;
-        xwin_base[t] = (int)window - 1; // dense copy for the range-walking kernel: one scalar load per tile
+        if (xwin_base) { // dense arrays for the range-walking kernel: one scalar load per tile
+            xwin_base[t] = walk_lo;
+            xwin_cover[t] = walk_inside;
+        }
         carry_meta[t] = meta;
         reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t] = meta;
         reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t + 1] = make_uint4(next_x, tile_ptr[t], tile_ptr[t + 1], stats);
@@ -542,10 +559,11 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
                                                        const uint32_t *__restrict__ hdr,
                                                        const int32_t *__restrict__ offset_ptr,
                                                        uint32_t *__restrict__ counters,
-                                                       uint32_t *__restrict__ host_words, int export_only)
+                                                       uint32_t *__restrict__ host_words, int export_only,
+                                                       const int32_t *__restrict__ xwin_cover)
 {
-    __shared__ unsigned part[16][3];
-    unsigned on = 0, in = 0, lines = 0;
+    __shared__ unsigned part[16][5];
+    unsigned on = 0, in = 0, lines = 0, won = 0, win = 0; // (won / win: tiles with / non-zeros inside a walking-kernel window)
     if (export_only)
         stamp_phase(counters, 3); // (k_tile_tables, which stamps this phase, did not run)
     for (int t = blockIdx.x * 1024 + threadIdx.x; t < (export_only ? 0 : g.p - 1); t += gridDim.x * 1024) {
@@ -553,26 +571,39 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
         on += v != 0;
         in += v & 0xFFFFu;
         lines += v >> 16;
+        if (xwin_cover) {
+            const unsigned w = (unsigned)xwin_cover[t];
+            won += w != 0;
+            win += w;
+        }
     }
     on = (unsigned)wave_sum_i32((int)on);
     in = (unsigned)wave_sum_i32((int)in);
     lines = (unsigned)wave_sum_i32((int)lines);
+    won = (unsigned)wave_sum_i32((int)won);
+    win = (unsigned)wave_sum_i32((int)win);
     if ((threadIdx.x & (OMEGA - 1)) == 0) {
         part[threadIdx.x >> 6][0] = on;
         part[threadIdx.x >> 6][1] = in;
         part[threadIdx.x >> 6][2] = lines;
+        part[threadIdx.x >> 6][3] = won;
+        part[threadIdx.x >> 6][4] = win;
     }
     __syncthreads();
     if (threadIdx.x != 0)
         return;
-    on = in = lines = 0;
+    on = in = lines = won = win = 0;
     for (int w = 0; w < 16; w++)
-        on += part[w][0], in += part[w][1], lines += part[w][2];
+        on += part[w][0], in += part[w][1], lines += part[w][2], won += part[w][3], win += part[w][4];
     if (gridDim.x > 1) { // (one workgroup up to 16 k tiles: no atomics, no fence)
         if (on | in) {
             atomicAdd(counters + 0, on);
             atomicAdd(counters + 1, in);
             atomicAdd(counters + 3, lines);
+        }
+        if (won) {
+            atomicAdd(counters + 6, won);
+            atomicAdd(counters + 7, win);
         }
         __threadfence();
         if (atomicAdd(counters + 4, 1u) + 1u != gridDim.x)
@@ -581,13 +612,15 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
         on = __hip_atomic_load(counters + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         in = __hip_atomic_load(counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lines = __hip_atomic_load(counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        won = __hip_atomic_load(counters + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        win = __hip_atomic_load(counters + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!host_words)
         return;
     uint4 *out = reinterpret_cast<uint4 *>(host_words);
     const uint4 *stamps = reinterpret_cast<const uint4 *>(counters + STAMP_WORD);
     out[0] = make_uint4(tile_ptr[g.p - 1], (uint32_t)offset_ptr[g.p], on, in);
-    out[1] = make_uint4(counters[2], lines, 0u, 0u);
+    out[1] = make_uint4(counters[2], lines, won, win);
     out[2] = stamps[0]; // phase stamps 0, 1 (64-bit each)
     out[3] = stamps[1]; // phase stamps 2, 3
 }
@@ -808,19 +841,20 @@ hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int valu
         return hipSuccess;
     if (export_only) {
         hipLaunchKernelGGL(k_stats_export, dim3(1), dim3(1024), 0, s, g, d.tile_ptr, d.tile_hdr, d.offset_ptr, d.counters,
-                           host_words, 1);
+                           host_words, 1, (const int32_t *)nullptr);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_tile_tables, dim3(div_up(g.p, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
                        d.tile_ptr, d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.tile_hdr, d.counters,
-                       xwin_elems(value_size), value_size == 8 ? 4 : 5, d.xwin_base);
+                       xwin_elems(value_size), value_size == 8 ? 4 : 5, WALK_XWIN_BYTES / value_size, d.xwin_base,
+                       d.xwin_cover);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
     int blocks = div_up(g.p, 1024 * 16);
     blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
     hipLaunchKernelGGL(k_stats_export, dim3(blocks), dim3(1024), 0, s, g, d.tile_ptr, d.tile_hdr, d.offset_ptr,
-                       d.counters, host_words, 0);
+                       d.counters, host_words, 0, (const int32_t *)d.xwin_cover);
     return hipGetLastError();
 }
 

@@ -96,7 +96,8 @@ struct DeviceArrays {
     void *walk_lead;           // [walk_ranges + 1] of vT: parked leading partials
     void *walk_acc;            // [walk_ranges + 1] of vT: parked closing partials / exchange words, all zero between launches
     uint32_t *walk_cnt;        // [walk_ranges + 1] arrival counters, all zero between launches
-    int32_t *xwin_base;        // [p] x-window base of every tile (-1 = none): dense copy of carry_meta[t].w - 1
+    int32_t *xwin_base;        // [p] the walking kernel's x-window of every tile (first column, -1 = none); nullptr = not built
+    int32_t *xwin_cover;       // [p] non-zeros of the tile inside that window
 };
 
 // ---- conversion (csr5_format.hip) ----
@@ -157,10 +158,12 @@ struct SpmvOptions {
     int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_range + k_range_finish
     int walk;        // resolved: 1 = the range-walking pipelined kernel (csr5_walk.hip) instead of one tile per wavefront
     int walk_long_runs; // resolved: some row spans > RUN_SERIAL_MAX ranges (the walking kernel adds k_calibrate)
+    int walk_x_window;  // resolved: the walking kernel stages its (larger, rarely restaged) slice of x in LDS
 };
+constexpr int WALK_XWIN_BYTES = 16384;      // the walking kernel's slice of x in LDS per wavefront: 4 096 fp32 / 2 048 fp64 columns
 constexpr int WALK_MAX_SIGMA = 16;          // one descriptor packet per lane, two register sets of sigma elements
 constexpr int WALK_MAX_RANGES = 16384;      // upper bound of CSR5HIP_OPT_WALK_RANGES (k_walk_tables: one workgroup)
-constexpr int WALK_DEFAULT_RANGES = 2048;   // 8 wavefronts per CU
+constexpr int WALK_DEFAULT_WAVES_PER_CU = 8; // default number of ranges = 8 per CU (fewer when their LDS does not fit)
 constexpr int WALK_AUTO_MIN_TILES_PER_RANGE = 4; // auto: the walking kernel runs when every range gets at least this many tiles
 constexpr int HOT_LDS_BYTES = 128 * 1024;  // upper bound of the LDS table of hot x entries per workgroup (k_spmv_range)
 constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_range
@@ -199,7 +202,8 @@ constexpr int hot_child_sigma(int value_size) { return HOT_WAVE_LDS / (OMEGA * v
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s);
 // csr5_walk.hip: range-walking pipelined kernel on the plain format arrays
-bool walk_supported(const Geometry &g, int value_size, int x_window);
+bool walk_supported(const Geometry &g, int value_size);
+int walk_wave_lds_bytes(int sigma, int value_size, int x_window);
 hipError_t launch_walk_tables(const Geometry &g, const DeviceArrays &d, uint32_t *long_runs_out, hipStream_t s);
 hipError_t launch_spmv_walk_f64(const Geometry &g, const DeviceArrays &d, const void *x, void *y, const SpmvOptions &opt,
                                 hipStream_t s);

@@ -12,15 +12,13 @@
 //   * SOFTWARE PIPELINE, two register sets: tile t+1's column / value streams, its descriptor words, its tile_ptr / offset_ptr
 //     pair (scalar cache) and -- x-window variant -- the slice of x it gathers from are requested BEFORE tile t's gathers go out,
 //     so a tile costs one memory round trip (streams of t+1 and gathers of t in flight together) instead of two dependent ones.
-//   * x-window variant: the window base comes from a dense per-tile array (scalar load, two tiles ahead); the staged slice stays in
-//     LDS while consecutive tiles ask for the same base (k_tile_tables quantises the bases, so they do).
+//   * x-window variant: a wavefront that walks a range can afford a LARGE slice of x in LDS (16 KB: 4 096 fp32 / 2 048 fp64
+//     columns, four times the one-tile kernel's) because it restages rarely: the window base comes from a dense per-tile array
+//     (scalar load, two tiles ahead), k_tile_tables quantises the bases, and the staged slice stays while consecutive tiles ask
+//     for the same base.  A tile whose columns ALL lie inside the slice issues no global gather at all.
 //   * a tile's finished rows are compacted in LDS and leave as coalesced stores; tiles with empty rows scatter them through
 //     offset[] (requested together with the gathers, so the stores do not wait for a further round trip).
 #include "csr5_carry.h"
-
-#ifndef CSR5_WALK_ORDER
-#define CSR5_WALK_ORDER 1
-#endif
 
 namespace csr5 {
 
@@ -128,7 +126,7 @@ struct WalkParams {
 template <typename VT, int SIGMA, bool XWIN>
 constexpr int walk_lds_bytes()
 {
-    return OMEGA * SIGMA * (int)sizeof(VT) + (XWIN ? XWIN_BYTES + 16 : 0);
+    return OMEGA * SIGMA * (int)sizeof(VT) + (XWIN ? WALK_XWIN_BYTES + 16 : 0);
 }
 
 template <typename VT, int SIGMA, bool XWIN, bool NT>
@@ -141,8 +139,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     using word_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
     constexpr int T = OMEGA * SIGMA;
     constexpr int BIT_Y = bit_y_of(SIGMA), BIT_ALL = BIT_Y + BIT_SS;
-    constexpr int XWIN_ELEMS = xwin_elems(sizeof(VT));
-    constexpr int XW = XWIN ? XWIN_ELEMS / OMEGA : 1; // window loads per lane
+    constexpr unsigned WXB = WALK_XWIN_BYTES; // bytes of the staged slice of x; slot [WXB] behind it holds +0.0
     extern __shared__ __attribute__((aligned(16))) char smem[];
     VT *const lead = static_cast<VT *>(wp.lead), *const acc = static_cast<VT *>(wp.acc);
 
@@ -179,7 +176,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     const uint32_t next_meta_x = metac[4 * (R + 1)];
 
     auto *seg = (__attribute__((address_space(3))) VT *)(smem);
-    auto *win = (__attribute__((address_space(3))) VT *)(smem + (size_t)T * sizeof(VT)); // [XWIN_ELEMS] + one +0.0 slot
+    auto *win = (__attribute__((address_space(3))) char *)(smem + (size_t)T * sizeof(VT)); // WXB bytes of x + one +0.0 slot
     const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(x), (short)0, g.n * (int)sizeof(VT), 0x00020000);
 
     auto load = [&](WalkTile<VT, SIGMA> &tr, int t) {
@@ -200,34 +197,28 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
             tr.v[i] = NT ? __builtin_nontemporal_load(vt + i * OMEGA) : vt[i * OMEGA];
     };
 
-    // ---- x-window state (XWIN): `staged` = base of the slice of x that sits in LDS; `pend` = base of the slice in xw[] ----------
-    int staged = -1, pend = -1;
-    VT xw[XW];
-    auto win_fetch = [&](int wl) {
+    // ---- x-window (XWIN): `staged` = first column of the slice of x that sits in LDS.  Restaging is rare (once per range
+    //      or so) and blocking: 16-byte pieces, eight per lane in flight, straight into LDS.
+    int staged = -1;
+    auto restage = [&](int wl) {
         if constexpr (XWIN) {
-            pend = -1;
             if (wl >= 0 && wl != staged) { // (wave-uniform)
-                pend = wl;
-                // (slots behind the end of x read 0 through the buffer's range check; no column points there)
-                const unsigned first = (unsigned)(wl + lane) * (unsigned)sizeof(VT);
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                constexpr int PIECES = (int)WXB / 16, CH = 8;
+                // (columns behind the end of x read 0 through the buffer's range check; no column word points there)
+                const unsigned first = (unsigned)wl * (unsigned)sizeof(VT) + (unsigned)lane * 16u;
 #pragma unroll
-                for (int k = 0; k < XW; k++) {
-                    const unsigned off = first + (unsigned)(k * OMEGA) * (unsigned)sizeof(VT);
-                    if constexpr (sizeof(VT) == 8)
-                        xw[k] = __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
-                    else
-                        xw[k] = __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b32(xbuf, off, 0, 0));
+                for (int p0 = 0; p0 < PIECES; p0 += CH * OMEGA) {
+                    u32x4 piece[CH];
+#pragma unroll
+                    for (int k = 0; k < CH; k++)
+                        piece[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                 xbuf, first + (unsigned)(p0 + k * OMEGA) * 16u, 0, 0));
+#pragma unroll
+                    for (int k = 0; k < CH; k++)
+                        *(__attribute__((address_space(3))) u32x4 *)(win + (size_t)(p0 + k * OMEGA + lane) * 16) = piece[k];
                 }
-            }
-        }
-    };
-    auto win_commit = [&]() {
-        if constexpr (XWIN) {
-            if (pend >= 0) {
-#pragma unroll
-                for (int k = 0; k < XW; k++)
-                    win[k * OMEGA + lane] = xw[k];
-                staged = pend;
+                staged = wl;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -247,18 +238,39 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
             y[open_row] = total;
     };
 
-    // gathers of tile `tr` (window base wl, -1 = none): in-window lanes read LDS, the others x through a range-checked buffer
-    // load (in-window lanes carry an out-of-range offset there: "return 0, touch no memory"); a bitwise OR merges the two
-    auto gather = [&](const WalkTile<VT, SIGMA> &tr, int wl, word_t (&xg)[SIGMA], int32_t (&offv)[SIGMA]) {
-        const unsigned wbase = (XWIN && wl >= 0) ? (unsigned)wl : 0xC0000000u; // (no window: every column is "outside")
+    // gathers of tile `tr` (window base wl, -1 = none): in-window lanes will read LDS (compute), the others read x through a
+    // range-checked buffer load (in-window lanes carry an out-of-range offset there: "return 0, touch no memory") and a bitwise
+    // OR merges the two.  A tile whose columns ALL lie in the window issues no buffer load.  Returns "some lane is outside".
+    auto gather = [&](const WalkTile<VT, SIGMA> &tr, int wl, word_t (&xg)[SIGMA], int32_t (&offv)[SIGMA]) -> bool {
+        bool some_out = true;
+        if constexpr (XWIN) {
+            // byte offsets: (c - wl) * sizeof(vT) < WXB  <=>  the column lies in the staged slice
+            const unsigned wbase = wl >= 0 ? (unsigned)wl * (unsigned)sizeof(VT) : 0x80000000u + WXB; // (no window: all outside)
+            bool out = false;
 #pragma unroll
-        for (int i = 0; i < SIGMA; i++) {
-            const unsigned dlt = (unsigned)tr.c[i] - wbase;
-            const unsigned off = (XWIN && dlt < (unsigned)XWIN_ELEMS) ? 0xFFFFFFFFu : (unsigned)tr.c[i] * (unsigned)sizeof(VT);
-            if constexpr (sizeof(VT) == 8)
-                xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
-            else
-                xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b32(xbuf, off, 0, 0));
+            for (int i = 0; i < SIGMA; i++)
+                out |= (unsigned)tr.c[i] * (unsigned)sizeof(VT) - wbase >= WXB;
+            some_out = __ballot(out) != 0ull;
+            if (some_out) {
+#pragma unroll
+                for (int i = 0; i < SIGMA; i++) {
+                    const unsigned boff = (unsigned)tr.c[i] * (unsigned)sizeof(VT);
+                    const unsigned off = boff - wbase >= WXB ? boff : 0xFFFFFFFFu;
+                    if constexpr (sizeof(VT) == 8)
+                        xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
+                    else
+                        xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b32(xbuf, off, 0, 0));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++) {
+                const unsigned off = (unsigned)tr.c[i] * (unsigned)sizeof(VT);
+                if constexpr (sizeof(VT) == 8)
+                    xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
+                else
+                    xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b32(xbuf, off, 0, 0));
+            }
         }
         // empty-row tiles: the row offsets of the tile's segments (csr5_spmv_cuda.h:140-160), one coalesced load per 64 of them,
         // in the same batch as the gathers
@@ -273,19 +285,29 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
                 }
             }
         }
+        return some_out;
     };
 
     // ---- one tile whose loads (streams in `tr`, gathers in `xg`) are in flight or done ----------------------------------------
-    auto compute = [&](const WalkTile<VT, SIGMA> &tr, int wl, const word_t (&xg)[SIGMA], const int32_t (&offv)[SIGMA]) {
+    auto compute = [&](const WalkTile<VT, SIGMA> &tr, int wl, bool some_out, const word_t (&xg)[SIGMA],
+                       const int32_t (&offv)[SIGMA]) {
         VT mx[SIGMA];
         if constexpr (XWIN) {
-            const unsigned wbase = wl >= 0 ? (unsigned)wl : 0xC0000000u;
+            const unsigned wbase = wl >= 0 ? (unsigned)wl * (unsigned)sizeof(VT) : 0x80000000u + WXB;
+            word_t lw[SIGMA];
 #pragma unroll
             for (int i = 0; i < SIGMA; i++) {
-                const unsigned dlt = (unsigned)tr.c[i] - wbase;
-                const word_t lw = __builtin_bit_cast(word_t, win[dlt < (unsigned)XWIN_ELEMS ? dlt : (unsigned)XWIN_ELEMS]);
-                mx[i] = __builtin_bit_cast(VT, (word_t)(xg[i] | lw));
+                const unsigned d = (unsigned)tr.c[i] * (unsigned)sizeof(VT) - wbase;
+                lw[i] = *(const __attribute__((address_space(3))) word_t *)(win + (d < WXB ? d : WXB)); // outside: the +0.0 slot
             }
+            if (some_out) { // (wave-uniform)
+#pragma unroll
+                for (int i = 0; i < SIGMA; i++)
+                    lw[i] |= xg[i];
+            }
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++)
+                mx[i] = __builtin_bit_cast(VT, lw[i]);
         } else {
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
@@ -320,16 +342,21 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
         bool direct = f0 && lane != 0;
         VT sum = tr.v[0] * mx[0];
         VT first_sum = 0;
+        // steps at which NO lane starts a row cost one fused multiply-add: the test is scalar, on the OR of the lanes' flags
+        // (long rows: a tile of nd24k holds two or three row starts in 1 024 elements)
+        const uint32_t any_flags = wave_or(flags);
 #pragma unroll
         for (int i = 1; i < SIGMA; i++) {
-            if ((flags >> (31 - i)) & 1u) {
-                if (direct)
-                    seg[y_off] = sum;
-                else
-                    first_sum = sum;
-                y_off += direct;
-                direct = true;
-                sum = 0;
+            if ((any_flags >> (31 - i)) & 1u) {
+                if ((flags >> (31 - i)) & 1u) {
+                    if (direct)
+                        seg[y_off] = sum;
+                    else
+                        first_sum = sum;
+                    y_off += direct;
+                    direct = true;
+                    sum = 0;
+                }
             }
             sum = __builtin_fma(tr.v[i], mx[i], sum);
         }
@@ -419,7 +446,9 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
         open_is_lead = false;
     };
 
-    // ---- the walk: tiles in pairs (two register sets, no copies), an odd last tile peeled -----------------------------------
+    // ---- the walk: tiles in pairs (two register sets, no copies), an odd last tile peeled ----------------------------------
+    // Order inside a step: this tile's gathers FIRST (vector loads return in order: they must not queue behind 12 KB of
+    // streams), then the next tile's streams, which stay in flight while this tile computes.
     WalkTile<VT, SIGMA> a, b;
     word_t xg[SIGMA];
     int32_t offv[SIGMA];
@@ -428,13 +457,10 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     if constexpr (XWIN) {
         wl_cur = xwc[tb];
         wl_next = xwc[tb + 1 < te ? tb + 1 : tb];
-        win[XWIN_ELEMS] = (VT)0; // what the out-of-window lanes read
-        win_fetch(wl_cur);
-        win_commit();
+        *(__attribute__((address_space(3))) word_t *)(win + WXB) = 0; // what the out-of-window lanes read
+        restage(wl_cur);
     }
     int t = tb;
-#if CSR5_WALK_ORDER == 0
-    // streams of the next tile FIRST, this tile's gathers behind them (the range kernel's order, csr5_hot.hip)
     for (; t + 1 < te; t += 2) {
         int wl2 = -1, wl3 = -1;
         if constexpr (XWIN) {
@@ -442,65 +468,28 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
             wl3 = xwc[t + 3 < te ? t + 3 : (t + 2 < te ? t + 2 : t + 1)];
         }
         __builtin_amdgcn_sched_barrier(0);
+        const bool out_a = gather(a, wl_cur, xg, offv);
+        __builtin_amdgcn_sched_barrier(0);
         load(b, t + 1);
-        win_fetch(wl_next);
         __builtin_amdgcn_sched_barrier(0);
-        gather(a, wl_cur, xg, offv);
+        compute(a, wl_cur, out_a, xg, offv);
+        restage(wl_next);
         __builtin_amdgcn_sched_barrier(0);
-        compute(a, wl_cur, xg, offv);
-        win_commit();
+        const bool out_b = gather(b, wl_next, xg, offv);
         __builtin_amdgcn_sched_barrier(0);
         load(a, t + 2 < te ? t + 2 : t + 1);
-        win_fetch(wl2);
         __builtin_amdgcn_sched_barrier(0);
-        gather(b, wl_next, xg, offv);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(b, wl_next, xg, offv);
-        win_commit();
+        compute(b, wl_next, out_b, xg, offv);
+        restage(wl2);
         wl_cur = wl2;
         wl_next = wl3;
     }
     if (t < te) {
         __builtin_amdgcn_sched_barrier(0);
-        gather(a, wl_cur, xg, offv);
+        const bool out_a = gather(a, wl_cur, xg, offv);
         __builtin_amdgcn_sched_barrier(0);
-        compute(a, wl_cur, xg, offv);
+        compute(a, wl_cur, out_a, xg, offv);
     }
-#else
-    // this tile's gathers FIRST (vector loads return in order: they must not queue behind 12 KB of streams), then the next
-    // tile's window slice and streams, which stay in flight while this tile computes
-    for (; t + 1 < te; t += 2) {
-        int wl2 = -1, wl3 = -1;
-        if constexpr (XWIN) {
-            wl2 = xwc[t + 2 < te ? t + 2 : t + 1];
-            wl3 = xwc[t + 3 < te ? t + 3 : (t + 2 < te ? t + 2 : t + 1)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        gather(a, wl_cur, xg, offv);
-        __builtin_amdgcn_sched_barrier(0);
-        win_fetch(wl_next);
-        load(b, t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a, wl_cur, xg, offv);
-        win_commit();
-        __builtin_amdgcn_sched_barrier(0);
-        gather(b, wl_next, xg, offv);
-        __builtin_amdgcn_sched_barrier(0);
-        win_fetch(wl2);
-        load(a, t + 2 < te ? t + 2 : t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(b, wl_next, xg, offv);
-        win_commit();
-        wl_cur = wl2;
-        wl_next = wl3;
-    }
-    if (t < te) {
-        __builtin_amdgcn_sched_barrier(0);
-        gather(a, wl_cur, xg, offv);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a, wl_cur, xg, offv);
-    }
-#endif
 
     // ---- the seams of this range: its lead, and the row that is open at its end --------------------------------------------
     if (open_is_lead)
@@ -544,13 +533,9 @@ static hipError_t launch_walk_sigma(const Geometry &g, const DeviceArrays &d, co
     switch (g.sigma) {
 #define CSR5_WALK_CASE(S)                                                                                                      \
     case S:                                                                                                                    \
-        if (opt.x_window) {                                                                                                    \
-            if constexpr (S % 4 == 0)                                                                                          \
-                return opt.stream_nt ? launch_walk_one<VT, S, true, true>(g, d, x, y, opt, s)                                  \
-                                     : launch_walk_one<VT, S, true, false>(g, d, x, y, opt, s);                                \
-            else                                                                                                               \
-                return hipErrorInvalidValue;                                                                                   \
-        }                                                                                                                      \
+        if (opt.walk_x_window)                                                                                                 \
+            return opt.stream_nt ? launch_walk_one<VT, S, true, true>(g, d, x, y, opt, s)                                      \
+                                 : launch_walk_one<VT, S, true, false>(g, d, x, y, opt, s);                                    \
         return opt.stream_nt ? launch_walk_one<VT, S, false, true>(g, d, x, y, opt, s)                                         \
                              : launch_walk_one<VT, S, false, false>(g, d, x, y, opt, s);
         CSR5_WALK_CASE(4) CSR5_WALK_CASE(5) CSR5_WALK_CASE(6) CSR5_WALK_CASE(7) CSR5_WALK_CASE(8) CSR5_WALK_CASE(9)
@@ -562,15 +547,17 @@ static hipError_t launch_walk_sigma(const Geometry &g, const DeviceArrays &d, co
 }
 
 #if !defined(CSR5_WALK_ONLY_F32)
-// can the walking kernel run this matrix?  (sigma <= 16: one descriptor packet; x-window variant compiled for sigma 4, 8, 12, 16;
-// x within the reach of a 32-bit buffer offset)
-bool walk_supported(const Geometry &g, int value_size, int x_window)
+// can the walking kernel run this matrix?  (sigma <= 16: one descriptor packet; x within the reach of a 32-bit buffer offset)
+bool walk_supported(const Geometry &g, int value_size)
 {
     if (g.p <= 1 || g.sigma < 4 || g.sigma > WALK_MAX_SIGMA)
         return false;
-    if (x_window && g.sigma % 4 != 0)
-        return false;
     return (long long)g.n * value_size < (1LL << 31);
+}
+// dynamic LDS of one wavefront (= workgroup) of the walking kernel
+int walk_wave_lds_bytes(int sigma, int value_size, int x_window)
+{
+    return OMEGA * sigma * value_size + (x_window ? WALK_XWIN_BYTES + 16 : 0);
 }
 #endif
 

@@ -61,6 +61,18 @@ __device__ __forceinline__ VT wave_sum(VT v)
     v += dpp_move<DPP_ROW_BCAST31>(v);              // rows 2,3 += lane 31 -> lane 63 = wave sum
     return bcast_lane(v, OMEGA - 1);
 }
+// bitwise OR over the 64 lanes, result wave-uniform (same DPP steps as wave_sum)
+__device__ __forceinline__ uint32_t wave_or(uint32_t w)
+{
+    int v = (int)w;
+    v |= dpp_word<DPP_ROW_SHR1>(v);
+    v |= dpp_word<DPP_ROW_SHR2>(v);
+    v |= dpp_word<DPP_ROW_SHR4>(v);
+    v |= dpp_word<DPP_ROW_SHR8>(v);
+    v |= dpp_word<DPP_ROW_BCAST15>(v);
+    v |= dpp_word<DPP_ROW_BCAST31>(v);
+    return (uint32_t)__builtin_amdgcn_readlane(v, OMEGA - 1);
+}
 // sum over lanes 0..count-1 of a value that is ZERO in every other lane (count wave-uniform, 1..64)
 template <typename VT>
 __device__ __forceinline__ VT head_sum(VT v, int count)

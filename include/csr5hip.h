@@ -159,6 +159,8 @@ typedef struct csr5hip_info {
     int slab_values_narrowed;      /* 1 = CSR5HIP_OPT_NARROW_VALUES took effect: the slab kernel streams fp32 values       */
     int tile_walk;                 /* 1 = spmv() launches the range-walking pipelined kernel (CSR5HIP_OPT_TILE_WALK)           */
     int walk_ranges;               /* tile ranges (wavefronts) of that kernel; 0 = its tables were not built                   */
+    int walk_x_window;             /* 1 = it gathers through its 16-KB LDS slice of x (rarely restaged: 4 096 fp32 / 2 048 fp64 columns) */
+    int walk_x_window_cover_pct;   /* share of the non-zeros (tiles 0..p-2) inside their tile's 16-KB window                    */
 } csr5hip_info;
 
 /* anonymouslibHandle(m, n) -- anonymouslib_cuda.h:15.  Uses the current HIP device. */

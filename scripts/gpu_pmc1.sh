@@ -14,6 +14,8 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     if os.environ.get("KFILTER", "k_spmv") in r.get("Kernel_Name", ""):
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+last = int(os.environ.get("KLAST", "0"))  # > 0: only the last KLAST dispatches (the cold-protocol launches of a bench run come last)
 for c, v in sorted(agg.items()):
+    v = v[-last:] if last > 0 else v
     print(f"   {c:34s} n={len(v):3d} avg={sum(v)/len(v):14.1f}")
 PY

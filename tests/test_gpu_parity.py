@@ -70,7 +70,8 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         info_out.update(column_slabs=i.column_slabs, slab_segments=i.slab_segments, slab_sigma=i.slab_sigma,
                         slab_tiles=i.slab_tiles, sigma=i.sigma, slab_hot=i.slab_hot,
                         slab_hot_cover_pct=i.slab_hot_cover_pct, tile_walk=i.tile_walk, walk_ranges=i.walk_ranges,
-                        p=i.p, x_window_active=i.x_window_active)
+                        p=i.p, x_window_active=i.x_window_active, walk_x_window=i.walk_x_window,
+                        walk_x_window_cover_pct=i.walk_x_window_cover_pct)
     col_t = ci.cpu().numpy().copy()
     val_t = va.cpu().numpy().copy()
     ys = []

@@ -55,7 +55,7 @@ def test_walk_x_window_variant(oracle, dtype):
                 info = {}
                 _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=2, nt=nt, walk=2, walk_ranges=ranges,
                                    slabs=0, info_out=info)
-                assert info["tile_walk"] == (1 if fmt.p > 1 else 0) and info["x_window_active"] == 1
+                assert info["tile_walk"] == (1 if fmt.p > 1 else 0) and info["walk_x_window"] == info["tile_walk"]
                 exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
                 assert np.array_equal(ys[0], exp), (mat.name, sigma, nt, ranges, np.flatnonzero(ys[0] != exp)[:8])
             val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=31, mode="real")
@@ -129,6 +129,7 @@ def test_walk_full_size_workloads(oracle, workload):
         arrays, _, _, ys = _run(mat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, dtype=dtype, walk=2,
                                 walk_ranges=ranges, slabs=0, info_out=info, repeat=2)
         assert info["tile_walk"] == 1, info
+        assert info["walk_x_window"] == (1 if workload == "nd24k" else 0), info  # auto: the banded stand-in gets windows
         before_tail = np.arange(mat.m) < arrays["tail_start"]  # (every row of the CSR tail is written, csr5hip.h spmv)
         for y in ys:
             assert np.array_equal(y.astype(np.float64)[nonempty], ref[nonempty]), (workload, ranges)
