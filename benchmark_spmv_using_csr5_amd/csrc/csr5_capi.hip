@@ -369,8 +369,11 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         if (value < 0 || value > 2)
             return CSR5HIP_INVALID_ARGUMENT;
         h->nt_request = value;
-        if (h->format == CSR5HIP_FORMAT_CSR5)
+        if (h->format == CSR5HIP_FORMAT_CSR5) {
             h->opt.stream_nt = nt_decision(h);
+            if (h->is_child && h->hot_enabled) // another instantiation of the range kernel: its LDS limit
+                HIP_TRY(prepare_spmv_hot(h->g, h->d, h->value_type, h->opt));
+        }
         break;
     case CSR5HIP_OPT_X_WINDOW:
         if (value < 0 || value > 2)
@@ -1165,6 +1168,14 @@ static int build_slabs_impl(csr5hip_handle h)
     if (rc != CSR5HIP_SUCCESS) {
         release_slabs(h);
         return rc;
+    }
+    if (c->hot_enabled) { // the range kernel this child launches needs the CU's whole LDS: raised here, once, not per SpMV
+        const hipError_t e = prepare_spmv_hot(c->g, c->d, c->value_type, c->opt);
+        if (e != hipSuccess) {
+            rc = fail_hip(e, "LDS limit of the range kernel");
+            release_slabs(h);
+            return rc;
+        }
     }
     h->slab_S = S;
     h->slab_m2 = (int)m2;

@@ -266,10 +266,9 @@ __host__ __device__ inline int transpose_pitch(int sigma) { return OMEGA + (OMEG
 template <typename VT>
 __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint32_t *__restrict__ tile_ptr,
                                                      int32_t *__restrict__ col, VT *__restrict__ val,
-                                                     int r2c, int tiles_per_block, int values_all,
+                                                     int r2c, int tiles_per_block,
                                                      uint32_t *__restrict__ counters)
 {
-    // values_all: a hot slab child with packed column codes -- only the values move, and EVERY tile 0 .. p-2 does
     stamp_phase(counters, 2);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // A workgroup moves `tiles_per_block` consecutive tiles: the bytes a compute unit has in flight are what bounds this
@@ -287,7 +286,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint3
     if ((int)threadIdx.x < tiles_per_block) {
         const int t = t0 + (int)threadIdx.x;
         // fast-track tiles are not transposed; the test is on the RAW words (format_cuda.h:540)
-        moved[threadIdx.x] = t < g.p - 1 && (values_all || tile_ptr[t] != tile_ptr[t + 1]);
+        moved[threadIdx.x] = t < g.p - 1 && tile_ptr[t] != tile_ptr[t + 1];
     }
     __syncthreads();
     const size_t base = (size_t)t0 * T;
@@ -299,8 +298,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint3
         int i, l;
         if (r2c) { i = idx % sigma; l = idx / sigma; }
         else     { l = idx & (OMEGA - 1); i = idx >> 6; }
-        if (!values_all)
-            sc[tt * per_tile + i * pitch + l] = col[base + e];
+        sc[tt * per_tile + i * pitch + l] = col[base + e];
         sv[tt * per_tile + i * pitch + l] = val[base + e];
     }
     __syncthreads();
@@ -311,8 +309,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_transpose(Geometry g, const uint3
         int i, l;
         if (r2c) { l = idx & (OMEGA - 1); i = idx >> 6; }
         else     { i = idx % sigma; l = idx / sigma; }
-        if (!values_all)
-            col[base + e] = sc[tt * per_tile + i * pitch + l];
+        col[base + e] = sc[tt * per_tile + i * pitch + l];
         val[base + e] = sv[tt * per_tile + i * pitch + l];
     }
 }
@@ -479,26 +476,45 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
             lo = lo < 0 ? 0 : (lo > hi_limit ? hi_limit : lo);
             return quantum > 1 ? lo / quantum * quantum : lo & ~3;
         };
-        // score every lane's candidate on the 64 samples (v_readlane broadcasts, no LDS shuffles)
-        const int my_lo = window_of(sample);
-        int score = 0;
+        int lo, best_score;
+        if (quantum > 1) {
+            // the walking kernel's window: centred on the MEDIAN of the 64 samples -- robust against the few far-off columns of
+            // a banded tile, so the quantised base moves only when the band itself has drifted by a quantum (a best-of-64
+            // choice flips between equally good bases from tile to tile, and every flip is a 16-KB restage)
+            int rank = 0;
 #pragma unroll
-        for (int j = 0; j < OMEGA; j++)
-            score += (unsigned)(__builtin_amdgcn_readlane(sample, j) - my_lo) < (unsigned)XE;
-        // best candidate: highest score, lowest lane on ties (deterministic)
-        int best = score * OMEGA + (OMEGA - 1 - lane);
+            for (int j = 0; j < OMEGA; j++) {
+                const int o = __builtin_amdgcn_readlane(sample, j);
+                rank += o < sample || (o == sample && j < lane);
+            }
+            const unsigned long long mid = __ballot(rank == OMEGA / 2);
+            const int median = __builtin_amdgcn_readlane(sample, __builtin_ctzll(mid));
+            lo = window_of(median);
+            int in = (unsigned)(sample - lo) < (unsigned)XE;
+            best_score = __popcll(__ballot(in));
+        } else {
+            // score every lane's candidate on the 64 samples (v_readlane broadcasts, no LDS shuffles)
+            const int my_lo = window_of(sample);
+            int score = 0;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const int o = __shfl_xor(best, d, OMEGA);
-            best = o > best ? o : best;
+            for (int j = 0; j < OMEGA; j++)
+                score += (unsigned)(__builtin_amdgcn_readlane(sample, j) - my_lo) < (unsigned)XE;
+            // best candidate: highest score, lowest lane on ties (deterministic)
+            int best = score * OMEGA + (OMEGA - 1 - lane);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const int o = __shfl_xor(best, d, OMEGA);
+                best = o > best ? o : best;
+            }
+            const int best_all = __builtin_amdgcn_readfirstlane(best);
+            lo = __builtin_amdgcn_readlane(my_lo, OMEGA - 1 - (best_all % OMEGA));
+            best_score = best_all / OMEGA;
         }
-        const int best_all = __builtin_amdgcn_readfirstlane(best);
-        const int lo = __builtin_amdgcn_readlane(my_lo, OMEGA - 1 - (best_all % OMEGA));
         *inside_out = 0;
         // The 64 samples are every sigma-th element of the tile.  A window that holds fewer than a quarter of the samples
         // it would need cannot cover XWIN_MIN_COVER_PCT % of the tile: such tiles (every tile of a matrix with scattered
         // columns) are left without reading their other column words -- 1 GB and 0.3 ms of this pass on R-MAT 24.
-        if ((best_all / OMEGA) * 400 < OMEGA * XWIN_MIN_COVER_PCT)
+        if (best_score * 400 < OMEGA * XWIN_MIN_COVER_PCT)
             return -1;
         int inside = 0;
         for (int i = 0; i < g.sigma; i++)
@@ -780,7 +796,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_transpose_values(Geometry g, VT *
     }
 }
 
-static hipError_t transpose_launch(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c, bool values_all, hipStream_t s)
+hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c, hipStream_t s)
 {
     if (g.p <= 1)
         return hipSuccess;
@@ -792,16 +808,11 @@ static hipError_t transpose_launch(const Geometry &g, const DeviceArrays &d, int
     const dim3 grid((unsigned)((g.p - 1 + tpb - 1) / tpb));
     if (value_type == CSR5HIP_F64)
         hipLaunchKernelGGL(k_transpose<double>, grid, dim3(FMT_BLOCK), lds, s, g, d.tile_ptr, d.col, (double *)d.val, r2c ? 1 : 0, tpb,
-                           values_all ? 1 : 0, r2c ? d.counters : nullptr);
+                           r2c ? d.counters : nullptr);
     else
         hipLaunchKernelGGL(k_transpose<float>, grid, dim3(FMT_BLOCK), lds, s, g, d.tile_ptr, d.col, (float *)d.val, r2c ? 1 : 0, tpb,
-                           values_all ? 1 : 0, r2c ? d.counters : nullptr);
+                           r2c ? d.counters : nullptr);
     return hipGetLastError();
-}
-
-hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_type, bool r2c, hipStream_t s)
-{
-    return transpose_launch(g, d, value_type, r2c, false, s);
 }
 
 hipError_t launch_transpose_values(const Geometry &g, const DeviceArrays &d, int value_type, hipStream_t s)
@@ -814,16 +825,12 @@ hipError_t launch_transpose_values(const Geometry &g, const DeviceArrays &d, int
     return hipGetLastError();
     if (value_type == CSR5HIP_F64) {
         switch (g.sigma) {
-        case 4: CSR5_TV(double, 4)
         case 8: CSR5_TV(double, 8)
-        case 12: CSR5_TV(double, 12)
         case 16: CSR5_TV(double, 16)
         }
     } else {
         switch (g.sigma) {
-        case 4: CSR5_TV(float, 4)
         case 8: CSR5_TV(float, 8)
-        case 12: CSR5_TV(float, 12)
         case 16: CSR5_TV(float, 16)
         }
     }

@@ -246,7 +246,7 @@ k_spmv_range(Geometry g, const ST *__restrict__ val, const uint32_t *__restrict_
                 VT s = 0;
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++)
-                    s = __builtin_fma((VT)tr.v[i], mx[i], s);
+                    s = fma_vt((VT)tr.v[i], mx[i], s);
                 open.val += wave_sum(s);
                 return;
             }
@@ -265,7 +265,7 @@ k_spmv_range(Geometry g, const ST *__restrict__ val, const uint32_t *__restrict_
                     direct = true;
                     sum = 0;
                 }
-                sum = __builtin_fma((VT)tr.v[i], mx[i], sum);
+                sum = fma_vt((VT)tr.v[i], mx[i], sum);
             }
             if (!direct)
                 first_sum = sum;
@@ -673,8 +673,11 @@ hipError_t launch_narrow(const double *v, size_t n, float *o, int tile_elems, in
 }
 
 // ---- dispatch ----------------------------------------------------------------------------------------------------------
+// prepare_only: raise the LDS limit of the instantiation this child will launch (160 KB of dynamic LDS) and return.  Done
+// once per conversion (csr5_capi.hip build_slabs), not per SpMV and not cached in a process-wide table: the attribute belongs to
+// the (device, kernel) pair the handle was converted on, and no two host threads ever race on shared state for it.
 template <typename VT, int SIGMA, bool NT, typename ST = VT>
-static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const void *x, void *y, hipStream_t s)
+static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const void *x, void *y, hipStream_t s, bool prepare_only)
 {
     HotParams hp{d.hot_slabs, d.hot_slabs / NUM_XCD, d.hot_capacity, d.hot_count, d.hot_tile0, d.col_lo,
                  d.col_hi,    d.slab_off,             d.xperm,        d.cold_base, d.cold_total};
@@ -682,24 +685,14 @@ static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const v
     constexpr int DEPTH = CSR5_HOT_DEPTH;
     if constexpr (std::is_same<VT, double>::value && std::is_same<ST, double>::value) {
         if (d.val32) // the child's values are kept as fp32 (every one of them exactly): the instantiation that streams 4-byte values
-            return launch_range<VT, SIGMA, NT, float>(g, d, x, y, s);
+            return launch_range<VT, SIGMA, NT, float>(g, d, x, y, s, prepare_only);
     }
     auto kern = k_spmv_range<VT, SIGMA, NT, DEPTH, ST>;
     const ST *val = std::is_same<ST, VT>::value ? (const ST *)d.val : (const ST *)d.val32;
-    // the LDS limit of this instantiation is raised once per device and size, not on every SpMV (a host-side driver call
-    // in front of a launch of a few hundred microseconds; `lds` depends only on the table capacity and the value type)
-    static int lds_set[64]; // [device]: the size the attribute was last set to (0 = never)
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess)
-        return e;
-    if (dev < 0 || dev >= 64 || lds_set[dev] != (int)lds) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess)
-            return e;
-        if (dev >= 0 && dev < 64)
-            lds_set[dev] = (int)lds;
-    }
+    if (prepare_only)
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024); // (the CU's whole LDS: the same value from every handle, whatever its table size)
+    hipError_t e = hipSuccess;
     if (g.p > 1) {
         hipLaunchKernelGGL(kern, dim3(NUM_XCD * HOT_WGS_PER_XCD), dim3(HOT_BLOCK), lds, s, g, val, d.tile_ptr, (VT *)y,
                            (VT *)d.range_lead, hp);
@@ -727,7 +720,8 @@ hipError_t launch_range_heads(const Geometry &g, const DeviceArrays &d, hipStrea
 // a hot child is converted at sigma = hot_child_sigma(): 8 for fp64, 16 for fp32 (whole dwords of column codes per lane,
 // a tile's segments fit the y-compaction region)
 template <typename VT>
-static hipError_t launch_range_sigma(const Geometry &g, const DeviceArrays &d, const void *x, void *y, bool nt, hipStream_t s)
+static hipError_t launch_range_sigma(const Geometry &g, const DeviceArrays &d, const void *x, void *y, bool nt, hipStream_t s,
+                                     bool prepare_only)
 {
     if (!d.col_lo || !d.xperm)
         return hipErrorInvalidValue;
@@ -735,7 +729,8 @@ static hipError_t launch_range_sigma(const Geometry &g, const DeviceArrays &d, c
 #define CSR5_HOT_CASE(S)                                                                                               \
     case S:                                                                                                            \
         if constexpr ((size_t)OMEGA * S * sizeof(VT) <= (size_t)HOT_WAVE_LDS)                                          \
-            return nt ? launch_range<VT, S, true>(g, d, x, y, s) : launch_range<VT, S, false>(g, d, x, y, s);         \
+            return nt ? launch_range<VT, S, true>(g, d, x, y, s, prepare_only)                                         \
+                      : launch_range<VT, S, false>(g, d, x, y, s, prepare_only);                                       \
         else                                                                                                           \
             return hipErrorInvalidValue;
         CSR5_HOT_CASE(8) CSR5_HOT_CASE(16)
@@ -750,8 +745,17 @@ hipError_t launch_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_t
 {
     if (g.p <= 0)
         return hipSuccess;
-    return value_type == CSR5HIP_F64 ? launch_range_sigma<double>(g, d, x, y, opt.stream_nt != 0, s)
-                                     : launch_range_sigma<float>(g, d, x, y, opt.stream_nt != 0, s);
+    return value_type == CSR5HIP_F64 ? launch_range_sigma<double>(g, d, x, y, opt.stream_nt != 0, s, false)
+                                     : launch_range_sigma<float>(g, d, x, y, opt.stream_nt != 0, s, false);
+}
+
+// conversion time (and whenever the child's stream policy changes): the LDS limit of the range kernel this child launches
+hipError_t prepare_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const SpmvOptions &opt)
+{
+    if (g.p <= 0)
+        return hipSuccess;
+    return value_type == CSR5HIP_F64 ? launch_range_sigma<double>(g, d, nullptr, nullptr, opt.stream_nt != 0, nullptr, true)
+                                     : launch_range_sigma<float>(g, d, nullptr, nullptr, opt.stream_nt != 0, nullptr, true);
 }
 
 } // namespace csr5

@@ -215,6 +215,7 @@ hipError_t launch_calibrate_long(int count, int m, int value_type, const uint32_
 // csr5_hot.hip: the slab child's SpMV when its column words are hot-encoded (persistent range kernel + finish)
 hipError_t launch_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, void *y,
                            const SpmvOptions &opt, hipStream_t s);
+hipError_t prepare_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const SpmvOptions &opt);
 hipError_t launch_fp32_exact(const double *v, size_t n, unsigned *flag, hipStream_t s);
 hipError_t launch_narrow(const double *v, size_t n, float *o, int tile_elems, int transposed_tiles, hipStream_t s);
 hipError_t launch_range_heads(const Geometry &g, const DeviceArrays &d, hipStream_t s);

@@ -224,9 +224,9 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     // acc + element i as ONE fused multiply-add
     auto accumulate = [&](int i, VT acc) -> VT {
         if constexpr (SIGMA > 0)
-            return __builtin_fma(mv[i], mx[i], acc);
+            return fma_vt(mv[i], mx[i], acc);
         else
-            return __builtin_fma(vt[i * OMEGA], gather(ct[i * OMEGA]), acc);
+            return fma_vt(vt[i * OMEGA], gather(ct[i * OMEGA]), acc);
     };
 
     // Decode the descriptor and reduce the spill HERE, in the entry block, before any data-dependent

@@ -20,6 +20,10 @@
 //     offset[] (requested together with the gathers, so the stores do not wait for a further round trip).
 #include "csr5_carry.h"
 
+#ifndef CSR5_WALK_DEPTH
+#define CSR5_WALK_DEPTH 3 // tiles whose streams are requested ahead of the tile that computes, + 1 (2 or 3 register sets)
+#endif
+
 namespace csr5 {
 
 constexpr uint32_t WALK_EXACT = 0x80000000u; // walk_row bit: the range's first row BEGINS with the range's first element
@@ -126,10 +130,10 @@ struct WalkParams {
 template <typename VT, int SIGMA, bool XWIN>
 constexpr int walk_lds_bytes()
 {
-    return OMEGA * SIGMA * (int)sizeof(VT) + (XWIN ? WALK_XWIN_BYTES + 16 : 0);
+    return OMEGA * SIGMA * (int)sizeof(VT) + (XWIN ? WALK_XWIN_BYTES : 0);
 }
 
-template <typename VT, int SIGMA, bool XWIN, bool NT>
+template <typename VT, int SIGMA, bool XWIN, bool NT, int DEPTH>
 __global__ void __launch_bounds__(OMEGA)
 k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const VT *__restrict__ val,
             const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc,
@@ -139,7 +143,11 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     using word_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
     constexpr int T = OMEGA * SIGMA;
     constexpr int BIT_Y = bit_y_of(SIGMA), BIT_ALL = BIT_Y + BIT_SS;
-    constexpr unsigned WXB = WALK_XWIN_BYTES; // bytes of the staged slice of x; slot [WXB] behind it holds +0.0
+    // bytes of the staged slice of x.  Lanes outside it read +0.0 from the LAST slot of the y-compaction region right in front
+    // of the slice (never used by a tile: a tile stores at most T - 2 segments there), so that eight wavefronts of the fp32
+    // sigma = 16 kernel fill a CU's 160 KB exactly
+    constexpr unsigned WXB = WALK_XWIN_BYTES;
+    constexpr unsigned ZERO_SLOT = 0u - (unsigned)sizeof(VT);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     VT *const lead = static_cast<VT *>(wp.lead), *const acc = static_cast<VT *>(wp.acc);
 
@@ -176,7 +184,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     const uint32_t next_meta_x = metac[4 * (R + 1)];
 
     auto *seg = (__attribute__((address_space(3))) VT *)(smem);
-    auto *win = (__attribute__((address_space(3))) char *)(smem + (size_t)T * sizeof(VT)); // WXB bytes of x + one +0.0 slot
+    auto *win = (__attribute__((address_space(3))) char *)(smem + (size_t)T * sizeof(VT)); // WXB bytes of x
     const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(x), (short)0, g.n * (int)sizeof(VT), 0x00020000);
 
     auto load = [&](WalkTile<VT, SIGMA> &tr, int t) {
@@ -298,7 +306,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
 #pragma unroll
             for (int i = 0; i < SIGMA; i++) {
                 const unsigned d = (unsigned)tr.c[i] * (unsigned)sizeof(VT) - wbase;
-                lw[i] = *(const __attribute__((address_space(3))) word_t *)(win + (d < WXB ? d : WXB)); // outside: the +0.0 slot
+                lw[i] = *(const __attribute__((address_space(3))) word_t *)(win + (int)(d < WXB ? d : ZERO_SLOT)); // outside: +0.0
             }
             if (some_out) { // (wave-uniform)
 #pragma unroll
@@ -333,7 +341,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
             VT s = 0;
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
-                s = __builtin_fma(tr.v[i], mx[i], s);
+                s = fma_vt(tr.v[i], mx[i], s);
             open_val += wave_sum(s);
             return;
         }
@@ -358,7 +366,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
                     sum = 0;
                 }
             }
-            sum = __builtin_fma(tr.v[i], mx[i], sum);
+            sum = fma_vt(tr.v[i], mx[i], sum);
         }
         if (!direct)
             first_sum = sum;
@@ -446,49 +454,57 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
         open_is_lead = false;
     };
 
-    // ---- the walk: tiles in pairs (two register sets, no copies), an odd last tile peeled ----------------------------------
-    // Order inside a step: this tile's gathers FIRST (vector loads return in order: they must not queue behind 12 KB of
-    // streams), then the next tile's streams, which stay in flight while this tile computes.
-    WalkTile<VT, SIGMA> a, b;
+    // ---- the walk -----------------------------------------------------------------------------------------------------------
+    // One step = one tile: this tile's gathers FIRST (vector loads return in order: they must not queue behind the streams), then
+    // the streams of the tile DEPTH - 1 ahead, which stay in flight while this tile computes; the tile in between is in flight
+    // already.  DEPTH register sets rotate without copies (the loop is unrolled DEPTH times, the last tiles are peeled).  HBM
+    // latency under load is ~2.5 us here: with one tile of streams in flight per wavefront (DEPTH 2) and the 8 wavefronts per CU
+    // the 16-KB window leaves room for, a CU holds 64 KB in flight and the chip 5 TB/s; DEPTH 3 doubles that.
     word_t xg[SIGMA];
     int32_t offv[SIGMA];
-    int wl_cur = -1, wl_next = -1;
+    int wl_cur = -1;
+    auto step = [&](WalkTile<VT, SIGMA> &cur, WalkTile<VT, SIGMA> &ahead, int tt, auto load_ahead) {
+        int wl_nx = -1;
+        if constexpr (XWIN)
+            wl_nx = xwc[tt + 1 < te ? tt + 1 : tt]; // the next tile's window: read when this tile is done
+        __builtin_amdgcn_sched_barrier(0);
+        const bool some_out = gather(cur, wl_cur, xg, offv);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(load_ahead)::value)
+            load(ahead, tt + DEPTH - 1 < te ? tt + DEPTH - 1 : te - 1); // (behind the range's end: its last tile again, unused)
+        __builtin_amdgcn_sched_barrier(0);
+        compute(cur, wl_cur, some_out, xg, offv);
+        restage(wl_nx);
+        wl_cur = wl_nx;
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    WalkTile<VT, SIGMA> a, b;
     load(a, tb);
     if constexpr (XWIN) {
         wl_cur = xwc[tb];
-        wl_next = xwc[tb + 1 < te ? tb + 1 : tb];
-        *(__attribute__((address_space(3))) word_t *)(win + WXB) = 0; // what the out-of-window lanes read
+        *(__attribute__((address_space(3))) word_t *)(win + (int)ZERO_SLOT) = 0; // what the out-of-window lanes read
         restage(wl_cur);
     }
     int t = tb;
-    for (; t + 1 < te; t += 2) {
-        int wl2 = -1, wl3 = -1;
-        if constexpr (XWIN) {
-            wl2 = xwc[t + 2 < te ? t + 2 : t + 1];
-            wl3 = xwc[t + 3 < te ? t + 3 : (t + 2 < te ? t + 2 : t + 1)];
+    if constexpr (DEPTH == 2) {
+        for (; t + 2 <= te; t += 2) {
+            step(a, b, t, std::true_type{});
+            step(b, a, t + 1, std::true_type{});
         }
-        __builtin_amdgcn_sched_barrier(0);
-        const bool out_a = gather(a, wl_cur, xg, offv);
-        __builtin_amdgcn_sched_barrier(0);
-        load(b, t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a, wl_cur, out_a, xg, offv);
-        restage(wl_next);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool out_b = gather(b, wl_next, xg, offv);
-        __builtin_amdgcn_sched_barrier(0);
-        load(a, t + 2 < te ? t + 2 : t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(b, wl_next, out_b, xg, offv);
-        restage(wl2);
-        wl_cur = wl2;
-        wl_next = wl3;
-    }
-    if (t < te) {
-        __builtin_amdgcn_sched_barrier(0);
-        const bool out_a = gather(a, wl_cur, xg, offv);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(a, wl_cur, out_a, xg, offv);
+        if (t < te)
+            step(a, a, t, std::false_type{});
+    } else {
+        WalkTile<VT, SIGMA> c;
+        load(b, tb + 1 < te ? tb + 1 : tb);
+        for (; t + 3 <= te; t += 3) {
+            step(a, c, t, std::true_type{});
+            step(b, a, t + 1, std::true_type{});
+            step(c, b, t + 2, std::true_type{});
+        }
+        if (t < te)
+            step(a, a, t, std::false_type{});
+        if (t + 1 < te)
+            step(b, b, t + 1, std::false_type{});
     }
 
     // ---- the seams of this range: its lead, and the row that is open at its end --------------------------------------------
@@ -516,7 +532,7 @@ static hipError_t launch_walk_one(const Geometry &g, const DeviceArrays &d, cons
     WalkParams wp{d.walk_row, reinterpret_cast<const uint4 *>(d.walk_meta), d.walk_lead, d.walk_acc, d.walk_cnt, d.xwin_base,
                   d.walk_ranges};
     constexpr size_t lds = (size_t)walk_lds_bytes<VT, SIGMA, XWIN>();
-    hipLaunchKernelGGL((k_spmv_walk<VT, SIGMA, XWIN, NT>), dim3(d.walk_ranges + tail_blocks), dim3(OMEGA), lds, s, g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x,
+    hipLaunchKernelGGL((k_spmv_walk<VT, SIGMA, XWIN, NT, CSR5_WALK_DEPTH>), dim3(d.walk_ranges + tail_blocks), dim3(OMEGA), lds, s, g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x,
                        d.tile_ptr, d.tile_desc, d.offset_ptr, d.offset, (VT *)y, wp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !opt.walk_long_runs)
@@ -557,7 +573,7 @@ bool walk_supported(const Geometry &g, int value_size)
 // dynamic LDS of one wavefront (= workgroup) of the walking kernel
 int walk_wave_lds_bytes(int sigma, int value_size, int x_window)
 {
-    return OMEGA * sigma * value_size + (x_window ? WALK_XWIN_BYTES + 16 : 0);
+    return OMEGA * sigma * value_size + (x_window ? WALK_XWIN_BYTES : 0);
 }
 #endif
 

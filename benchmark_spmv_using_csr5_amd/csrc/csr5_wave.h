@@ -5,6 +5,11 @@
 
 namespace csr5 {
 
+// a * b + c as ONE fused multiply-add of the value type (__builtin_fma alone is the fp64 one: fp32 operands would be widened,
+// multiplied-added in fp64 and narrowed again -- three conversions per element and the fp64 rate; so it was until round 5)
+__device__ __forceinline__ float fma_vt(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_vt(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
 // ---- cross-lane helpers on DPP (data-parallel primitives: lane moves folded into VALU operands, no LDS
 //      crossbar round trip as with ds_bpermute).  A 64-bit value moves as two 32-bit halves. -------------
 // Full row/bank masks: bound_ctrl makes source lanes outside the row / wave read 0 and leaves no "old"
