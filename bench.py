@@ -103,10 +103,11 @@ def parse_args():
     ap.add_argument("--slabs", default="auto", help="column slabs: auto (default), 0 = off, 2..64 = that many")
     ap.add_argument("--slab-shift", type=int, default=None)
     ap.add_argument("--slab-hot", default="auto", choices=["auto", "off", "force"], help="LDS hot table of the slab kernel")
-    ap.add_argument("--x-snapshot", type=int, default=1, choices=[0, 1],
-                    help="hot-table slab kernel: 1 (default) = its permuted copy of x is taken once per setX, as the reference CLI's "
-                         "protocol allows (setX once, NUM_RUN spmv calls on the same x: CSR5_cuda/main.cu:63-99); 0 = by every "
-                         "spmv (the library default: x is read live)")
+    ap.add_argument("--x-snapshot", type=int, default=0, choices=[0, 1],
+                    help="hot-table slab kernel: 0 (default = the LIBRARY default) = its permuted copy of x is re-taken by every "
+                         "spmv (x is read live, as the reference reads it); 1 = once per setX, which the reference CLI's protocol "
+                         "allows (setX once, NUM_RUN spmv calls on the same x: CSR5_cuda/main.cu:63-99) -- reported as the side "
+                         "figure roofline.x_snapshot_once_per_setX")
     ap.add_argument("--tile-walk", default="auto", choices=["auto", "off", "force"],
                     help="plain path: the range-walking pipelined tile kernel (CSR5HIP_OPT_TILE_WALK)")
     ap.add_argument("--walk-ranges", type=int, default=0, help="tile ranges of the walking kernel, 0 = default")
@@ -240,7 +241,7 @@ class Problem:
         _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
         _ck(A.setTileWalk({"off": 0, "auto": 1, "force": 2}[getattr(args, "tile_walk", "auto")]), "setTileWalk")
         _ck(A.setWalkRanges(int(getattr(args, "walk_ranges", 0))), "setWalkRanges")
-        rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 1)))
+        rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 0)))
         if rc != 0 and not os.environ.get("CSR5HIP_LIB"):  # (an older library build under A/B test does not know the option)
             _ck(rc, "setXSnapshot")
         if getattr(args, "zero_empty", 0):
@@ -343,9 +344,9 @@ def roofline_dict(prob, ev_ms_per_step, wall_ms_per_step, extra=None):
         "kernel": ("csr5::k_spmv_range + csr5::k_range_finish" if info.slab_hot else "csr5::k_spmv") +
                   (" + csr5::k_slab_combine (all inside the step time)" if info.column_slabs else ""),
         "algorithmic_bytes_per_launch": prob.b_alg,
-        # diagnostic: bytes the CSR5 kernel actually streams = B_alg with row_ptr replaced by
-        # tile_ptr + tile_desc (x and y still counted once)
-        "csr5_stream_bytes_per_launch": prob.b_alg - 4 * (prob.m + 1) + 4 * (info.p + 1) + 4 * info.p * 64 * info.num_packet,
+        # diagnostic: what the kernels of one step actually move, by array (computed from the structure's sizes,
+        # not measured; `traffic` below is the measured total).  B_alg stays the roofline's numerator.
+        "stream_bytes_breakdown": stream_breakdown(prob),
         "launch_us": round(ev_ms_per_step * 1e3, 3),
         "cache": ("working set far beyond the 256-MiB Infinity Cache: every step streams from HBM"
                   if prob.b_alg > 2 * INFINITY_CACHE_BYTES else
@@ -357,12 +358,44 @@ def roofline_dict(prob, ev_ms_per_step, wall_ms_per_step, extra=None):
     return d
 
 
+def stream_breakdown(prob) -> dict:
+    """Bytes one SpMV step moves, array by array, for the path the handle runs.  Plain path: the CSR5 format arrays (B_alg with
+    row_ptr replaced by tile_ptr + tile_desc).  Column slabs + hot table: what the slab CHILD streams -- 3-byte column codes,
+    values, the child's tile_ptr, the LDS table images (once per XCD and slab from HBM; the 32 workgroups of an XCD re-read
+    them from L2), the cold region of the permuted x (lower bound: every entry once; a 128-byte line may be fetched again), the
+    per-(row, slab) partial sums P written by the range kernel and read by the combine, the combine's row bytes and base words,
+    y, and -- x read live -- k_x_permute's read of x and write of the permuted copy."""
+    i, v = prob.info, prob.vsize
+    if not i.column_slabs:
+        d = {"column_index": 4 * prob.nnz, "value": v * prob.nnz, "tile_ptr": 4 * (i.p + 1),
+             "tile_desc": 4 * i.p * 64 * i.num_packet, "x_once": v * prob.n, "y": v * prob.m}
+    elif not i.slab_hot:
+        d = {"child_column_index": 4 * prob.nnz, "child_value": v * prob.nnz, "child_tile_ptr": 4 * (i.slab_tiles + 1),
+             "child_tile_desc": 4 * i.slab_tiles * 64, "x_once": v * prob.n, "P_written": v * i.slab_segments,
+             "P_read": v * i.slab_segments, "combine_row_bytes": i.slab_segments, "y": v * prob.m}
+    else:
+        cap = 16384 if v == 8 else 32768
+        vs = 4 if i.slab_values_narrowed else v
+        d = {"child_column_codes": 3 * prob.nnz, "child_value": vs * prob.nnz, "child_tile_ptr": 4 * (i.slab_tiles + 1),
+             "table_images_once_per_slab": v * cap * i.column_slabs, "cold_x_region_once": v * i.slab_cold_entries,
+             "P_written": v * i.slab_segments, "P_read": v * i.slab_segments, "combine_row_bytes": i.slab_segments,
+             "combine_base_words": 4 * (prob.m // 16 + 1) * 2, "y": v * prob.m}
+        if not i.x_snapshot:
+            d["x_permute_read_x"] = v * prob.n
+            d["x_permute_write_copy"] = v * (cap * i.column_slabs + i.slab_cold_entries)
+            d["x_permute_column_lists"] = 4 * (cap * i.column_slabs + i.slab_cold_entries)
+    d["sum"] = int(sum(d.values()))
+    d["note"] = "computed from array sizes; gathers count each distinct entry once (lines may be re-fetched): a lower bound of `traffic`"
+    return d
+
+
 def config_dict(prob, args, ingest_ms=None):
     info = prob.info
     return {
         "m_per_gpu": prob.m, "n": prob.n, "nnz_per_gpu": prob.nnz, "sigma": info.sigma, "tiles": info.p,
         "spmv_mode": args.mode, "launch": args.launch,
         "lds_x_window": bool(info.x_window_active), "x_window_cover_pct": info.x_window_cover_pct,
+        "tile_walk": bool(info.tile_walk), "walk_ranges": info.walk_ranges, "walk_x_window": bool(info.walk_x_window),
         "column_slabs": info.column_slabs, "slab_shift": info.slab_shift, "slab_segments": info.slab_segments,
         "slab_sigma": info.slab_sigma, "slab_build_ms": round(info.t_slab_ms, 3),
         "slab_hot_table": bool(info.slab_hot), "slab_hot_cover_pct": info.slab_hot_cover_pct,
@@ -587,18 +620,23 @@ def main():
                 roof = cold_is_the_number(prob, roof, ev_per_step, ms_per_step, cold_ms, k, cs)
             else:
                 roof["cold"] = cold_dict(prob, cold_ms, k, cs)
-        if world == 1 and info.slab_x_permuted and info.x_snapshot and not args.no_side_figures:
-            # the same workload with the library default: the permuted copy of x is re-taken by every spmv() (x read live)
-            _ck(prob.A.setXSnapshot(0), "setXSnapshot")
+        if world == 1 and info.slab_x_permuted and not info.x_snapshot and not args.no_side_figures:
+            # side figure: the same workload under the reference CLI's protocol -- setX once, then the timed loop -- with the
+            # permuted copy of x taken once per setX (CSR5HIP_OPT_X_SNAPSHOT = 1, what ./spmv opts into)
+            _ck(prob.A.setXSnapshot(1), "setXSnapshot")
             lsteps = max(5, steps // 4)
             lwall, lev = timed(prob, lsteps, 2, args.launch, None)
-            _ck(prob.A.setXSnapshot(1), "setXSnapshot")
-            roof["x_live"] = {"launch_us": round(lev / lsteps * 1e3, 3),
-                              "frac": round(prob.b_alg / (lev / lsteps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": lsteps,
-                              "note": "library default CSR5HIP_OPT_X_SNAPSHOT = 0: csr5::k_x_permute runs inside every step "
-                                      "(a caller may overwrite x between spmv() calls without calling setX again); the "
-                                      "headline uses the reference CLI's protocol -- setX once, then the timed loop -- with "
-                                      "the copy taken once per setX"}
+            _ck(prob.A.setXSnapshot(0), "setXSnapshot")
+            roof["x_snapshot_once_per_setX"] = {
+                "launch_us": round(lev / lsteps * 1e3, 3),
+                "frac": round(prob.b_alg / (lev / lsteps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": lsteps,
+                "note": "opt-in CSR5HIP_OPT_X_SNAPSHOT = 1: csr5::k_x_permute runs once per setX instead of inside every step "
+                        "(the caller promises not to change x's contents without calling setX again).  NOT the headline: the "
+                        "headline runs at the library's defaults (x read live, as rounds 1-3 and the reference's spmv do); "
+                        "round 4's headline was this figure"}
+        elif world == 1 and info.slab_x_permuted and info.x_snapshot:
+            roof["x_protocol"] = ("NON-DEFAULT: CSR5HIP_OPT_X_SNAPSHOT = 1 (--x-snapshot 1): the permuted copy of x is taken once "
+                                  "per setX, outside the timed steps")
         if (world == 1 and info.slab_hot and dtype_name == "f64" and not info.slab_values_narrowed and hasattr(prob.A, "setNarrowValues")
                 and not args.no_side_figures):
             # the same workload with CSR5HIP_OPT_NARROW_VALUES: the reference CLI's rand() % 10 values are exact in fp32, so
@@ -680,6 +718,18 @@ def main():
                 except Exception as e:  # a sub-config must never cost the headline line
                     subs.append({"workload": name, "error": repr(e)})
             out["configs"] = subs
+            # the same figures, compact, where the driver's record keeps them (it drops top-level keys it does not know)
+            summary = {}
+            for name, sc in zip(("scircuit", "webbase", "nd24k"), subs):
+                r = sc.get("roofline") or {}
+                w = r.get("warm") or {}
+                summary[name] = ({"error": sc["error"]} if "error" in sc else
+                                 {"dtype": sc["dtype"], "cold_frac": r.get("frac"), "cold_us": r.get("launch_us"),
+                                  "warm_frac": w.get("frac"), "warm_us": w.get("launch_us"),
+                                  "traffic_ratio": (round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3) if r.get("traffic") else None),
+                                  "kernel": r.get("kernel"), "sigma": sc["config"]["sigma"], "column_slabs": sc["config"]["column_slabs"],
+                                  "tile_walk": sc["config"].get("tile_walk"), "data": sc.get("data")})
+            out["roofline"]["configs"] = summary
         print(json.dumps(out), flush=True)
     else:
         prob.close()
@@ -722,6 +772,9 @@ def cpu_baseline(prob, y_gpu, budget_s: float) -> dict:
         y, ms, conv_ms = ref.avx2_spmv(m, n, row_ptr, col, val64, x64, warm=2 if big else 50, runs=runs)
         kind = "reference"
     else:
+        print("bench.py: oracle/_ref (the reference's own CSR5_avx2 build) is not in this tree -- cpu_baseline.kind = \"port\": "
+              "timing our C restatement of it instead (build it where /root/reference exists: make -C oracle ref)",
+              file=sys.stderr, flush=True)
         orc = Oracle()
         cores = orc.num_threads()
         fmt = orc.convert(4, 16, m, row_ptr, col, val64)

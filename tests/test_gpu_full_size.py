@@ -109,3 +109,47 @@ def test_fp32_full_size_against_the_fp64_oracle(oracle, workload):
     scale = oracle.csr_spmv(m, row_ptr, col, np.abs(v64), np.abs(x64))
     err = np.abs(y.astype(np.float64) - y64)
     assert np.all(err[nonempty] <= 1e-5 * np.maximum(scale[nonempty], 1.0)), (workload, float((err / np.maximum(scale, 1.0)).max()))
+
+
+def test_rmat24_eight_row_blocks_at_size(oracle):
+    """BASELINE config 4's sharding at its own size: the 8 cost-balanced row blocks of ONE R-MAT 24 (what the 8 GPUs of a node
+    would hold; generated per shard, `matrices.rmat_device_shard`), one after the other through their own handles at the
+    library's defaults.  Every block must run the headline's path (16 column slabs, LDS hot table), the blocks' costs must be
+    balanced within 10 %, and every block's y must equal the reference's compiled CSR5_avx2 (oracle/_ref; the pinned oracle
+    where that is absent) on the same block, exactly, on the CLI's integer data.  Per-block times -> gpurun_out/r05_shards.txt
+    (the code path of scripts/experiments/shard_alone.py).  N > 1 on hardware stays unmeasured: these are single-GPU times."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("shard_alone", os.path.join(root, "scripts", "experiments", "shard_alone.py"))
+    shard_alone = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(shard_alone)
+    from benchmark_spmv_using_csr5_amd import sharding as S
+    ref = Reference() if Reference.available() else None
+    world, recs = 8, []
+    for rank in range(world):
+        rec, out = shard_alone.measure_block(24, world, rank, torch.device(DEV), steps=30, keep_y=True)
+        recs.append(rec)
+        assert rec["slabs"] == 16 and rec["hot"] == 1, rec
+        m = rec["m"]
+        nonempty = np.diff(out["row_ptr"]) > 0
+        if ref is not None:
+            exp, _, _ = ref.avx2_spmv(m, 1 << 24, out["row_ptr"], out["col"], out["val"], out["x"], y0=np.zeros(m))
+        else:
+            exp = oracle.csr_spmv(m, out["row_ptr"], out["col"], out["val"], out["x"])
+        assert np.array_equal(out["y"][nonempty], exp[nonempty]), rank
+        del out
+    assert sum(r["m"] for r in recs) == 1 << 24 and sum(r["nnz"] for r in recs) == 16 << 24
+    cost = np.asarray([r["nnz"] + S.ROW_WEIGHT * r["m"] for r in recs], dtype=np.float64)
+    assert cost.max() <= 1.10 * cost.mean(), cost / cost.mean()
+    out_dir = os.path.join(root, "gpurun_out")
+    if os.path.isdir(out_dir):
+        slow = max(r["us"] for r in recs)
+        with open(os.path.join(out_dir, "r05_shards.txt"), "w") as f:
+            f.write("# the 8 cost-balanced row blocks of R-MAT 24 (BASELINE config 4), each ALONE on one MI355X at the library's defaults "
+                    "(x read live), tests/test_gpu_full_size.py::test_rmat24_eight_row_blocks_at_size;\n# N > 1 on hardware is "
+                    "unmeasured: an 8-GPU step would take at least the slowest block's time\n")
+            for r in recs:
+                f.write(json.dumps(r) + "\n")
+            f.write(f"# slowest block {slow} us; cost imbalance max/mean {cost.max() / cost.mean():.3f}\n")

@@ -859,3 +859,41 @@ def test_spmv_is_capturable_in_a_callers_graph(oracle):
         del graph
         A.destroy()
         A.close()
+
+
+@pytest.mark.gpu
+def test_batch_harness_writes_one_row_per_matrix(tmp_path):
+    """scripts/bench_batch.py (the reference's avx512 CLI appends `file,GFlops` to results.csv,
+    CSR5_avx512/main.cpp:105-110): two Matrix Market files in -> two JSON lines and two CSV rows out, with the matrix's
+    dimensions, sigma, GFLOPS and roofline fraction; a second invocation APPENDS."""
+    import csv
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    mats = [M.scircuit_like(scale=0.05), M.example_matrix()]
+    files = []
+    for k, mat in enumerate(mats):
+        mat.val[:] = 1.0
+        path = tmp_path / f"m{k}.mtx"
+        M.write_mtx(str(path), mat)
+        files.append(str(path))
+    out = str(tmp_path / "results")
+    cmd = [sys.executable, os.path.join(root, "scripts", "bench_batch.py"), *files, "--out", out, "--steps", "20", "--warmup", "5",
+           "--no-cpu-baseline"]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert run.returncode == 0, run.stderr
+    lines = [json.loads(l) for l in open(out + ".jsonl")]
+    rows = list(csv.DictReader(open(out + ".csv")))
+    assert len(lines) == 2 and len(rows) == 2
+    for mat, f, d, r in zip(mats, files, lines, rows):
+        assert d["file"] == f and r["file"] == f
+        assert (int(r["m"]), int(r["n"]), int(r["nnz"])) == (mat.m, mat.n, mat.nnz)
+        assert d["config"]["nnz_per_gpu"] == mat.nnz and d["n_gpus"] == 1 and r["dtype"] == "f64"
+        assert 4 <= int(r["sigma"]) <= 32 and float(r["gflops"]) > 0 and 0 < float(r["roof_frac"]) < 1
+        assert "matrix market file" in d["data"]
+    run = subprocess.run(cmd[:3] + ["--out", out, "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], capture_output=True,
+                         text=True, timeout=900)
+    assert run.returncode == 0, run.stderr
+    assert len(open(out + ".jsonl").readlines()) == 3 and len(list(csv.DictReader(open(out + ".csv")))) == 3
