@@ -108,7 +108,7 @@ def parse_args():
                          "spmv (x is read live, as the reference reads it); 1 = once per setX, which the reference CLI's protocol "
                          "allows (setX once, NUM_RUN spmv calls on the same x: CSR5_cuda/main.cu:63-99) -- reported as the side "
                          "figure roofline.x_snapshot_once_per_setX")
-    ap.add_argument("--tile-walk", default="auto", choices=["auto", "off", "force"],
+    ap.add_argument("--tile-walk", default="off", choices=["auto", "off", "force"],
                     help="plain path: the range-walking pipelined tile kernel (CSR5HIP_OPT_TILE_WALK)")
     ap.add_argument("--walk-ranges", type=int, default=0, help="tile ranges of the walking kernel, 0 = default")
     ap.add_argument("--zero-empty", type=int, default=0, choices=[0, 1],
@@ -239,7 +239,7 @@ class Problem:
         if args.slab_shift is not None:
             _ck(A.setSlabShift(args.slab_shift), "setSlabShift")
         _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
-        _ck(A.setTileWalk({"off": 0, "auto": 1, "force": 2}[getattr(args, "tile_walk", "auto")]), "setTileWalk")
+        _ck(A.setTileWalk({"off": 0, "auto": 1, "force": 2}[getattr(args, "tile_walk", "off")]), "setTileWalk")
         _ck(A.setWalkRanges(int(getattr(args, "walk_ranges", 0))), "setWalkRanges")
         rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 0)))
         if rc != 0 and not os.environ.get("CSR5HIP_LIB"):  # (an older library build under A/B test does not know the option)

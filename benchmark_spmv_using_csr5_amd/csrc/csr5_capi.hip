@@ -115,7 +115,7 @@ struct csr5hip_handle_s {
     size_t scan_tmp_bytes = 0;
     uint32_t scalar_words[2] = {0, 0}; // landing zone of the two 4-byte reads of the conversion (checkpoint loading)
     uint32_t *host_words = nullptr;    // 32 pinned, device-visible words the last conversion kernels export into
-    int walk_request = 1;        // CSR5HIP_OPT_TILE_WALK: 0 off, 1 auto (default), 2 force
+    int walk_request = 0;        // CSR5HIP_OPT_TILE_WALK: 0 off (default), 1 auto, 2 force
     int walk_ranges_request = 0; // CSR5HIP_OPT_WALK_RANGES: 0 = default
     int walk_xwin_tiles = 0;     // tiles that got one of the walking kernel's (16-KB) x-windows at conversion
     long long walk_xwin_covered = 0; // non-zeros inside those windows

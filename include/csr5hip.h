@@ -113,8 +113,11 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       gathers, the open row stays in registers, one leading partial per RANGE goes through the
                                       arrival protocol -- instead of one tile per wavefront.  Same format arrays, same results up to
                                       the association of cut rows' partial sums (bit-reproducible run to run either way).
-                                      0 = off, 1 = auto (default: on when every range gets >= 4 tiles and sigma <= 16), 2 = force
-                                      (still needs sigma in 4..16) */
+                                      0 = off (default), 1 = auto (on when every range gets >= 4 tiles and sigma is in 4..16), 2 = force
+                                      (still needs sigma in 4..16).  Off by default because on MI355X it measured 5-15 % SLOWER
+                                      than the one-tile kernel on every BASELINE stand-in (profiles/r05_walk.md): with ~2 500
+                                      issue cycles of per-tile work a wavefront is instruction-bound, and the 2-3 wavefronts per
+                                      SIMD its registers and LDS leave room for hide less of that than the one-tile kernel's 7. */
 #define CSR5HIP_OPT_WALK_RANGES 14 /* number of tile ranges (= wavefronts) of the walking kernel: 0 = default (2 048 = 8 per CU),
                                       else 1 .. 16 384; never more than p - 1 */
 

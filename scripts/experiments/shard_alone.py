@@ -55,12 +55,13 @@ def measure_block(scale, world, rank, dev, steps=50, slabs="auto", hot="auto", r
            "hot": i.slab_hot, "hot_cover_pct": i.slab_hot_cover_pct, "x_snapshot": x_snapshot, "us": round(us, 1),
            "frac": round(b_alg / (us * 1e-6) / 8e12, 3),
            "gflops_if_all_ranks_alike": round(2 * mat.nnz * world / (us * 1e-6) / 1e9, 1)}
+    A.destroy()  # (asCSR: the value array the handle transposed in place is back in CSR order)
+    A.close()
     out = None
     if keep_y:
+        torch.cuda.synchronize()
         out = {"y": y.cpu().numpy(), "row_ptr": mat.row_ptr.cpu().numpy(), "col": mat.col.cpu().numpy(),
                "val": va.cpu().numpy(), "x": x.cpu().numpy()}
-    A.destroy()
-    A.close()
     del mat, va, x, y
     torch.cuda.empty_cache()
     return rec, out
