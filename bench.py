@@ -367,7 +367,8 @@ def stream_breakdown(prob) -> dict:
     y, and -- x read live -- k_x_permute's read of x and write of the permuted copy."""
     i, v = prob.info, prob.vsize
     if not i.column_slabs:
-        d = {"column_index": 4 * prob.nnz, "value": v * prob.nnz, "tile_ptr": 4 * (i.p + 1),
+        d = {("column_codes_16bit" if i.narrow_columns else "column_index"): (2 if i.narrow_columns else 4) * prob.nnz,
+             "value": v * prob.nnz, "tile_ptr": 4 * (i.p + 1),
              "tile_desc": 4 * i.p * 64 * i.num_packet, "x_once": v * prob.n, "y": v * prob.m}
     elif not i.slab_hot:
         d = {"child_column_index": 4 * prob.nnz, "child_value": v * prob.nnz, "child_tile_ptr": 4 * (i.slab_tiles + 1),
@@ -395,7 +396,7 @@ def config_dict(prob, args, ingest_ms=None):
         "m_per_gpu": prob.m, "n": prob.n, "nnz_per_gpu": prob.nnz, "sigma": info.sigma, "tiles": info.p,
         "spmv_mode": args.mode, "launch": args.launch,
         "lds_x_window": bool(info.x_window_active), "x_window_cover_pct": info.x_window_cover_pct,
-        "tile_walk": bool(info.tile_walk), "walk_ranges": info.walk_ranges, "walk_x_window": bool(info.walk_x_window),
+        "narrow_columns": bool(info.narrow_columns), "tile_walk": bool(info.tile_walk), "walk_ranges": info.walk_ranges, "walk_x_window": bool(info.walk_x_window),
         "column_slabs": info.column_slabs, "slab_shift": info.slab_shift, "slab_segments": info.slab_segments,
         "slab_sigma": info.slab_sigma, "slab_build_ms": round(info.t_slab_ms, 3),
         "slab_hot_table": bool(info.slab_hot), "slab_hot_cover_pct": info.slab_hot_cover_pct,

@@ -117,6 +117,11 @@ struct csr5hip_handle_s {
     uint32_t *host_words = nullptr;    // 32 pinned, device-visible words the last conversion kernels export into
     int walk_request = 0;        // CSR5HIP_OPT_TILE_WALK: 0 off (default), 1 auto, 2 force
     int walk_ranges_request = 0; // CSR5HIP_OPT_WALK_RANGES: 0 = default
+    // narrow column codes of the x-window kernel (csr5_format.hip k_col16): built when that kernel is selected
+    int col16_request = 1;       // CSR5HIP_OPT_NARROW_COLUMNS: 0 off, 1 auto (default)
+    bool col16_built = false;    // the codes of the current conversion exist
+    unsigned col16_wide = 0;     // tiles that span >= 65 536 columns (the codes are used only when there is none)
+    Buffer b_col16;              // codes [(p-1) * T / 2 words], then base16 [p]
     int walk_xwin_tiles = 0;     // tiles that got one of the walking kernel's (16-KB) x-windows at conversion
     long long walk_xwin_covered = 0; // non-zeros inside those windows
     double wall_clock_khz = 0;         // rate of the device's constant wall clock (phase stamps)
@@ -250,6 +255,7 @@ int csr5hip_free(csr5hip_handle h)
     h->drop_graphs();
     release_slabs(h);
     h->b_arena.release();
+    h->b_col16.release();
     if (h->host_words)
         (void)hipHostFree(h->host_words);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -334,6 +340,13 @@ int csr5hip_set_sigma(csr5hip_handle h, int sigma)
 static int build_slabs(csr5hip_handle h);
 static int build_slabs_impl(csr5hip_handle h);
 static int prepare_walk(csr5hip_handle h);
+static int prepare_col16(csr5hip_handle h);
+// kernel-side tables of the plain (non-slab) path that are built on demand: narrow column codes, walking-kernel ranges
+static int prepare_plain(csr5hip_handle h)
+{
+    const int rc = prepare_col16(h);
+    return rc != CSR5HIP_SUCCESS ? rc : prepare_walk(h);
+}
 
 int csr5hip_set_option(csr5hip_handle h, int option, int value)
 {
@@ -344,8 +357,8 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         if (value != 0 && value != 1)
             return CSR5HIP_INVALID_ARGUMENT;
         h->opt.mode = value;
-        if (h->format == CSR5HIP_FORMAT_CSR5) {
-            const int rc = prepare_walk(h);
+        if (h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0) {
+            const int rc = prepare_plain(h);
             if (rc != CSR5HIP_SUCCESS)
                 return rc;
         }
@@ -381,7 +394,7 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         h->xwin_request = value;
         if (h->format == CSR5HIP_FORMAT_CSR5) {
             h->opt.x_window = xwin_decision(h);
-            const int rc = prepare_walk(h);
+            const int rc = h->slab_S <= 0 ? prepare_plain(h) : CSR5HIP_SUCCESS;
             if (rc != CSR5HIP_SUCCESS)
                 return rc;
         }
@@ -431,6 +444,16 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
                 h->drop_graphs();
                 return build_slabs(h);
             }
+        }
+        break;
+    case CSR5HIP_OPT_NARROW_COLUMNS:
+        if (value != 0 && value != 1)
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->col16_request = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0) {
+            const int rc = prepare_col16(h);
+            if (rc != CSR5HIP_SUCCESS)
+                return rc;
         }
         break;
     case CSR5HIP_OPT_TILE_WALK:
@@ -487,6 +510,10 @@ static int derive_geometry(csr5hip_handle h, int sigma)
     h->xwin_covered = 0;
     h->xwin_lines = 0;
     h->opt.long_runs = 0;
+    h->col16_built = false; // (the column words are about to be permuted again)
+    h->opt.col16 = 0;
+    h->d.col16 = nullptr;
+    h->d.base16 = nullptr;
     h->t_malloc = h->t_tile_ptr = h->t_tile_desc = h->t_transpose = 0;
     h->drop_graphs();
     return CSR5HIP_SUCCESS;
@@ -568,6 +595,37 @@ static void finish_format_scalars(csr5hip_handle h)
         return;
     h->g.tail_start = (int)(h->scalar_words[0] & ROW_MASK);
     h->num_offsets = (int)h->scalar_words[1];
+}
+
+// ---- narrow column codes (csr5_format.hip k_col16, csr5_spmv.hip C16) ---------------------------------------------------
+// Only the x-window kernel reads them (a matrix whose tiles are covered by 4-KB windows of x has local columns), so they are
+// built when that kernel is selected: one pass over the tile-ordered column words + one synchronisation for the count of wide
+// tiles; 2 bytes per non-zero of device memory.  Stays valid until the next conversion.
+static int prepare_col16(csr5hip_handle h)
+{
+    h->opt.col16 = 0;
+    h->d.col16 = nullptr;
+    h->d.base16 = nullptr;
+    const Geometry &g = h->g;
+    if (h->col16_request == 0 || h->is_child || g.p <= 1 || h->opt.mode != 1 || !h->opt.x_window || !col16_sigma(g.sigma))
+        return CSR5HIP_SUCCESS;
+    const size_t code_words = (size_t)(g.p - 1) * (g.tile_elems / 2);
+    if (!h->col16_built) {
+        HIP_TRY(h->b_col16.reserve((code_words + (size_t)g.p + 1) * 4));
+        uint32_t *wide = h->d.counters + 5;
+        HIP_TRY(hipMemsetAsync(wide, 0, 4, h->stream));
+        HIP_TRY(launch_col16(g, h->d, (uint32_t *)h->b_col16.ptr, (int32_t *)h->b_col16.ptr + code_words, wide, h->stream));
+        HIP_TRY(hipMemcpyAsync(&h->col16_wide, wide, 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->col16_built = true;
+    }
+    if (h->col16_wide == 0) {
+        h->d.col16 = (const uint32_t *)h->b_col16.ptr;
+        h->d.base16 = (const int32_t *)h->b_col16.ptr + code_words;
+        h->opt.col16 = 1;
+    }
+    h->drop_graphs();
+    return CSR5HIP_SUCCESS;
 }
 
 // ---- the range-walking pipelined kernel (csr5_walk.hip) ------------------------------------------------------------------
@@ -857,7 +915,7 @@ static int build_slabs(csr5hip_handle h)
     h->slab_fallback = false;
     const int rc = build_slabs_impl(h);
     if (rc == CSR5HIP_SUCCESS) // (the plain path serves spmv() when no structure is active: its walking kernel's tables, if wanted)
-        return h->slab_S > 0 || h->is_child ? rc : prepare_walk(h);
+        return h->slab_S > 0 || h->is_child ? rc : prepare_plain(h);
     const std::string why = g_last_error;
     (void)hipGetLastError(); // clear a sticky allocation error
     release_slabs(h);
@@ -866,7 +924,7 @@ static int build_slabs(csr5hip_handle h)
     g_last_error = "column slabs not built, plain tile kernel in use: " + why;
     if (h->slab_request >= 2)
         return rc;
-    return prepare_walk(h);
+    return prepare_plain(h);
 }
 
 static int build_slabs_impl(csr5hip_handle h)
@@ -1731,6 +1789,7 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_cold_entries = info->slab_x_permuted ? h->cold_total : 0;
     info->x_snapshot = h->x_snapshot;
     info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
+    info->narrow_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.x_window && h->opt.col16 ? 1 : 0;
     info->tile_walk = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.walk ? 1 : 0;
     info->walk_ranges = h->format == CSR5HIP_FORMAT_CSR5 ? h->d.walk_ranges : 0;
     info->walk_x_window = info->tile_walk && h->opt.walk_x_window ? 1 : 0;
@@ -1741,7 +1800,7 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     long long bytes = (long long)h->b_arena.cap;
     for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_val32, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
                             &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_range_head, &h->b_slab_tmp,
-                            &h->b_col_lo, &h->b_col_hi, &h->b_cold_base, &h->b_cold_cols, &h->b_xperm})
+                            &h->b_col_lo, &h->b_col_hi, &h->b_cold_base, &h->b_cold_cols, &h->b_xperm, &h->b_col16})
         bytes += (long long)b->cap;
     if (h->slab_child)
         bytes += (long long)h->slab_child->b_arena.cap;

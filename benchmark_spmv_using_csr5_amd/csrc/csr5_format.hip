@@ -641,6 +641,56 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
     out[3] = stamps[1]; // phase stamps 2, 3
 }
 
+// ---------------------------------------------------------------------------------------------
+// Narrow column codes (ours; a kernel-side table like the x-window, the format arrays are untouched).  A tile of a banded /
+// blocked matrix spans far fewer than 2^16 columns: column - (smallest column of the tile) fits 16 bits, and the x-window
+// kernel then streams 2 bytes per non-zero instead of 4 (fp32: 6 instead of 8 bytes per non-zero in all).  One wavefront per
+// tile t < p-1: minimum and maximum of the tile's column words (same positions as the tile-ordered column_index, so a code
+// pairs with the value at its position whether or not the tile was transposed), the codes two per word, base16[t]; a tile
+// that spans 65 536 columns or more counts into *wide_tiles -- the codes are used only when that stays 0.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(FMT_BLOCK) k_col16(Geometry g, const int32_t *__restrict__ col, uint32_t *__restrict__ col16,
+                                                 int32_t *__restrict__ base16, uint32_t *__restrict__ wide_tiles)
+{
+    const int lane = threadIdx.x & (OMEGA - 1);
+    const int t = blockIdx.x * FMT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (t >= g.p - 1)
+        return;
+    const int32_t *c = col + (size_t)t * g.tile_elems + lane;
+    int lo = 0x7FFFFFFF, hi = 0;
+    for (int i = 0; i < g.sigma; i++) {
+        const int v = c[i * OMEGA];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int ol = __shfl_xor(lo, d, OMEGA), oh = __shfl_xor(hi, d, OMEGA);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if (lane == 0) {
+        base16[t] = lo;
+        if (hi - lo >= 65536)
+            atomicAdd(wide_tiles, 1u);
+    }
+    uint32_t *out = col16 + (size_t)t * (g.tile_elems / 2) + lane;
+    for (int dd = 0; dd < g.sigma / 2; dd++) {
+        const uint32_t a = (uint32_t)(c[(2 * dd) * OMEGA] - lo), b = (uint32_t)(c[(2 * dd + 1) * OMEGA] - lo);
+        out[dd * OMEGA] = (a & 0xFFFFu) | (b << 16);
+    }
+}
+
+hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col16, int32_t *base16, uint32_t *wide_tiles,
+                        hipStream_t s)
+{
+    if (g.p <= 1)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_col16, dim3((g.p - 1 + FMT_WAVES_PER_BLOCK - 1) / FMT_WAVES_PER_BLOCK), dim3(FMT_BLOCK), 0, s, g, d.col, col16, base16,
+                       wide_tiles);
+    return hipGetLastError();
+}
+
 // checkpoint loading: the index arrays come from a file and are used as addresses by every later kernel
 __global__ void __launch_bounds__(256) k_validate_csr(int m, int n, int nnz, const int32_t *__restrict__ row_ptr,
                                                       const int32_t *__restrict__ col, uint32_t *__restrict__ flag)

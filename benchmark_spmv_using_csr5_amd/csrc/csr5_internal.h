@@ -98,6 +98,10 @@ struct DeviceArrays {
     uint32_t *walk_cnt;        // [walk_ranges + 1] arrival counters, all zero between launches
     int32_t *xwin_base;        // [p] the walking kernel's x-window of every tile (first column, -1 = none); nullptr = not built
     int32_t *xwin_cover;       // [p] non-zeros of the tile inside that window
+    // narrow column codes of the x-window kernel (csr5_spmv.hip C16): every tile 0 .. p-2 spans fewer than 65 536 columns
+    const uint32_t *col16;     // [(p-1) * T / 2] two 16-bit codes per word: elements (2d, lane) | (2d+1, lane) << 16 of tile t at
+                               // t * T/2 + d * 64 + lane, code = column - base16[t]; nullptr = not built
+    const int32_t *base16;     // [p] smallest column of every tile
 };
 
 // ---- conversion (csr5_format.hip) ----
@@ -113,6 +117,10 @@ hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_
 hipError_t launch_transpose_values(const Geometry &g, const DeviceArrays &d, int value_type, hipStream_t s);
 hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int value_size, uint32_t *host_words, bool export_only,
                               hipStream_t s);
+// narrow column codes: codes + per-tile base from the tile-ordered column_index; *wide_tiles += tiles that span >= 65 536 columns
+hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col16, int32_t *base16, uint32_t *wide_tiles,
+                        hipStream_t s);
+constexpr bool col16_sigma(int sigma) { return sigma == 8 || sigma == 12 || sigma == 16 || sigma == 24 || sigma == 32; }
 hipError_t launch_warmup(hipStream_t s);
 // flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)
 hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,
@@ -156,6 +164,7 @@ struct SpmvOptions {
     int stream_nt;   // resolved: 1 = column/value streams use non-temporal loads
     int long_runs;   // resolved: the matrix has rows spanning > RUN_SERIAL_MAX tiles (fused mode adds k_calibrate)
     int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_range + k_range_finish
+    int col16;       // resolved: 1 = the x-window kernel streams 16-bit column codes (2 bytes per non-zero less)
     int walk;        // resolved: 1 = the range-walking pipelined kernel (csr5_walk.hip) instead of one tile per wavefront
     int walk_long_runs; // resolved: some row spans > RUN_SERIAL_MAX ranges (the walking kernel adds k_calibrate)
     int walk_x_window;  // resolved: the walking kernel stages its (larger, rarely restaged) slice of x in LDS

@@ -49,14 +49,15 @@ constexpr int wave_lds_bytes()
 // SIGMA > 0: compile-time sigma (loads hoisted into registers, flag walk fully unrolled).
 // SIGMA == 0: run-time sigma (any 1..32), same code shape, used for sigma < 4 and as a cross-check.
 // One tile, one wavefront.  `wave_lds` = this wavefront's private LDS region (x-window / y segments).
-template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT, bool C16 = false>
 __device__ __forceinline__ void
 tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restrict__ col, const VT *__restrict__ val,
           const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc,
           const int32_t *__restrict__ offset_ptr, const int32_t *__restrict__ offset, VT *__restrict__ calibrator,
           VT *__restrict__ y, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta, const uint32_t *__restrict__ hdr,
-          char *wave_lds)
+          char *wave_lds, const uint32_t *__restrict__ col16 = nullptr, const int32_t *__restrict__ base16 = nullptr)
 {
+    static_assert(!C16 || (SIGMA > 0 && SIGMA % 2 == 0 && FUSED && !NT), "narrow column codes: two per word, fused kernel");
     auto gather = [&](int32_t cw) -> VT { return x[(uint32_t)cw]; };
     const int sigma = SIGMA > 0 ? SIGMA : g.sigma;
     const int bit_y = SIGMA > 0 ? bit_y_of(SIGMA > 0 ? SIGMA : 1) : g.bit_y;
@@ -111,6 +112,13 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
                 c[i] = __builtin_nontemporal_load(ct + i * OMEGA);
+        } else if constexpr (C16) {
+            // narrow column codes (k_col16): two per word, half the column stream; the tile's base rides in the same batch
+            const uint32_t *cw = col16 + (size_t)t * (T / 2) + lane;
+#pragma unroll
+            for (int dd = 0; dd < SIGMA / 2; dd++)
+                c[2 * dd] = (int32_t)cw[dd * OMEGA];
+            c[1] = base16[t + vz];
         } else {
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
@@ -156,6 +164,15 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             // trip for every tile with a short spill).  Costs nothing: vector loads return in order and these two
             // were requested right after the column words the gathers below wait for anyway.
             asm volatile("" : "+v"(spill_c), "+v"(spill_v));
+        }
+        if constexpr (C16) {
+            const int32_t base = __builtin_amdgcn_readfirstlane(c[1]);
+#pragma unroll
+            for (int dd = SIGMA / 2 - 1; dd >= 0; dd--) { // (downwards: c[1] holds the base until pair 0 is decoded)
+                const uint32_t w = (uint32_t)c[2 * dd];
+                c[2 * dd] = base + (int32_t)(w & 0xFFFFu);
+                c[2 * dd + 1] = base + (int32_t)(w >> 16);
+            }
         }
         VT xv[NREG];
         if constexpr (XWIN) {
@@ -398,14 +415,14 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
 }
 
 // One tile per wavefront, WAVES_PER_BLOCK tiles per workgroup; the CSR tail = extra workgroups of the same grid.
-template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false, bool C16 = false>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
        const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
        const uint32_t *__restrict__ tile_desc, const int32_t *__restrict__ offset_ptr,
        const int32_t *__restrict__ offset, VT *__restrict__ calibrator, VT *__restrict__ y,
        int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta,
-       const uint32_t *__restrict__ hdr)
+       const uint32_t *__restrict__ hdr, const uint32_t *__restrict__ col16, const int32_t *__restrict__ base16)
 {
     // Pull EVERY kernel argument into SGPRs with the first batch of scalar loads: an argument that is
     // first touched further down would otherwise cost its own kernarg round trip on the critical path.
@@ -439,9 +456,9 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     const int t = __builtin_amdgcn_readfirstlane(blk * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6));
     if (t >= g.p - 1)
         return;
-    tile_body<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT>(
+    tile_body<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, C16>(
         g, t, lane, col, val, x, tile_ptr, tile_desc, offset_ptr, offset, calibrator, y, acc, cnt, meta, hdr,
-        smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>());
+        smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>(), col16, base16);
 }
 
 // ---- carry resolution by a second launch ---------------------------------------------------------
@@ -499,7 +516,7 @@ k_calibrate(Geometry g, const uint32_t *__restrict__ tile_ptr, const uint4 *__re
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------
-template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false, bool C16 = false>
 static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
                              const SpmvOptions &opt, hipStream_t s)
 {
@@ -511,11 +528,11 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
     size_t lds = (size_t)g.tile_elems * sizeof(VT); // tail product buffer (tail workgroups)
     if (lds < (size_t)WAVES_PER_BLOCK * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>())
         lds = (size_t)WAVES_PER_BLOCK * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>();
-    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), lds, s,
+    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, C16>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), lds, s,
                        g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x, d.tile_ptr,
                        d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, tile_blocks,
                        opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt,
-                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr);
+                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr, d.col16, d.base16);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || (FUSED && !opt.long_runs))
         return e;
@@ -534,6 +551,11 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
 #define CSR5_CASE(S)                                                                               \
     case S:                                                                                        \
         if constexpr (FUSED) {                                                                     \
+            if constexpr (col16_sigma(S)) {                                                        \
+                if (opt.x_window && opt.col16 && d.col16)                                          \
+                    return opt.lds_y ? launch_one<VT, S, FUSED, true, true, false, true>(g, d, x, y, opt, s)  \
+                                     : launch_one<VT, S, FUSED, true, false, false, true>(g, d, x, y, opt, s); \
+            }                                                                                      \
             if (opt.x_window)                                                                      \
                 return opt.lds_y ? launch_one<VT, S, FUSED, true, true>(g, d, x, y, opt, s)        \
                                  : launch_one<VT, S, FUSED, true, false>(g, d, x, y, opt, s);      \

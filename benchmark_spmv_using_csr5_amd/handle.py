@@ -156,6 +156,11 @@ class anonymouslibHandle:
         for bit, 4 bytes less per non-zero); 0 (default) = off; csr5hip.h CSR5HIP_OPT_NARROW_VALUES"""
         return self.setOption(_capi.OPT_NARROW_VALUES, int(value))
 
+    def setNarrowColumns(self, value: int) -> int:
+        """x-window kernel: 1 = auto (default) stream 16-bit column codes when every tile spans < 65 536 columns, 0 = off
+        (csr5hip.h CSR5HIP_OPT_NARROW_COLUMNS)"""
+        return self.setOption(_capi.OPT_NARROW_COLUMNS, int(value))
+
     def setTileWalk(self, value: int) -> int:
         """plain path: 0 = one tile per wavefront, 1 = auto (default), 2 = force the range-walking pipelined kernel
         (csr5hip.h CSR5HIP_OPT_TILE_WALK)"""

@@ -121,6 +121,13 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
 #define CSR5HIP_OPT_WALK_RANGES 14 /* number of tile ranges (= wavefronts) of the walking kernel: 0 = default (2 048 = 8 per CU),
                                       else 1 .. 16 384; never more than p - 1 */
 
+#define CSR5HIP_OPT_NARROW_COLUMNS 15 /* x-window kernel: when EVERY tile 0 .. p-2 spans fewer than 65 536 columns (banded / blocked
+                                      matrices; any matrix with n <= 65 536) the kernel streams 16-bit column codes -- column minus the
+                                      tile's smallest column, two per word, kept in a private array next to column_index -- instead of the
+                                      32-bit column words: 2 bytes less per non-zero, the same gathers, bit-identical results.  Built at
+                                      conversion when the x-window kernel is selected (sigma 8, 12, 16, 24 or 32); +2 bytes per non-zero of
+                                      device memory.  1 = auto (default), 0 = off.  csr5hip_info.narrow_columns says what happened. */
+
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
 /* Host-visible snapshot of the handle's private state (anonymouslib_cuda.h:27-52). */
@@ -160,6 +167,7 @@ typedef struct csr5hip_info {
     int slab_cold_entries;         /* entries of that copy behind the table images (columns gathered from memory)        */
     int x_snapshot;                /* CSR5HIP_OPT_X_SNAPSHOT as set                                                      */
     int slab_values_narrowed;      /* 1 = CSR5HIP_OPT_NARROW_VALUES took effect: the slab kernel streams fp32 values       */
+    int narrow_columns;            /* 1 = the x-window kernel streams 16-bit column codes (CSR5HIP_OPT_NARROW_COLUMNS)            */
     int tile_walk;                 /* 1 = spmv() launches the range-walking pipelined kernel (CSR5HIP_OPT_TILE_WALK)           */
     int walk_ranges;               /* tile ranges (wavefronts) of that kernel; 0 = its tables were not built                   */
     int walk_x_window;             /* 1 = it gathers through its 16-KB LDS slice of x (rarely restaged: 4 096 fp32 / 2 048 fp64 columns) */

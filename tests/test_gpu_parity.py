@@ -30,7 +30,7 @@ def _device_csr(mat, val, dtype):
 
 def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None, nt=None,
          slabs=None, slab_shift=None, zero_empty=None, info_out=None, hot=None, x_snapshot=None, narrow=None,
-         walk=None, walk_ranges=None):
+         walk=None, walk_ranges=None, narrow_cols=None):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
@@ -58,6 +58,8 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         assert A.setXSnapshot(x_snapshot) == 0
     if narrow is not None:
         assert A.setNarrowValues(narrow) == 0
+    if narrow_cols is not None:
+        assert A.setNarrowColumns(narrow_cols) == 0
     if walk is not None:
         assert A.setTileWalk(walk) == 0
     if walk_ranges is not None:
@@ -70,7 +72,7 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         info_out.update(column_slabs=i.column_slabs, slab_segments=i.slab_segments, slab_sigma=i.slab_sigma,
                         slab_tiles=i.slab_tiles, sigma=i.sigma, slab_hot=i.slab_hot,
                         slab_hot_cover_pct=i.slab_hot_cover_pct, tile_walk=i.tile_walk, walk_ranges=i.walk_ranges,
-                        p=i.p, x_window_active=i.x_window_active, walk_x_window=i.walk_x_window,
+                        p=i.p, x_window_active=i.x_window_active, walk_x_window=i.walk_x_window, narrow_columns=i.narrow_columns,
                         walk_x_window_cover_pct=i.walk_x_window_cover_pct)
     col_t = ci.cpu().numpy().copy()
     val_t = va.cpu().numpy().copy()
@@ -897,3 +899,44 @@ def test_batch_harness_writes_one_row_per_matrix(tmp_path):
                          text=True, timeout=900)
     assert run.returncode == 0, run.stderr
     assert len(open(out + ".jsonl").readlines()) == 3 and len(list(csv.DictReader(open(out + ".csv")))) == 3
+
+
+@pytest.mark.gpu
+def test_narrow_column_codes(oracle):
+    """CSR5HIP_OPT_NARROW_COLUMNS: the x-window kernel streams 16-bit column codes (column - smallest column of the tile) when
+    every tile spans < 65 536 columns.  Same gathers, same arithmetic: bit-identical to the 32-bit column stream on real data,
+    exact against the oracle on integer data; matrices with and without empty rows / hub rows (the zoo: n < 65 536, so every
+    tile is narrow once the window kernel is forced); a matrix with a tile spanning > 65 535 columns keeps the 32-bit stream."""
+    mats = zoo.small_zoo() + [M.nd24k_like(scale=0.05, dtype=np.float64)]
+    for mat in mats:
+        for sigma, dtype in ((8, np.float64), (16, np.float64), (24, np.float64), (16, np.float32), (32, np.float32)):
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=61, mode="int")
+            if dtype == np.float32:
+                val, x = (val % 3).astype(np.float32), (x % 3).astype(np.float32)
+            fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+            info = {}
+            arrays, col_t, val_t, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=2, slabs=0, info_out=info)
+            _check_format(arrays, col_t, val_t, fmt)  # the format arrays (incl. the 32-bit column_index) are untouched
+            assert info["narrow_columns"] == (1 if fmt.p > 1 else 0), (mat.name, sigma, info)
+            assert np.array_equal(ys[0], _expected_y(oracle, fmt, mat, x, Y_POISON)), (mat.name, sigma, np.dtype(dtype).name)
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=62, mode="real")
+            _, _, _, y16 = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=2, slabs=0, repeat=2)
+            info = {}
+            _, _, _, y32 = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=2, slabs=0, narrow_cols=0, info_out=info)
+            assert info["narrow_columns"] == 0
+            assert np.array_equal(y16[0], y32[0]) and np.array_equal(y16[0], y16[1]), (mat.name, sigma, "bit-identical")
+    # auto: the banded stand-in gets windows AND codes without being asked; sigma 6 (no instantiation) and a wide matrix do not
+    nd = M.nd24k_like(scale=0.05, dtype=np.float32)
+    val, x = M.fill_values(nd.nnz, nd.n, np.float32, seed=63, mode="int")
+    val, x = (val % 3).astype(np.float32), (x % 3).astype(np.float32)
+    info = {}
+    _, _, _, ys = _run(nd, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, dtype=np.float32, info_out=info)
+    assert info["sigma"] == 16 and info["x_window_active"] == 1 and info["narrow_columns"] == 1, info
+    assert np.array_equal(ys[0].astype(np.float64), oracle.csr_spmv(nd.m, nd.row_ptr, nd.col, val.astype(np.float64), x.astype(np.float64)))
+    rng = np.random.default_rng(5)
+    wide = M.csr_from_row_lengths(rng.integers(1, 40, size=30000), 300_000, rng, band=0.0, name="wide")
+    val, x = M.fill_values(wide.nnz, wide.n, np.float64, seed=64, mode="int")
+    info = {}
+    _, _, _, ys = _run(wide, val, x, 16, H.SPMV_FUSED, xwin=2, slabs=0, info_out=info)
+    assert info["x_window_active"] == 1 and info["narrow_columns"] == 0, info
+    assert np.array_equal(ys[0][np.diff(wide.row_ptr) > 0], oracle.csr_spmv(wide.m, wide.row_ptr, wide.col, val, x)[np.diff(wide.row_ptr) > 0])
