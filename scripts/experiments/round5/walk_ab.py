@@ -32,7 +32,7 @@ def measure(mat, label, dtype_name, a, dev, steps=400, cold=True):
         cms, k, cs = B.timed_cold(lambda: B.Problem(mat, label, dtype_name, a, dev, 14), prob, steps, 20)
         cold_us = cms * 1e3
     i = prob.info
-    desc = f"sigma={i.sigma} walk={i.tile_walk}/{i.walk_ranges} xwin={i.x_window_active}/{i.walk_x_window}({i.walk_x_window_cover_pct}%) slabs={i.column_slabs}/hot={i.slab_hot} p={i.p}"
+    desc = f"sigma={i.sigma} walk={i.tile_walk}/{i.walk_ranges} c16={i.narrow_columns} xwin={i.x_window_active}/{i.walk_x_window}({i.walk_x_window_cover_pct}%) slabs={i.column_slabs}/hot={i.slab_hot} p={i.p}"
     b = prob.b_alg
     prob.close()
     return warm_us, cold_us, desc, b
