@@ -22,6 +22,31 @@ namespace csr5 {
 
 constexpr int HOT_BLOCK = HOT_WAVES * OMEGA;
 
+// ---- which tiles of a slab does wavefront range rho walk? ------------------------------------------------------------------
+// The slab's n tiles are dealt evenly to the workgroups (HOT_WAVES ranges each); inside a workgroup the wavefronts do NOT get
+// equal shares.  With two wavefronts per SIMD the one that was launched first wins every issue conflict: measured with
+// wall-clock stamps per range (scripts/experiments/round5/range_stamps.py, R-MAT 24) wavefronts 0-3 of a workgroup finish
+// equal ranges 5.5 % below the mean and wavefronts 4-7 5.5 % above it, in every workgroup and slab (with a skew of 80 per mille: 0.98 ... 1.016) -- and the workgroup waits
+// for its slowest wavefront at every slab boundary (the table refill).  The first half of a workgroup's wavefronts therefore
+// takes HOT_SKEW_PERMIL per mille more tiles than the mean, the second half as much less.
+#ifndef CSR5_HOT_SKEW_PERMIL
+#define CSR5_HOT_SKEW_PERMIL 85
+#endif
+constexpr int HOT_SKEW_PERMIL = HOT_WAVES == 8 ? CSR5_HOT_SKEW_PERMIL : 0;
+__host__ __device__ __forceinline__ int hot_range_begin(int n, int rho) // first tile (relative to the slab) of range rho; rho == ranges: n
+{
+    constexpr int nwg = HOT_RANGES_PER_SLAB / HOT_WAVES;
+    const int wg = rho / HOT_WAVES, j = rho % HOT_WAVES;
+    if (wg >= nwg)
+        return n;
+    const int q = n / nwg, rem = n % nwg;
+    const int wb = wg * q + (wg < rem ? wg : rem), sz = q + (wg < rem ? 1 : 0);
+    // cumulative share of wavefronts 0 .. j-1 in 1/(1000 HOT_WAVES): 1000 + skew each in the first half, 1000 - skew in the second
+    constexpr int half = HOT_WAVES / 2;
+    const int cum = j <= half ? j * (1000 + HOT_SKEW_PERMIL) : half * (1000 + HOT_SKEW_PERMIL) + (j - half) * (1000 - HOT_SKEW_PERMIL);
+    return wb + (int)((long long)sz * cum / (1000 * HOT_WAVES));
+}
+
 // The child's column words come as 3-byte codes (k_hot_encode ENC_PACK) in CSR order -- lane l's sigma codes are
 // consecutive: 2 sigma bytes of col_lo, sigma bytes of col_hi (whole dwords: the child's sigma is a multiple of four) --
 // and are decoded into c[] when they have arrived.
@@ -95,6 +120,14 @@ struct OpenRow {
     bool is_lead; // the row was already open when the range began: the partial goes to lead[range], not to P
 };
 
+#if defined(CSR5_RANGE_STAMPS) // experiment builds only: wall-clock stamps (100 MHz) of every wavefront range: start, end
+__device__ unsigned long long g_range_stamps[2 * 64 * HOT_RANGES_PER_SLAB];
+extern "C" int csr5hip_debug_range_stamps(unsigned long long *dst, int count)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_range_stamps), (size_t)count * sizeof(unsigned long long));
+}
+#endif
+
 template <typename VT, int SIGMA, bool NT, int DEPTH, typename ST = VT>
 __global__ void __launch_bounds__(HOT_BLOCK)
 k_spmv_range(Geometry g, const ST *__restrict__ val, const uint32_t *__restrict__ tile_ptr, VT *__restrict__ P,
@@ -142,10 +175,13 @@ k_spmv_range(Geometry g, const ST *__restrict__ val, const uint32_t *__restrict_
         // this wavefront's contiguous range of the slab's tiles
         const int t0 = hp.tile0[k], n = hp.tile0[k + 1] - t0;
         const int nr = nwg * (HOT_BLOCK / OMEGA), rho = wg * (HOT_BLOCK / OMEGA) + wave;
-        const int q = n / nr, rem = n % nr;
-        const int tb = __builtin_amdgcn_readfirstlane(t0 + rho * q + (rho < rem ? rho : rem));
-        const int te = __builtin_amdgcn_readfirstlane(tb + q + (rho < rem ? 1 : 0));
+        const int tb = __builtin_amdgcn_readfirstlane(t0 + hot_range_begin(n, rho));
+        const int te = __builtin_amdgcn_readfirstlane(t0 + hot_range_begin(n, rho + 1));
         VT *const my_lead = lead + (size_t)k * nr + rho;
+#if defined(CSR5_RANGE_STAMPS)
+        if (lane == 0)
+            g_range_stamps[2 * (k * nr + rho)] = wall_clock64();
+#endif
         if (tb >= te) {
             if (lane == 0)
                 *my_lead = 0;
@@ -402,6 +438,10 @@ k_spmv_range(Geometry g, const ST *__restrict__ val, const uint32_t *__restrict_
             }
         }
         emit_open(); // the last open row of the range: a later range may continue it (its lead is added by k_range_finish)
+#if defined(CSR5_RANGE_STAMPS)
+        if (lane == 0)
+            g_range_stamps[2 * (k * nr + rho) + 1] = wall_clock64();
+#endif
     }
 }
 
@@ -434,9 +474,8 @@ __device__ __forceinline__ RangeHead range_head(const Geometry &g, const int32_t
         return RangeHead{g.tail_start < g.m ? g.tail_start : -1, (long long)(g.p - 1) * g.tile_elems};
     const int k = R / ranges_per_slab, rho = R % ranges_per_slab;
     const int t0 = tile0[k], n = tile0[k + 1] - t0;
-    const int q = n / ranges_per_slab, rem = n % ranges_per_slab;
-    const int tb = t0 + rho * q + (rho < rem ? rho : rem);
-    if (q + (rho < rem ? 1 : 0) <= 0)
+    const int tb = t0 + hot_range_begin(n, rho);
+    if (hot_range_begin(n, rho + 1) - hot_range_begin(n, rho) <= 0)
         return RangeHead{-1, 0};
     return RangeHead{(int)(tile_ptr[tb] & ROW_MASK), (long long)tb * g.tile_elems};
 }

@@ -449,19 +449,26 @@ k_slab_nonempty(int m, const int32_t *__restrict__ row_ptr, uint32_t *__restrict
 // floating-point atomics.  Most blocks need one round; a block whose 256 rows all own a segment in some slab needs four.
 // (Round 2 gave a wavefront 64 rows and fetched the partials row-wise: one 15 %-full load instruction per (block, slab),
 // 4.2 M of them on R-MAT 24, and 16 ballots per block to index them.)
-template <typename VT, int S>
-__global__ void __launch_bounds__(SLAB_BLOCK)
-k_slab_combine(int m, int tail_start, int zero_empty, int m2, const uint32_t *__restrict__ base,
-               const unsigned char *__restrict__ rowidx, const uint32_t *__restrict__ nonempty,
-               const VT *__restrict__ P, VT *__restrict__ y)
+#if defined(CSR5_COMBINE_STAMPS) // experiment builds only: wall-clock stamps (100 MHz) of every wavefront's start and end
+__device__ unsigned long long g_combine_stamps[2 * (1 << 17)];
+extern "C" int csr5hip_debug_combine_stamps(unsigned long long *dst, int count)
 {
-    __shared__ VT acc_all[SLAB_BLOCK / OMEGA][COMBINE_ROWS + OMEGA]; // + one dummy slot per lane
-    const int lane = threadIdx.x & (OMEGA - 1), w = threadIdx.x >> 6;
-    const int blk = blockIdx.x * (SLAB_BLOCK / OMEGA) + w;
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_combine_stamps), (size_t)count * sizeof(unsigned long long));
+}
+#endif
+
+#ifndef CSR5_COMBINE_WAVES
+#define CSR5_COMBINE_WAVES 4
+#endif
+constexpr int COMBINE_WAVES = CSR5_COMBINE_WAVES; // row blocks (= wavefronts) per workgroup of the combine
+// one 256-row block `blk` by one wavefront; `acc` = its COMBINE_ROWS + OMEGA accumulators in LDS
+template <typename VT, int S>
+__device__ __forceinline__ void combine_block(int blk, int lane, VT *acc, int m, int tail_start, int zero_empty, int m2,
+                                              const uint32_t *__restrict__ base, const unsigned char *__restrict__ rowidx,
+                                              const uint32_t *__restrict__ nonempty, const VT *__restrict__ P,
+                                              VT *__restrict__ y)
+{
     const int r0 = blk * COMBINE_ROWS;
-    if (r0 >= m)
-        return;
-    VT *acc = acc_all[w];
     // run bounds of the block: words [blk * S, blk * S + 2 S) = this block's and the next block's starts
     constexpr int BW = (2 * S + OMEGA - 1) / OMEGA;
     uint32_t bw[BW];
@@ -520,6 +527,89 @@ k_slab_combine(int m, int tail_start, int zero_empty, int m2, const uint32_t *__
                 y[r] = 0;
         }
     }
+}
+
+template <typename VT, int S>
+__global__ void __launch_bounds__(COMBINE_WAVES * OMEGA)
+k_slab_combine(int m, int tail_start, int zero_empty, int m2, const uint32_t *__restrict__ base,
+               const unsigned char *__restrict__ rowidx, const uint32_t *__restrict__ nonempty,
+               const VT *__restrict__ P, VT *__restrict__ y)
+{
+    __shared__ VT acc_all[COMBINE_WAVES][COMBINE_ROWS + OMEGA]; // + one dummy slot per lane
+    const int lane = threadIdx.x & (OMEGA - 1), w = threadIdx.x >> 6;
+    // Which 1 024 rows does this workgroup take?  Workgroup b runs on XCD b % 8 (dispatch order), so "rows 1024 b ..." hands
+    // every XCD the row groups with ONE pattern of bits 10-12 of the row index -- and on a graph whose row lengths follow the
+    // bits of the index (R-MAT: a row with a zero bit is 3.2x as long as its sibling with a one) XCD 0 gets 31x the partials of
+    // XCD 7: the kernel ran 180 us with 13 of 32 wavefronts resident and a 40-us tail of one XCD (wall-clock stamps per
+    // wavefront, scripts/experiments/round5/combine_stamps.py).  Inside every octet of consecutive workgroups the row groups
+    // are therefore rotated by a hash of the octet's number: every XCD sees every bit pattern equally often, and which one it
+    // sees is unrelated to the octet's own (equally skewed) index bits.
+    int wg = blockIdx.x;
+    {
+        const int octet = wg >> 3;
+        if ((octet << 3) + 8 <= (int)gridDim.x)
+            wg = (octet << 3) + (((wg & 7) + (int)(((unsigned)octet * 0x9E3779B1u) >> 29)) & 7);
+    }
+    const int blk = wg * COMBINE_WAVES + w;
+    const int r0 = blk * COMBINE_ROWS;
+    if (r0 >= m)
+        return;
+#if defined(CSR5_COMBINE_STAMPS)
+    if (lane == 0 && blk < (1 << 17))
+        g_combine_stamps[2 * blk] = wall_clock64();
+#endif
+    combine_block<VT, S>(blk, lane, acc_all[w], m, tail_start, zero_empty, m2, base, rowidx, nonempty, P, y);
+#if defined(CSR5_COMBINE_STAMPS)
+    if (lane == 0 && blk < (1 << 17))
+        g_combine_stamps[2 * blk + 1] = wall_clock64();
+#endif
+}
+
+
+// Persistent form (CSR5_COMBINE_PERSISTENT builds): 8 workgroups per CU stay resident and every wavefront draws row blocks from
+// a ticket counter (the next ticket is requested before the current block is worked on, so its round trip is hidden).  The
+// counter re-arms itself: every wavefront draws exactly one ticket beyond the last block, so the wavefront that draws ticket
+// nblk + nwaves - 1 is the last to touch it and stores 0.  Which wavefront adds a block does not change a bit of y.
+template <typename VT, int S>
+__global__ void __launch_bounds__(COMBINE_WAVES * OMEGA)
+k_slab_combine_persistent(int m, int tail_start, int zero_empty, int m2, const uint32_t *__restrict__ base,
+                          const unsigned char *__restrict__ rowidx, const uint32_t *__restrict__ nonempty,
+                          const VT *__restrict__ P, VT *__restrict__ y, unsigned *__restrict__ ticket)
+{
+    __shared__ VT acc_all[COMBINE_WAVES][COMBINE_ROWS + OMEGA];
+    const int lane = threadIdx.x & (OMEGA - 1), w = threadIdx.x >> 6;
+    const unsigned nblk = (unsigned)((m + COMBINE_ROWS - 1) / COMBINE_ROWS), nwaves = gridDim.x * COMBINE_WAVES;
+#if defined(CSR5_COMBINE_STATIC)
+    // static schedule: round k hands wavefront g block k * nwaves + ((g + hash(k)) mod nwaves): the blocks of one wavefront come
+    // from different parts of the row range AND carry unrelated low index bits
+    const unsigned g = blockIdx.x * COMBINE_WAVES + w;
+    for (unsigned k = 0; k * nwaves < nblk; k++) {
+        const unsigned t = k * nwaves + (g + (k * 0x9E3779B1u >> 8)) % nwaves;
+        if (t < nblk) {
+            combine_block<VT, S>((int)t, lane, acc_all[w], m, tail_start, zero_empty, m2, base, rowidx, nonempty, P, y);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    (void)ticket;
+    return;
+#endif
+    auto draw = [&]() -> unsigned {
+        unsigned t = 0;
+        if (lane == 0)
+            t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+    };
+    unsigned t = draw();
+    while (t < nblk) {
+        const unsigned next = draw();
+        combine_block<VT, S>((int)t, lane, acc_all[w], m, tail_start, zero_empty, m2, base, rowidx, nonempty, P, y);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // the next block's LDS writes stay behind this block's reads
+        __builtin_amdgcn_wave_barrier();
+        t = next;
+    }
+    if (t == nblk + nwaves - 1u && lane == 0)
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- hot columns of every slab (LDS table of the persistent kernel k_spmv_range, csr5_hot.hip) ---------------------
@@ -1071,12 +1161,26 @@ hipError_t slab_tables(int m, int m2, int nnz, int S, int p, const int32_t *row_
     return hipGetLastError();
 }
 
+#if defined(CSR5_COMBINE_PERSISTENT) // experiment builds: one process-wide ticket word (the product would keep one per handle)
+__device__ unsigned g_combine_ticket = 0;
+#endif
 template <typename VT>
 static hipError_t combine_typed(int m, int tail_start, int zero_empty, int S, int m2, const uint32_t *base,
                                 const unsigned char *rowidx, const uint32_t *nonempty, const void *P, void *y, hipStream_t s)
 {
-    const int rows_per_block = COMBINE_ROWS * (SLAB_BLOCK / OMEGA);
-    const dim3 grid((m + rows_per_block - 1) / rows_per_block), block(SLAB_BLOCK);
+    const int rows_per_block = COMBINE_ROWS * COMBINE_WAVES;
+    const dim3 grid((m + rows_per_block - 1) / rows_per_block), block(COMBINE_WAVES * OMEGA);
+#if defined(CSR5_COMBINE_PERSISTENT)
+    if (S == 16 && (int)grid.x > CSR5_COMBINE_PERSISTENT * 256) {
+        unsigned *ticket = nullptr;
+        hipError_t e = hipGetSymbolAddress((void **)&ticket, HIP_SYMBOL(g_combine_ticket));
+        if (e != hipSuccess)
+            return e;
+        hipLaunchKernelGGL((k_slab_combine_persistent<VT, 16>), dim3(CSR5_COMBINE_PERSISTENT * 256), block, 0, s, m, tail_start,
+                           zero_empty, m2, base, rowidx, nonempty, (const VT *)P, (VT *)y, ticket);
+        return hipGetLastError();
+    }
+#endif
     switch (S) {
 #define CSR5_SLAB_CASE(N)                                                                                              \
     case N:                                                                                                            \
