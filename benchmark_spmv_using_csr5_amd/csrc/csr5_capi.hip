@@ -184,6 +184,8 @@ static int xwin_decision(const csr5hip_handle_s *h)
     constexpr int XWIN_AUTO_COVER_PCT = 70;
     constexpr int XWIN_AUTO_MIN_SIGMA = 16;
     constexpr int XWIN_AUTO_MIN_LINES_F64 = 16;
+    if ((long long)h->g.n * (long long)h->vsize() >= (1LL << 31))
+        return 0; // (the window kernel reads x through a buffer resource with 32-bit byte offsets)
     if (h->xwin_request == 2)
         return 1;
     if (h->xwin_request != 1 || h->g.p <= 1 || h->xwin_tiles <= 0)

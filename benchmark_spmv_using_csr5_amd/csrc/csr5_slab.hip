@@ -451,10 +451,23 @@ k_slab_nonempty(int m, const int32_t *__restrict__ row_ptr, uint32_t *__restrict
 // 4.2 M of them on R-MAT 24, and 16 ballots per block to index them.)
 #if defined(CSR5_COMBINE_STAMPS) // experiment builds only: wall-clock stamps (100 MHz) of every wavefront's start and end
 __device__ unsigned long long g_combine_stamps[2 * (1 << 17)];
+__device__ unsigned long long g_combine_phase[4 * (1 << 17)]; // after the bounds arrived, after the partials arrived, after the adds, end
+#define COMBINE_PHASE(i)                                                                                               \
+    do {                                                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
+        if (lane == 0 && blk < (1 << 17))                                                                              \
+            g_combine_phase[4 * blk + (i)] = wall_clock64();                                                           \
+    } while (0)
+extern "C" int csr5hip_debug_combine_phase(unsigned long long *dst, int count)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_combine_phase), (size_t)count * sizeof(unsigned long long));
+}
 extern "C" int csr5hip_debug_combine_stamps(unsigned long long *dst, int count)
 {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_combine_stamps), (size_t)count * sizeof(unsigned long long));
 }
+#else
+#define COMBINE_PHASE(i)
 #endif
 
 #ifndef CSR5_COMBINE_WAVES
@@ -484,6 +497,7 @@ __device__ __forceinline__ void combine_block(int blk, int lane, VT *acc, int m,
 #pragma unroll
     for (int j = 0; j < COMBINE_ROWS / OMEGA; j++)
         acc[j * OMEGA + lane] = 0;
+    COMBINE_PHASE(0);
     auto bound = [&](int e) -> int { return __builtin_amdgcn_readlane((int)bw[e / OMEGA], e % OMEGA); };
     constexpr int G = S < 16 ? S : 16; // runs whose loads are in flight together
     const unsigned dummy = COMBINE_ROWS + lane;
@@ -508,6 +522,7 @@ __device__ __forceinline__ void combine_block(int blk, int lane, VT *acc, int m,
                 part[q] = P[j];
                 idx[q] = rowidx[j];
             }
+            COMBINE_PHASE(1);
 #pragma unroll
             for (int q = 0; q < G; q++) {
                 const unsigned slot = off + lane < len[q] ? idx[q] : dummy;
@@ -515,6 +530,7 @@ __device__ __forceinline__ void combine_block(int blk, int lane, VT *acc, int m,
             }
         }
     }
+    COMBINE_PHASE(2);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll

@@ -45,6 +45,27 @@ constexpr int wave_lds_bytes()
     return (b + 15) & ~15;
 }
 
+#if defined(CSR5_TILE_STAMPS) // experiment builds only: wall-clock stamps (100 MHz) per tile: start, all loads + gathers landed, end
+static __device__ unsigned long long g_tile_stamps[3 * (1 << 16)];
+#if defined(CSR5_SPMV_ONLY_F32) // (the file is compiled once per value type: one array and one export per half)
+extern "C" int csr5hip_debug_tile_stamps_f32(unsigned long long *dst, int count)
+#else
+extern "C" int csr5hip_debug_tile_stamps_f64(unsigned long long *dst, int count)
+#endif
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_tile_stamps), (size_t)count * sizeof(unsigned long long));
+}
+#define TILE_STAMP(i, wait)                                                                                            \
+    do {                                                                                                               \
+        if (wait)                                                                                                      \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                           \
+        if (lane == 0 && t < (1 << 16))                                                                                \
+            g_tile_stamps[3 * t + (i)] = wall_clock64();                                                               \
+    } while (0)
+#else
+#define TILE_STAMP(i, wait)
+#endif
+
 // ---- tiles 0..p-2 ------------------------------------------------------------------------------
 // SIGMA > 0: compile-time sigma (loads hoisted into registers, flag walk fully unrolled).
 // SIGMA == 0: run-time sigma (any 1..32), same code shape, used for sigma < 4 and as a cross-check.
@@ -222,6 +243,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             mv[i] = v[i];
             mx[i] = xv[i];
         }
+        TILE_STAMP(1, true);
     } else if constexpr (FUSED) {
         mt = make_uint4(__builtin_amdgcn_readlane(hw, 0), __builtin_amdgcn_readlane(hw, 1),
                         __builtin_amdgcn_readlane(hw, 2), __builtin_amdgcn_readlane(hw, 3));
@@ -456,9 +478,11 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     const int t = __builtin_amdgcn_readfirstlane(blk * WAVES_PER_BLOCK + (int)(threadIdx.x >> 6));
     if (t >= g.p - 1)
         return;
+    TILE_STAMP(0, false);
     tile_body<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, C16>(
         g, t, lane, col, val, x, tile_ptr, tile_desc, offset_ptr, offset, calibrator, y, acc, cnt, meta, hdr,
         smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>(), col16, base16);
+    TILE_STAMP(2, false);
 }
 
 // ---- carry resolution by a second launch ---------------------------------------------------------

@@ -8,7 +8,7 @@ src=$root/benchmark_spmv_using_csr5_amd/csrc
 out=/tmp/csr5_spmvvar_$name
 mkdir -p $out
 make -C $src -j8 all > /dev/null
-HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -I$root/include -I$src -DCSR5_FEW_SIGMAS $flags"
+HIPFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -I$root/include -I$src $flags"
 /opt/rocm/bin/hipcc $HIPFLAGS -DCSR5_SPMV_ONLY_F64 -c $src/csr5_spmv.hip -o $out/csr5_spmv_f64.o &
 /opt/rocm/bin/hipcc $HIPFLAGS -DCSR5_SPMV_ONLY_F32 -c $src/csr5_spmv.hip -o $out/csr5_spmv_f32.o &
 wait

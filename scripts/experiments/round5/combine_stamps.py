@@ -50,3 +50,16 @@ print("slowest blocks (block, start us, lifetime us):", [(int(idx[i]), round(flo
 for q in range(8):
     sel = slice(q * len(life) // 8, (q + 1) * len(life) // 8)
     print(f"  blocks {q}/8 of the rows: mean lifetime {life[sel].mean():.2f} us, mean start {s[sel].mean():.1f} us")
+# phases of a block (experiment build): bounds arrived / partials arrived / adds done, relative to the wavefront's start
+ph = np.zeros(4 * nblk, dtype=np.uint64)
+if hasattr(lib, "csr5hip_debug_combine_phase"):
+    lib.csr5hip_debug_combine_phase.argtypes = [C.c_void_p, C.c_int]
+    if lib.csr5hip_debug_combine_phase(ph.ctypes.data, 4 * nblk) == 0:
+        ph = ph.astype(np.int64).reshape(nblk, 4)
+        good = ok & (ph[:, 0] >= t0) & (ph[:, 2] >= ph[:, 0])
+        a = (ph[good, 0] - t0[good]) / 100.0
+        b = (ph[good, 1] - ph[good, 0]) / 100.0
+        c = (ph[good, 2] - ph[good, 1]) / 100.0
+        dd = (t1[good] - ph[good, 2]) / 100.0
+        print(f"phases (us, mean / median): bounds {a.mean():.2f} / {np.median(a):.2f}; partials (last round) {b.mean():.2f} / {np.median(b):.2f}; "
+              f"adds {c.mean():.2f} / {np.median(c):.2f}; stores {dd.mean():.2f} / {np.median(dd):.2f}")
