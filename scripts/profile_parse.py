@@ -12,7 +12,7 @@ import os
 import sys
 
 tag, d, out = sys.argv[1], sys.argv[2], sys.argv[3]
-STEP = ("k_spmv", "k_slab_combine", "k_calibrate", "k_range_finish")
+STEP = ("k_spmv", "k_slab_combine", "k_calibrate", "k_range_finish", "k_x_permute")
 MAIN = ("k_spmv_hot", "k_spmv_range", "k_spmv<")
 
 
