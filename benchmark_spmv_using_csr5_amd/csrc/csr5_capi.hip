@@ -309,17 +309,19 @@ int csr5hip_set_x(csr5hip_handle h, const void *d_x)
 
 // gfx950 tables in the shape of the reference's (r, s, t, u) rule (anonymouslib_cuda.h:297-313, one table per
 // architecture and precision there too): k = nnz/m; sigma = r if k <= r; k if k <= s; s if k <= t; else u.
-// fp64: (6, 16, 256, 16); fp32: (8, 16, 256, 16) -- from sweeps of all sigma over mean row lengths 2..512, random and
+// fp64: (6, 16, 256, 16); fp32: (8, 16, 256, 24) -- from sweeps of all sigma over mean row lengths 2..512, random and
 // near-diagonal columns (scripts/experiments/sigma_table.py; profiles/r01_sigma_table.txt, re-run on the round-4 kernels in
 // profiles/r04_sigma_table.txt): the sigma surface is flat on gfx950 and the rules stay within a few per cent of the measured
 // best everywhere.  r = 6 instead of the reference's 4 costs random-column fp64 matrices < 1 % and gains 4-8 % where the
 // columns are local; fp32 rows are half as wide, so a tile of the same byte size holds twice the elements: short rows
 // (k <= 8) with local columns ran 5-8 % faster at sigma = 8 than at 6, at no cost with random columns.  Beyond 256
 // non-zeros per row sigma = 32 would gain 3-7 % on random columns but loses 10 % on the nd24k-like stand-in (x-window +
-// jitter): u = 16.
+// jitter): u = 16 for fp64.  fp32, round 5 (x-window kernel with narrow column codes, same-call pairs on nd24k-like: sigma 16 /
+// 20 / 24 / 32 = 52.4-53.0 / 53.7 / 51.1-51.6 / 52.4 us cold, 39.4-40.1 / 40.4 / 39.4-39.8 / 42.8 warm): u = 24 -- a 6-KB tile
+// like fp64's sigma = 16 ... 8.
 int csr5hip_auto_sigma(int m, int nnz, int value_type)
 {
-    const int r = value_type == CSR5HIP_F32 ? 8 : 6, s = 16, t = 256, u = 16;
+    const int r = value_type == CSR5HIP_F32 ? 8 : 6, s = 16, t = 256, u = value_type == CSR5HIP_F32 ? 24 : 16;
     const int k = m > 0 ? nnz / m : 0;
     if (k <= r) return r;
     if (k <= s) return k;

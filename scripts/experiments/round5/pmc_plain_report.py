@@ -9,14 +9,15 @@ import sys
 
 raw = open(sys.argv[1]).read()
 blocks = re.split(r"^#### ", raw, flags=re.M)[1:]
-TILES = {"nd24k": 28054, "webbase": 8087, "scircuit": 2497}  # tiles 0 .. p-2 at the auto sigma (16 / 6 / 6)
+TILES = {"nd24k": 28054, "webbase": 8087, "scircuit": 2497}  # tiles 0 .. p-2 at sigma 16 (nd24k: both kernels at 16) / 6 / 6
 
 print("""## What holds the plain-path tile kernels on the SuiteSparse-shaped stand-ins (round 5, final sources)?
 ## csr5::k_spmv = one tile per wavefront (rounds 1-4; + narrow column codes on the x-window variant since round 5);
 ## csr5::k_spmv_walk = the range-walking, software-pipelined kernel of round 5 (CSR5HIP_OPT_TILE_WALK = 2; DEPTH 3, 8 ranges per CU).
 ## rocprofv3 --pmc passes (one counter group per pass, counters + kernel trace only), scripts/experiments/round5/pmc_plain.sh on
 ## `bench.py --workload W --slabs 0 --tile-walk off|force --no-sub-configs --no-side-figures --steps 20 --warmup 5`; averages over the
-## 40 COLD-protocol launches (rotating copies of matrix / x / y beyond the Infinity Cache).  Sums over the chip: 256 CUs (TA / TCP / SQ),
+## 40 COLD-protocol launches (rotating copies of matrix / x / y beyond the Infinity Cache); nd24k-like at sigma = 16 for both kernels
+## (the walking kernel is compiled for sigma <= 16; the fp32 auto rule picks 24 for the one-tile kernel since round 5).  Sums over the chip: 256 CUs (TA / TCP / SQ),
 ## 128 L2 channels (TCC), 8 XCDs (GRBM).  SQ_* counters are in units of 4 clocks per wavefront.  Clock under the profiler ~2.1 GHz.
 """)
 
