@@ -545,8 +545,10 @@ static int reserve_aux(csr5hip_handle h)
     // zero-initialised part first
     const size_t o_desc = take(desc_words * 4), o_offp = take(p1 * 4), o_cal = take(p1 * h->vsize()),
                  o_acc = take(p1 * h->vsize()), o_cnt = take(p1 * 4), o_counters = take(COUNTER_WORDS * 4), o_tp = take(p1 * 4), o_offset = take(offset_cap * 4);
-    // range-walking kernel (csr5_walk.hip): arrival words of the ranges (zero between launches), then its tables
-    const bool walk_tables = !h->is_child;
+    // range-walking kernel (csr5_walk.hip): arrival words of the ranges (zero between launches), then its tables -- only when
+    // the kernel is enabled at conversion time (CSR5HIP_OPT_TILE_WALK != 0 before asCSR5): its 16-KB windows are found by the
+    // same pass as the one-tile kernel's and would cost every conversion a second scoring of every tile
+    const bool walk_tables = !h->is_child && h->walk_request != 0;
     const size_t wr = walk_tables ? (size_t)WALK_MAX_RANGES + 2 : 0;
     const size_t o_wacc = take(wr * h->vsize()), o_wcnt = take(wr * 4);
     const size_t zero_bytes = off;

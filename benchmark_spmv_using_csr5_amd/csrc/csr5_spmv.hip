@@ -590,7 +590,7 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
         return opt.lds_y ? launch_one<VT, S, FUSED, false, true>(g, d, x, y, opt, s)               \
                          : launch_one<VT, S, FUSED, false, false>(g, d, x, y, opt, s);
 #if defined(CSR5_FEW_SIGMAS) // experiment builds: few instantiations only
-        CSR5_CASE(4) CSR5_CASE(5) CSR5_CASE(8) CSR5_CASE(12) CSR5_CASE(16) CSR5_CASE(20) CSR5_CASE(32)
+        CSR5_CASE(4) CSR5_CASE(5) CSR5_CASE(6) CSR5_CASE(8) CSR5_CASE(12) CSR5_CASE(16) CSR5_CASE(20) CSR5_CASE(24) CSR5_CASE(32)
 #else
         CSR5_CASE(4) CSR5_CASE(5) CSR5_CASE(6) CSR5_CASE(7) CSR5_CASE(8) CSR5_CASE(9) CSR5_CASE(10)
         CSR5_CASE(11) CSR5_CASE(12) CSR5_CASE(13) CSR5_CASE(14) CSR5_CASE(15) CSR5_CASE(16)

@@ -114,7 +114,9 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       arrival protocol -- instead of one tile per wavefront.  Same format arrays, same results up to
                                       the association of cut rows' partial sums (bit-reproducible run to run either way).
                                       0 = off (default), 1 = auto (on when every range gets >= 4 tiles and sigma is in 4..16), 2 = force
-                                      (still needs sigma in 4..16).  Off by default because on MI355X it measured 5-15 % SLOWER
+                                      (still needs sigma in 4..16).  Set it BEFORE asCSR5(): the kernel's tables are built by the
+                                      conversion only when the option is non-zero then (turning it on afterwards has no effect
+                                      until the next conversion).  Off by default because on MI355X it measured 5-15 % SLOWER
                                       than the one-tile kernel on every BASELINE stand-in (profiles/r05_walk.md): with ~2 500
                                       issue cycles of per-tile work a wavefront is instruction-bound, and the 2-3 wavefronts per
                                       SIMD its registers and LDS leave room for hide less of that than the one-tile kernel's 7. */
