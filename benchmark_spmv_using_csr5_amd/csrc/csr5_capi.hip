@@ -652,12 +652,11 @@ static int walk_ranges_for(const csr5hip_handle_s *h)
 {
     int want = h->walk_ranges_request;
     if (want <= 0) {
-        static int cus = 0; // (written once with the same value by whoever comes first)
-        if (cus <= 0) {
-            int dev = 0, n = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-                n = 256;
-            cus = n;
+        int dev = 0, cus = 0; // (asked once per conversion: no process-wide cache to race on or to go stale)
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
         }
         const int lds = walk_wave_lds_bytes(h->g.sigma, (int)h->vsize(), h->opt.walk_x_window);
         int per_cu = (160 * 1024) / (lds > 0 ? lds : 1);
