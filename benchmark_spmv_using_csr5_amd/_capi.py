@@ -42,6 +42,7 @@ OPT_NARROW_VALUES = 12
 OPT_TILE_WALK = 13
 OPT_WALK_RANGES = 14
 OPT_NARROW_COLUMNS = 15
+OPT_DEFER_CARRIES = 16
 MULTI_OPT_ROW_WEIGHT = 100  # csr5hip_multi_set_option only (before input_csr)
 MULTI_OPT_OWN_REPLICAS = 101  # csr5hip_multi_set_option only (before set_x): devices[0]'s shards read a broadcast replica too
 
@@ -64,6 +65,7 @@ class Csr5Info(C.Structure):
         ("device_bytes", C.c_longlong),
         ("slab_x_permuted", C.c_int), ("slab_cold_entries", C.c_int), ("x_snapshot", C.c_int),
         ("slab_values_narrowed", C.c_int),
+        ("carries_deferred", C.c_int),
         ("narrow_columns", C.c_int),
         ("tile_walk", C.c_int),
         ("walk_ranges", C.c_int),

@@ -117,6 +117,10 @@ struct csr5hip_handle_s {
     uint32_t *host_words = nullptr;    // 32 pinned, device-visible words the last conversion kernels export into
     int walk_request = 0;        // CSR5HIP_OPT_TILE_WALK: 0 off (default), 1 auto, 2 force
     int walk_ranges_request = 0; // CSR5HIP_OPT_WALK_RANGES: 0 = default
+    // deferred carries (csr5_format.hip k_defer_carries): decided at conversion
+    int defer_request = 1;       // CSR5HIP_OPT_DEFER_CARRIES: 0 off, 1 auto (default), 2 force
+    unsigned multi_heads = 0;    // run heads at which >= 2 partials meet
+    bool carries_deferred = false;
     // narrow column codes of the x-window kernel (csr5_format.hip k_col16): built when that kernel is selected
     int col16_request = 1;       // CSR5HIP_OPT_NARROW_COLUMNS: 0 off, 1 auto (default)
     bool col16_built = false;    // the codes of the current conversion exist
@@ -450,6 +454,15 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
             }
         }
         break;
+    case CSR5HIP_OPT_DEFER_CARRIES:
+        if (value < 0 || value > 2)
+            return CSR5HIP_INVALID_ARGUMENT;
+        if (h->format == CSR5HIP_FORMAT_CSR5 && value != h->defer_request) {
+            set_last_error("CSR5HIP_OPT_DEFER_CARRIES takes effect at asCSR5(): set it while the matrix is in CSR form");
+            return CSR5HIP_INVALID_ARGUMENT;
+        }
+        h->defer_request = value;
+        break;
     case CSR5HIP_OPT_NARROW_COLUMNS:
         if (value != 0 && value != 1)
             return CSR5HIP_INVALID_ARGUMENT;
@@ -724,6 +737,17 @@ static int derive_kernel_tables(csr5hip_handle h)
     h->xwin_lines = (long long)w[5];
     h->walk_xwin_tiles = (int)w[6];
     h->walk_xwin_covered = (long long)w[7];
+    h->multi_heads = w[20];
+    // deferred carries: forced, or (auto) on a matrix of many tiles most of which take part in a multi-party handshake -- there
+    // the returning atomics at the end of every tile cost more than the second launch that replaces them (k_defer_carries)
+    h->carries_deferred = false;
+    if (!h->is_child && h->opt.mode == 1 && g.p > 1 && h->multi_heads > 0 &&
+        (h->defer_request == 2 ||
+         (h->defer_request == 1 && g.p - 1 >= DEFER_AUTO_MIN_TILES && (long long)h->multi_heads * 2 >= (long long)(g.p - 1)))) {
+        HIP_TRY(launch_defer_carries(g, h->d, s)); // (stream-ordered in front of every SpMV)
+        h->carries_deferred = true;
+        h->opt.long_runs = 1;
+    }
     // phase times from the kernels' wall-clock stamps (k_row_scan, k_tile_desc, k_transpose, k_tile_tables); a phase
     // whose kernel did not run (single-tile matrices) has no stamp and takes the next one's
     unsigned long long st[4];
@@ -1794,6 +1818,7 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_cold_entries = info->slab_x_permuted ? h->cold_total : 0;
     info->x_snapshot = h->x_snapshot;
     info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
+    info->carries_deferred = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->carries_deferred ? 1 : 0;
     info->narrow_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.x_window && h->opt.col16 ? 1 : 0;
     info->tile_walk = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.walk ? 1 : 0;
     info->walk_ranges = h->format == CSR5HIP_FORMAT_CSR5 ? h->d.walk_ranges : 0;

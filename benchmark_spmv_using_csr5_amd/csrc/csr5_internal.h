@@ -23,7 +23,7 @@ constexpr int FMT_BLOCK = OMEGA * FMT_WAVES_PER_BLOCK;
 constexpr int BIT_SS = 6;                     // bits of scansum_offset at omega = 64
 constexpr uint32_t ROW_MASK = 0x7FFFFFFFu;    // tile_ptr bit 31 = "tile has empty rows"
 constexpr int STAMP_WORD = 8;                 // counters[8..15]: wall-clock stamps of the conversion phases
-constexpr int COUNTER_WORDS = 16;
+constexpr int COUNTER_WORDS = 24;            // [16] = run heads at which >= 2 partials meet (summed by k_stats_export)
 constexpr int NUM_XCD = 8;
 constexpr int RUN_SERIAL_MAX = 64;            // carry runs up to this many tiles resolve in-kernel; longer ones in k_calibrate
 #ifndef CSR5_XWIN_BYTES
@@ -121,6 +121,9 @@ hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int valu
 hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col16, int32_t *base16, uint32_t *wide_tiles,
                         hipStream_t s);
 constexpr bool col16_sigma(int sigma) { return sigma == 8 || sigma == 12 || sigma == 16 || sigma == 24 || sigma == 32; }
+// deferred carries: every run head at which >= 2 partials meet is marked like a long run (carry_meta bit 26, in the array and in
+// the tile headers), so that its parties park their partials with plain stores and k_calibrate adds them
+hipError_t launch_defer_carries(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_warmup(hipStream_t s);
 // flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)
 hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,
@@ -169,6 +172,7 @@ struct SpmvOptions {
     int walk_long_runs; // resolved: some row spans > RUN_SERIAL_MAX ranges (the walking kernel adds k_calibrate)
     int walk_x_window;  // resolved: the walking kernel stages its (larger, rarely restaged) slice of x in LDS
 };
+constexpr int DEFER_AUTO_MIN_TILES = 8192;  // auto: carries are deferred to k_calibrate from this many tiles on (when most tiles hand-shake)
 constexpr int WALK_XWIN_BYTES = 16384;      // the walking kernel's slice of x in LDS per wavefront: 4 096 fp32 / 2 048 fp64 columns
 constexpr int WALK_MAX_SIGMA = 16;          // one descriptor packet per lane, two register sets of sigma elements
 constexpr int WALK_MAX_RANGES = 16384;      // upper bound of CSR5HIP_OPT_WALK_RANGES (k_walk_tables: one workgroup)

@@ -520,8 +520,10 @@ k_calibrate(Geometry g, const uint32_t *__restrict__ tile_ptr, const uint4 *__re
         if (LONG_ONLY)
             head = head && ((mt.x >> 26) & 1u);
     }
-    if (!LONG_ONLY && head && len <= RUN_SERIAL_MAX)
-        y[r] = sum_run<VT, false>(calibrator, t, len, has_first, has_first ? y[r] : (VT)0, lane, lane);
+    // (LONG_ONLY also serves the runs whose parties were told to park although they are short: deferred carries,
+    //  CSR5HIP_OPT_DEFER_CARRIES -- the closing partial waits in acc[head], as for a long run)
+    if (head && len <= RUN_SERIAL_MAX)
+        y[r] = sum_run<VT, false>(calibrator, t, len, has_first, has_first ? (LONG_ONLY ? acc[t] : y[r]) : (VT)0, lane, lane);
     unsigned long long todo = __ballot(head && len > RUN_SERIAL_MAX);
     while (todo) {
         const int leader = __builtin_ctzll(todo);

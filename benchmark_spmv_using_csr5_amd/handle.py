@@ -156,6 +156,11 @@ class anonymouslibHandle:
         for bit, 4 bytes less per non-zero); 0 (default) = off; csr5hip.h CSR5HIP_OPT_NARROW_VALUES"""
         return self.setOption(_capi.OPT_NARROW_VALUES, int(value))
 
+    def setDeferCarries(self, value: int) -> int:
+        """cut rows finished by a second small launch instead of in-kernel arrival atomics: 0 = off, 1 = auto (default), 2 = force;
+        set before asCSR5 (csr5hip.h CSR5HIP_OPT_DEFER_CARRIES)"""
+        return self.setOption(_capi.OPT_DEFER_CARRIES, int(value))
+
     def setNarrowColumns(self, value: int) -> int:
         """x-window kernel: 1 = auto (default) stream 16-bit column codes when every tile spans < 65 536 columns, 0 = off
         (csr5hip.h CSR5HIP_OPT_NARROW_COLUMNS)"""

@@ -130,6 +130,16 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       conversion when the x-window kernel is selected (sigma 8, 12, 16, 24 or 32); +2 bytes per non-zero of
                                       device memory.  1 = auto (default), 0 = off.  csr5hip_info.narrow_columns says what happened. */
 
+#define CSR5HIP_OPT_DEFER_CARRIES 16 /* fused mode, plain path.  A row cut by a tile boundary is finished inside the launch by an arrival
+                                      protocol that costs each party one returning device-scope atomic at the end of its tile.  On
+                                      matrices of many tiles whose rows are mostly longer than a tile's reach (banded / blocked, hundreds
+                                      of non-zeros per row) those round trips are 11-13 % of the kernel: there the parties PARK their
+                                      partials with plain stores and a second small launch (k_calibrate, the one rows spanning > 64 tiles
+                                      already use) adds them in tile order -- bit-identical results, spmv() stays one call.
+                                      1 = auto (default: >= 8 192 tiles and at least half of them hand-shake), 0 = off, 2 = force.
+                                      Takes effect at asCSR5(): set it while the matrix is in CSR form.
+                                      csr5hip_info.carries_deferred says what happened. */
+
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
 /* Host-visible snapshot of the handle's private state (anonymouslib_cuda.h:27-52). */
@@ -169,6 +179,7 @@ typedef struct csr5hip_info {
     int slab_cold_entries;         /* entries of that copy behind the table images (columns gathered from memory)        */
     int x_snapshot;                /* CSR5HIP_OPT_X_SNAPSHOT as set                                                      */
     int slab_values_narrowed;      /* 1 = CSR5HIP_OPT_NARROW_VALUES took effect: the slab kernel streams fp32 values       */
+    int carries_deferred;          /* 1 = cut rows are finished by a second small launch (CSR5HIP_OPT_DEFER_CARRIES)             */
     int narrow_columns;            /* 1 = the x-window kernel streams 16-bit column codes (CSR5HIP_OPT_NARROW_COLUMNS)            */
     int tile_walk;                 /* 1 = spmv() launches the range-walking pipelined kernel (CSR5HIP_OPT_TILE_WALK)           */
     int walk_ranges;               /* tile ranges (wavefronts) of that kernel; 0 = its tables were not built                   */

@@ -30,7 +30,7 @@ def _device_csr(mat, val, dtype):
 
 def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None, nt=None,
          slabs=None, slab_shift=None, zero_empty=None, info_out=None, hot=None, x_snapshot=None, narrow=None,
-         walk=None, walk_ranges=None, narrow_cols=None):
+         walk=None, walk_ranges=None, narrow_cols=None, defer=None):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
@@ -60,6 +60,8 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         assert A.setNarrowValues(narrow) == 0
     if narrow_cols is not None:
         assert A.setNarrowColumns(narrow_cols) == 0
+    if defer is not None:
+        assert A.setDeferCarries(defer) == 0
     if walk is not None:
         assert A.setTileWalk(walk) == 0
     if walk_ranges is not None:
@@ -73,7 +75,7 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
                         slab_tiles=i.slab_tiles, sigma=i.sigma, slab_hot=i.slab_hot,
                         slab_hot_cover_pct=i.slab_hot_cover_pct, tile_walk=i.tile_walk, walk_ranges=i.walk_ranges,
                         p=i.p, x_window_active=i.x_window_active, walk_x_window=i.walk_x_window, narrow_columns=i.narrow_columns,
-                        walk_x_window_cover_pct=i.walk_x_window_cover_pct)
+                        walk_x_window_cover_pct=i.walk_x_window_cover_pct, carries_deferred=i.carries_deferred)
     col_t = ci.cpu().numpy().copy()
     val_t = va.cpu().numpy().copy()
     ys = []
@@ -513,14 +515,16 @@ def test_seeded_fuzz_against_oracle(oracle):
         # the range-walking kernel (forced; it runs when sigma is in 4..16, fused mode, no slabs) with few / default ranges
         walk = int(rng.choice([0, 2])) if mode == H.SPMV_FUSED else None
         walk_ranges = int(rng.choice([0, 1, 2, 3, 7, 40])) if walk else None
+        # cut rows finished by the second launch instead of the arrival protocol (forced) on every other fused case
+        defer = (0, 2)[(case // 2) % 2] if mode == H.SPMV_FUSED else None
         fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
         arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, dtype=dtype, xwin=xwin, ldsy=ldsy, nt=nt, repeat=2,
                                         slabs=slabs, hot=hot, x_snapshot=snap, narrow=narrow, walk=walk,
-                                        walk_ranges=walk_ranges)
+                                        walk_ranges=walk_ranges, defer=defer)
         _check_format(arrays, col_t, val_t, fmt)
         exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
         for y in ys:
-            assert np.array_equal(y, exp), (case, m, n, sigma, mode, xwin, ldsy, nt, slabs, hot, dtype, walk, walk_ranges,
+            assert np.array_equal(y, exp), (case, m, n, sigma, mode, xwin, ldsy, nt, slabs, hot, dtype, walk, walk_ranges, defer,
                                             np.flatnonzero(y != exp)[:5])
 
 
@@ -899,6 +903,55 @@ def test_batch_harness_writes_one_row_per_matrix(tmp_path):
                          text=True, timeout=900)
     assert run.returncode == 0, run.stderr
     assert len(open(out + ".jsonl").readlines()) == 3 and len(list(csv.DictReader(open(out + ".csv")))) == 3
+
+
+@pytest.mark.gpu
+def test_deferred_carries(oracle):
+    """CSR5HIP_OPT_DEFER_CARRIES: the parties of every cut row park their partials with plain stores and a second launch
+    (k_calibrate) adds them in tile order.  Forced on the zoo and on a matrix whose rows span many tiles: exact against the
+    oracle on integer data; on real data bit-identical to the in-kernel arrival protocol and to the two-pass mode, launch after
+    launch; every kernel family (x-window, 16-bit codes, LDS y, NT).  Auto engages on a large nd24k-like matrix only."""
+    rng = np.random.default_rng(91)
+    lens = rng.integers(1500, 9000, size=200)
+    lens[::5] = rng.integers(0, 40, size=lens[::5].size)
+    long_rows = M.csr_from_row_lengths(lens, 50_000, rng, band=0.0, name="long-rows")
+    mats = zoo.small_zoo() + [long_rows, M.nd24k_like(scale=0.05, dtype=np.float64)]
+    for mat in mats:
+        for sigma, dtype, kw in ((4, np.float64, {}), (16, np.float64, dict(xwin=2)), (7, np.float64, dict(ldsy=2)),
+                                 (24, np.float32, dict(xwin=2)), (16, np.float32, dict(nt=2)), (32, np.float32, {})):
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=71, mode="int")
+            if dtype == np.float32:
+                val, x = (val % 3).astype(np.float32), (x % 3).astype(np.float32)
+            fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+            info = {}
+            arrays, col_t, val_t, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, walk=0, defer=2, repeat=2,
+                                            info_out=info, **kw)
+            _check_format(arrays, col_t, val_t, fmt)
+            exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+            assert np.array_equal(ys[0], exp) and np.array_equal(ys[1], exp), (mat.name, sigma, np.dtype(dtype).name, info)
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=72, mode="real")
+            info_on, info_off = {}, {}
+            _, _, _, yd = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, walk=0, defer=2, repeat=3, info_out=info_on, **kw)
+            _, _, _, yo = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, walk=0, defer=0, info_out=info_off, **kw)
+            _, _, _, y2 = _run(mat, val, x, sigma, H.SPMV_TWO_PASS, dtype=dtype, slabs=0)
+            assert info_off["carries_deferred"] == 0
+            if mat is long_rows:
+                assert info_on["carries_deferred"] == 1, info_on
+            for y in yd:
+                assert np.array_equal(y, yo[0]), (mat.name, sigma, "deferred == arrival protocol, bit for bit")
+            if mat is long_rows:  # rows certainly cut by tiles: same partials, same order as the two-pass calibrator
+                cut = np.diff(mat.row_ptr) > 64 * sigma * 2
+                assert np.array_equal(yd[0][cut], y2[0][cut]), (mat.name, sigma, "deferred == two-pass")
+    # auto: many tiles, most of them hand-shaking -> deferred; the same matrix at a tenth of the size -> not
+    for scale, expect in ((0.5, 1), (0.05, 0)):
+        nd = M.nd24k_like(scale=scale, dtype=np.float32)
+        val, x = M.fill_values(nd.nnz, nd.n, np.float32, seed=73, mode="int")
+        val, x = (val % 3).astype(np.float32), (x % 3).astype(np.float32)
+        info = {}
+        _, _, _, ys = _run(nd, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, dtype=np.float32, info_out=info)
+        assert info["carries_deferred"] == expect, (scale, info)
+        assert np.array_equal(ys[0].astype(np.float64),
+                              oracle.csr_spmv(nd.m, nd.row_ptr, nd.col, val.astype(np.float64), x.astype(np.float64)))
 
 
 @pytest.mark.gpu
