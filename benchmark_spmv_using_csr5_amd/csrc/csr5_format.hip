@@ -656,9 +656,10 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
 // Narrow column codes (ours; a kernel-side table like the x-window, the format arrays are untouched).  A tile of a banded /
 // blocked matrix spans far fewer than 2^16 columns: column - (smallest column of the tile) fits 16 bits, and the x-window
 // kernel then streams 2 bytes per non-zero instead of 4 (fp32: 6 instead of 8 bytes per non-zero in all).  One wavefront per
-// tile t < p-1: minimum and maximum of the tile's column words (same positions as the tile-ordered column_index, so a code
-// pairs with the value at its position whether or not the tile was transposed), the codes two per word, base16[t]; a tile
-// that spans 65 536 columns or more counts into *wide_tiles -- the codes are used only when that stays 0.
+// tile t < p-1: minimum and maximum of the tile's column words, the codes of a lane's elements (2 dd, 2 dd + 1) in its word dd
+// (element i of lane l = position i * 64 + l of the tile-ordered column_index, so a code pairs with the value there whether or
+// not the tile was transposed), a lane's words in 16-byte pieces, base16[t]; a tile that spans 65 536 columns or more counts
+// into *wide_tiles -- the codes are used only when that stays 0.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(FMT_BLOCK) k_col16(Geometry g, const int32_t *__restrict__ col, uint32_t *__restrict__ col16,
                                                  int32_t *__restrict__ base16, uint32_t *__restrict__ wide_tiles)
@@ -685,10 +686,15 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_col16(Geometry g, const int32_t *
         if (hi - lo >= 65536)
             atomicAdd(wide_tiles, 1u);
     }
-    uint32_t *out = col16 + (size_t)t * (g.tile_elems / 2) + lane;
-    for (int dd = 0; dd < g.sigma / 2; dd++) {
+    // word dd of a lane (codes of its elements 2 dd, 2 dd + 1): the lane's words in 16-byte pieces, piece k of all lanes
+    // together (the kernel reads a piece with ONE 16-byte load per lane, 1 KB per wave instruction); sigma / 2 not a multiple
+    // of 4 (sigma = 12): the last two words as an 8-byte piece
+    uint32_t *out = col16 + (size_t)t * (g.tile_elems / 2);
+    const int W = g.sigma / 2, G4 = W / 4;
+    for (int dd = 0; dd < W; dd++) {
         const uint32_t a = (uint32_t)(c[(2 * dd) * OMEGA] - lo), b = (uint32_t)(c[(2 * dd + 1) * OMEGA] - lo);
-        out[dd * OMEGA] = (a & 0xFFFFu) | (b << 16);
+        const int at = dd < 4 * G4 ? (dd >> 2) * 4 * OMEGA + lane * 4 + (dd & 3) : G4 * 4 * OMEGA + lane * 2 + (dd - 4 * G4);
+        out[at] = (a & 0xFFFFu) | (b << 16);
     }
 }
 

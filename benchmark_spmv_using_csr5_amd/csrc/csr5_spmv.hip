@@ -128,18 +128,29 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     constexpr int NREG = SIGMA > 0 ? SIGMA : 1;
     int32_t c[NREG];
     VT v[NREG];
+    uint32_t cw16[C16 ? NREG / 2 : 1]; // narrow column codes, two per word
+    int32_t base_c16 = 0;
     if constexpr (SIGMA > 0) {
         if constexpr (NT) {
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
                 c[i] = __builtin_nontemporal_load(ct + i * OMEGA);
         } else if constexpr (C16) {
-            // narrow column codes (k_col16): two per word, half the column stream; the tile's base rides in the same batch
-            const uint32_t *cw = col16 + (size_t)t * (T / 2) + lane;
+            // narrow column codes (k_col16): two per word, half the column stream, in 16-byte pieces per lane (col16_word_offset:
+            // sigma / 8 loads per tile instead of sigma / 2 -- the address unit is busy 76 % of this kernel's launch and handles
+            // one wave instruction per ~16 clocks whatever its width); the tile's base rides in the same batch
+            const uint32_t *ctile = col16 + (size_t)t * (T / 2);
+            constexpr int W = SIGMA / 2, G4 = W / 4;
 #pragma unroll
-            for (int dd = 0; dd < SIGMA / 2; dd++)
-                c[2 * dd] = (int32_t)cw[dd * OMEGA];
-            c[1] = base16[t + vz];
+            for (int k = 0; k < G4; k++) {
+                const uint4 q = reinterpret_cast<const uint4 *>(ctile)[k * OMEGA + lane];
+                cw16[4 * k] = q.x, cw16[4 * k + 1] = q.y, cw16[4 * k + 2] = q.z, cw16[4 * k + 3] = q.w;
+            }
+            if constexpr (W % 4 != 0) {
+                const uint2 q = reinterpret_cast<const uint2 *>(ctile + G4 * 4 * OMEGA)[lane];
+                cw16[4 * G4] = q.x, cw16[4 * G4 + 1] = q.y;
+            }
+            base_c16 = base16[t + vz];
         } else {
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
@@ -187,12 +198,11 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             asm volatile("" : "+v"(spill_c), "+v"(spill_v));
         }
         if constexpr (C16) {
-            const int32_t base = __builtin_amdgcn_readfirstlane(c[1]);
+            const int32_t base = __builtin_amdgcn_readfirstlane(base_c16);
 #pragma unroll
-            for (int dd = SIGMA / 2 - 1; dd >= 0; dd--) { // (downwards: c[1] holds the base until pair 0 is decoded)
-                const uint32_t w = (uint32_t)c[2 * dd];
-                c[2 * dd] = base + (int32_t)(w & 0xFFFFu);
-                c[2 * dd + 1] = base + (int32_t)(w >> 16);
+            for (int dd = 0; dd < SIGMA / 2; dd++) {
+                c[2 * dd] = base + (int32_t)(cw16[dd] & 0xFFFFu);
+                c[2 * dd + 1] = base + (int32_t)(cw16[dd] >> 16);
             }
         }
         VT xv[NREG];
@@ -205,12 +215,26 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             // issued FIRST, so they overlap the window fetch.
             VT *win = reinterpret_cast<VT *>(wave_lds);
             const int wlo = (int)__builtin_amdgcn_readfirstlane(mt.w) - 1;
+            const bool x_vec16 = (reinterpret_cast<uintptr_t>(x) & 15u) == 0; // (a caller's x need only be element-aligned)
             if (wlo >= 0) {
-                // stage the window: 16 coalesced wave loads -> 16 LDS stores (private to this wave)
+                // stage the window (private to this wave): four 16-byte loads and LDS stores per lane when x allows it (window
+                // bases are multiples of 4 columns, k_tile_tables), else 16 coalesced element loads
+                if (x_vec16 && wlo + XWIN_ELEMS <= g.n) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(x + wlo);
+                    uint4 *dst = reinterpret_cast<uint4 *>(win);
+                    uint4 q[XWIN_BYTES / 16 / OMEGA];
 #pragma unroll
-                for (int k = 0; k < XWIN_ELEMS / OMEGA; k++) {
-                    const int j = wlo + k * OMEGA + lane;
-                    win[k * OMEGA + lane] = x[j < g.n ? j : g.n - 1];
+                    for (int k = 0; k < XWIN_BYTES / 16 / OMEGA; k++)
+                        q[k] = src[k * OMEGA + lane];
+#pragma unroll
+                    for (int k = 0; k < XWIN_BYTES / 16 / OMEGA; k++)
+                        dst[k * OMEGA + lane] = q[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < XWIN_ELEMS / OMEGA; k++) {
+                        const int j = wlo + k * OMEGA + lane;
+                        win[k * OMEGA + lane] = x[j < g.n ? j : g.n - 1];
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--sigma", default="-1")
     ap.add_argument("--slabs", default="auto")
     ap.add_argument("--no-cold", action="store_true")
+    ap.add_argument("--modes", default="off,force,auto")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     for w in args.workloads:
@@ -34,7 +35,7 @@ def main():
                "scircuit": lambda: M.scircuit_like(dtype=npd), "webbase": lambda: M.webbase_like(dtype=npd),
                "rmat20": lambda: M.rmat(20, 16, seed=4, dtype=npd), "rmat22": lambda: M.rmat(22, 16, seed=4, dtype=npd)}[w]()
         ys = {}
-        for mode in ("off", "force", "auto"):
+        for mode in args.modes.split(","):
             a = base_args(sigma=args.sigma, slabs=slabs, tile_walk="off", defer_carries=mode)
             warm, cold, desc, b = measure(mat, w, dtype_name, a, dev, cold=not args.no_cold)
             a.values = "real"  # (rounding-sensitive data for the comparison)
@@ -50,8 +51,9 @@ def main():
             fc = b / (cold * 1e-6) / 8e12 if cold else float("nan")
             print(f"{w:9s} defer={mode:5s} ({deferred}) warm {warm:8.2f} us ({fw:.3f})  cold {cold if cold else float('nan'):8.2f} us ({fc:.3f})  {desc}",
                   flush=True)
-        same = torch.equal(ys["off"].view(torch.uint8), ys["force"].view(torch.uint8))
-        print(f"{w:9s} off == force bit for bit: {same}", flush=True)
+        if "off" in ys and "force" in ys:
+            same = torch.equal(ys["off"].view(torch.uint8), ys["force"].view(torch.uint8))
+            print(f"{w:9s} off == force bit for bit: {same}", flush=True)
 
 
 if __name__ == "__main__":

@@ -30,10 +30,13 @@ def _device_csr(mat, val, dtype):
 
 def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None, nt=None,
          slabs=None, slab_shift=None, zero_empty=None, info_out=None, hot=None, x_snapshot=None, narrow=None,
-         walk=None, walk_ranges=None, narrow_cols=None, defer=None):
+         walk=None, walk_ranges=None, narrow_cols=None, defer=None, x_misaligned=False):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
+    if x_misaligned:  # a caller's x need only be element-aligned: one element into a larger allocation
+        xd = torch.cat([torch.zeros(1, dtype=tdt, device=DEV), xd])[1:]
+        assert xd.data_ptr() % 16 != 0
     yd = torch.full((mat.m,), y0, dtype=tdt, device=DEV)
     A = H.anonymouslibHandle(mat.m, mat.n, dtype=np.dtype(dtype).name)
     assert A.inputCSR(mat.nnz, rp, ci, va) == 0
@@ -978,6 +981,9 @@ def test_narrow_column_codes(oracle):
             _, _, _, y32 = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=2, slabs=0, narrow_cols=0, info_out=info)
             assert info["narrow_columns"] == 0
             assert np.array_equal(y16[0], y32[0]) and np.array_equal(y16[0], y16[1]), (mat.name, sigma, "bit-identical")
+            # x one element off a 16-byte boundary: the window is staged element by element instead of in 16-byte pieces
+            _, _, _, yu = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=2, slabs=0, x_misaligned=True)
+            assert np.array_equal(yu[0], y16[0]), (mat.name, sigma, "element-aligned x")
     # auto: the banded stand-in gets windows AND codes without being asked; sigma 6 (no instantiation) and a wide matrix do not
     nd = M.nd24k_like(scale=0.05, dtype=np.float32)
     val, x = M.fill_values(nd.nnz, nd.n, np.float32, seed=63, mode="int")
