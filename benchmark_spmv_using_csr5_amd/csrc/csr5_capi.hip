@@ -352,8 +352,8 @@ static int prepare_col16(csr5hip_handle h);
 // kernel-side tables of the plain (non-slab) path that are built on demand: narrow column codes, walking-kernel ranges
 static int prepare_plain(csr5hip_handle h)
 {
-    const int rc = prepare_col16(h);
-    return rc != CSR5HIP_SUCCESS ? rc : prepare_walk(h);
+    const int rc = prepare_walk(h); // (first: which kernel runs decides whether the narrow column codes are of use)
+    return rc != CSR5HIP_SUCCESS ? rc : prepare_col16(h);
 }
 
 int csr5hip_set_option(csr5hip_handle h, int option, int value)
@@ -484,8 +484,8 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
                 return CSR5HIP_INVALID_ARGUMENT;
             h->walk_ranges_request = value;
         }
-        if (h->format == CSR5HIP_FORMAT_CSR5) {
-            const int rc = prepare_walk(h);
+        if (h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0) {
+            const int rc = prepare_plain(h); // (the walking kernel's tables, then the column codes of whichever kernel runs)
             if (rc != CSR5HIP_SUCCESS)
                 return rc;
         }
@@ -626,7 +626,9 @@ static int prepare_col16(csr5hip_handle h)
     h->d.col16 = nullptr;
     h->d.base16 = nullptr;
     const Geometry &g = h->g;
-    if (h->col16_request == 0 || h->is_child || g.p <= 1 || h->opt.mode != 1 || !h->opt.x_window || !col16_sigma(g.sigma))
+    // (a windowed kernel serves spmv(): the one-tile kernel's 4-KB windows, or the walking kernel with its 16-KB ones)
+    const bool windowed = h->opt.walk ? h->opt.walk_x_window != 0 : h->opt.x_window != 0;
+    if (h->col16_request == 0 || h->is_child || g.p <= 1 || h->opt.mode != 1 || !windowed || !col16_sigma(g.sigma))
         return CSR5HIP_SUCCESS;
     const size_t code_words = (size_t)(g.p - 1) * (g.tile_elems / 2);
     if (!h->col16_built) {
@@ -1819,7 +1821,10 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->x_snapshot = h->x_snapshot;
     info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
     info->carries_deferred = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->carries_deferred ? 1 : 0;
-    info->narrow_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.x_window && h->opt.col16 ? 1 : 0;
+    info->narrow_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.col16 &&
+                                   (h->opt.walk ? h->opt.walk_x_window && h->g.sigma <= WALK_MAX_SIGMA : h->opt.x_window)
+                               ? 1
+                               : 0;
     info->tile_walk = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.walk ? 1 : 0;
     info->walk_ranges = h->format == CSR5HIP_FORMAT_CSR5 ? h->d.walk_ranges : 0;
     info->walk_x_window = info->tile_walk && h->opt.walk_x_window ? 1 : 0;

@@ -173,10 +173,16 @@ struct SpmvOptions {
     int walk_x_window;  // resolved: the walking kernel stages its (larger, rarely restaged) slice of x in LDS
 };
 constexpr int DEFER_AUTO_MIN_TILES = 8192;  // auto: carries are deferred to k_calibrate from this many tiles on (when most tiles hand-shake)
-constexpr int WALK_XWIN_BYTES = 16384;      // the walking kernel's slice of x in LDS per wavefront: 4 096 fp32 / 2 048 fp64 columns
+#ifndef CSR5_WALK_XWIN_BYTES
+#define CSR5_WALK_XWIN_BYTES 16384
+#endif
+#ifndef CSR5_WALK_WAVES_PER_CU
+#define CSR5_WALK_WAVES_PER_CU 8
+#endif
+constexpr int WALK_XWIN_BYTES = CSR5_WALK_XWIN_BYTES;      // the walking kernel's slice of x in LDS per wavefront: 4 096 fp32 / 2 048 fp64 columns
 constexpr int WALK_MAX_SIGMA = 16;          // one descriptor packet per lane, two register sets of sigma elements
 constexpr int WALK_MAX_RANGES = 16384;      // upper bound of CSR5HIP_OPT_WALK_RANGES (k_walk_tables: one workgroup)
-constexpr int WALK_DEFAULT_WAVES_PER_CU = 8; // default number of ranges = 8 per CU (fewer when their LDS does not fit)
+constexpr int WALK_DEFAULT_WAVES_PER_CU = CSR5_WALK_WAVES_PER_CU; // default number of ranges = 8 per CU (fewer when their LDS does not fit)
 constexpr int WALK_AUTO_MIN_TILES_PER_RANGE = 4; // auto: the walking kernel runs when every range gets at least this many tiles
 constexpr int HOT_LDS_BYTES = 128 * 1024;  // upper bound of the LDS table of hot x entries per workgroup (k_spmv_range)
 constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_range

@@ -109,10 +109,19 @@ hipError_t launch_walk_tables(const Geometry &g, const DeviceArrays &d, uint32_t
 #endif
 
 // ---- the kernel -----------------------------------------------------------------------------------------------------------
-template <typename VT, int SIGMA>
+template <typename VT, int SIGMA, bool C16>
 struct WalkTile {
-    int32_t c[SIGMA];
+    // column words: one per element, or (C16, narrow column codes of k_col16) two 16-bit codes per word + the tile's base
+    int32_t c[C16 ? SIGMA / 2 : SIGMA];
+    int32_t cbase; // (wave-uniform, scalar cache)
     VT v[SIGMA];
+    __device__ __forceinline__ int32_t column(int i) const
+    {
+        if constexpr (C16)
+            return cbase + (int32_t)(((uint32_t)c[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+        else
+            return c[i];
+    }
     uint32_t w0;         // descriptor word of this lane: y_offset | scansum_offset | bit flags (one packet: sigma <= 16)
     uint32_t tp0, tp1;   // tile_ptr[t], tile_ptr[t + 1] (wave-uniform, scalar cache)
     int32_t offp, offn;  // offset_pointer[t], [t + 1]
@@ -124,6 +133,8 @@ struct WalkParams {
     void *lead, *acc;     // [nranges + 1] of vT: parked leading partials (the calibrator's role) / closing partials
     uint32_t *cnt;        // [nranges + 1] arrival counters
     const int32_t *xwin;  // [p] window base of every tile, -1 = none
+    const uint32_t *col16; // narrow column codes (C16 kernels), base16 behind them
+    const int32_t *base16;
     int nranges;
 };
 
@@ -133,13 +144,15 @@ constexpr int walk_lds_bytes()
     return OMEGA * SIGMA * (int)sizeof(VT) + (XWIN ? WALK_XWIN_BYTES : 0);
 }
 
-template <typename VT, int SIGMA, bool XWIN, bool NT, int DEPTH>
+template <typename VT, int SIGMA, bool XWIN, bool NT, int DEPTH, bool C16 = false>
 __global__ void __launch_bounds__(OMEGA)
 k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col, const VT *__restrict__ val,
             const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc,
             const int32_t *__restrict__ offset_ptr, const int32_t *__restrict__ offset, VT *__restrict__ y, WalkParams wp)
 {
     static_assert(num_packet_of(SIGMA) == 1, "one descriptor word per lane");
+    static_assert(!C16 || (col16_sigma(SIGMA) && !NT), "narrow column codes: the sigmas k_col16 serves");
+    using Tile = WalkTile<VT, SIGMA, C16>;
     using word_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
     constexpr int T = OMEGA * SIGMA;
     constexpr int BIT_Y = bit_y_of(SIGMA), BIT_ALL = BIT_Y + BIT_SS;
@@ -176,6 +189,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     const auto *tpc = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)tile_ptr;
     const auto *opc = (const __attribute__((address_space(4))) int32_t *)(uintptr_t)offset_ptr;
     const auto *xwc = (const __attribute__((address_space(4))) int32_t *)(uintptr_t)wp.xwin;
+    const auto *b16c = (const __attribute__((address_space(4))) int32_t *)(uintptr_t)wp.base16;
     // the protocol words of this range, requested now and read when the range is done
     const auto *rowc = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)wp.row;
     const auto *metac = (const __attribute__((address_space(4))) uint32_t *)(uintptr_t)wp.meta; // uint4 per range
@@ -187,14 +201,31 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     auto *win = (__attribute__((address_space(3))) char *)(smem + (size_t)T * sizeof(VT)); // WXB bytes of x
     const auto xbuf = __builtin_amdgcn_make_buffer_rsrc(const_cast<VT *>(x), (short)0, g.n * (int)sizeof(VT), 0x00020000);
 
-    auto load = [&](WalkTile<VT, SIGMA> &tr, int t) {
+    auto load = [&](Tile &tr, int t) {
         const size_t base = (size_t)t * T + lane;
         const int32_t *ct = col + base;
         const VT *vt = val + base;
         // column words first: the gathers wait for them only
+        if constexpr (C16) {
+            // sigma / 8 loads of 16 bytes per lane (+ one of 8 for sigma = 12): the layout k_col16 writes
+            const uint32_t *ctile = wp.col16 + (size_t)t * (T / 2);
+            constexpr int W = SIGMA / 2, G4 = W / 4;
 #pragma unroll
-        for (int i = 0; i < SIGMA; i++)
-            tr.c[i] = NT ? __builtin_nontemporal_load(ct + i * OMEGA) : ct[i * OMEGA];
+            for (int k = 0; k < G4; k++) {
+                const uint4 q = reinterpret_cast<const uint4 *>(ctile)[k * OMEGA + lane];
+                tr.c[4 * k] = (int32_t)q.x, tr.c[4 * k + 1] = (int32_t)q.y, tr.c[4 * k + 2] = (int32_t)q.z, tr.c[4 * k + 3] = (int32_t)q.w;
+            }
+            if constexpr (W % 4 != 0) {
+                const uint2 q = reinterpret_cast<const uint2 *>(ctile + G4 * 4 * OMEGA)[lane];
+                tr.c[4 * G4] = (int32_t)q.x, tr.c[4 * G4 + 1] = (int32_t)q.y;
+            }
+            tr.cbase = b16c[t];
+        } else {
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++)
+                tr.c[i] = NT ? __builtin_nontemporal_load(ct + i * OMEGA) : ct[i * OMEGA];
+            tr.cbase = 0;
+        }
         tr.w0 = tile_desc[(size_t)t * OMEGA + lane];
         tr.tp0 = tpc[t];
         tr.tp1 = tpc[t + 1];
@@ -249,7 +280,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     // gathers of tile `tr` (window base wl, -1 = none): in-window lanes will read LDS (compute), the others read x through a
     // range-checked buffer load (in-window lanes carry an out-of-range offset there: "return 0, touch no memory") and a bitwise
     // OR merges the two.  A tile whose columns ALL lie in the window issues no buffer load.  Returns "some lane is outside".
-    auto gather = [&](const WalkTile<VT, SIGMA> &tr, int wl, word_t (&xg)[SIGMA], int32_t (&offv)[SIGMA]) -> bool {
+    auto gather = [&](const Tile &tr, int wl, word_t (&xg)[SIGMA], int32_t (&offv)[SIGMA]) -> bool {
         bool some_out = true;
         if constexpr (XWIN) {
             // byte offsets: (c - wl) * sizeof(vT) < WXB  <=>  the column lies in the staged slice
@@ -257,12 +288,12 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
             bool out = false;
 #pragma unroll
             for (int i = 0; i < SIGMA; i++)
-                out |= (unsigned)tr.c[i] * (unsigned)sizeof(VT) - wbase >= WXB;
+                out |= (unsigned)tr.column(i) * (unsigned)sizeof(VT) - wbase >= WXB;
             some_out = __ballot(out) != 0ull;
             if (some_out) {
 #pragma unroll
                 for (int i = 0; i < SIGMA; i++) {
-                    const unsigned boff = (unsigned)tr.c[i] * (unsigned)sizeof(VT);
+                    const unsigned boff = (unsigned)tr.column(i) * (unsigned)sizeof(VT);
                     const unsigned off = boff - wbase >= WXB ? boff : 0xFFFFFFFFu;
                     if constexpr (sizeof(VT) == 8)
                         xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
@@ -273,7 +304,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
         } else {
 #pragma unroll
             for (int i = 0; i < SIGMA; i++) {
-                const unsigned off = (unsigned)tr.c[i] * (unsigned)sizeof(VT);
+                const unsigned off = (unsigned)tr.column(i) * (unsigned)sizeof(VT);
                 if constexpr (sizeof(VT) == 8)
                     xg[i] = __builtin_bit_cast(word_t, __builtin_amdgcn_raw_buffer_load_b64(xbuf, off, 0, 0));
                 else
@@ -297,7 +328,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     };
 
     // ---- one tile whose loads (streams in `tr`, gathers in `xg`) are in flight or done ----------------------------------------
-    auto compute = [&](const WalkTile<VT, SIGMA> &tr, int wl, bool some_out, const word_t (&xg)[SIGMA],
+    auto compute = [&](const Tile &tr, int wl, bool some_out, const word_t (&xg)[SIGMA],
                        const int32_t (&offv)[SIGMA]) {
         VT mx[SIGMA];
         if constexpr (XWIN) {
@@ -305,7 +336,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
             word_t lw[SIGMA];
 #pragma unroll
             for (int i = 0; i < SIGMA; i++) {
-                const unsigned d = (unsigned)tr.c[i] * (unsigned)sizeof(VT) - wbase;
+                const unsigned d = (unsigned)tr.column(i) * (unsigned)sizeof(VT) - wbase;
                 lw[i] = *(const __attribute__((address_space(3))) word_t *)(win + (int)(d < WXB ? d : ZERO_SLOT)); // outside: +0.0
             }
             if (some_out) { // (wave-uniform)
@@ -463,7 +494,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
     word_t xg[SIGMA];
     int32_t offv[SIGMA];
     int wl_cur = -1;
-    auto step = [&](WalkTile<VT, SIGMA> &cur, WalkTile<VT, SIGMA> &ahead, int tt, auto load_ahead) {
+    auto step = [&](Tile &cur, Tile &ahead, int tt, auto load_ahead) {
         int wl_nx = -1;
         if constexpr (XWIN)
             wl_nx = xwc[tt + 1 < te ? tt + 1 : tt]; // the next tile's window: read when this tile is done
@@ -478,7 +509,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
         wl_cur = wl_nx;
         __builtin_amdgcn_sched_barrier(0);
     };
-    WalkTile<VT, SIGMA> a, b;
+    Tile a, b;
     load(a, tb);
     if constexpr (XWIN) {
         wl_cur = xwc[tb];
@@ -494,7 +525,7 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
         if (t < te)
             step(a, a, t, std::false_type{});
     } else {
-        WalkTile<VT, SIGMA> c;
+        Tile c;
         load(b, tb + 1 < te ? tb + 1 : tb);
         for (; t + 3 <= te; t += 3) {
             step(a, c, t, std::true_type{});
@@ -523,16 +554,16 @@ k_spmv_walk(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__re
 }
 
 // ---- dispatch -------------------------------------------------------------------------------------------------------------
-template <typename VT, int SIGMA, bool XWIN, bool NT>
+template <typename VT, int SIGMA, bool XWIN, bool NT, bool C16 = false>
 static hipError_t launch_walk_one(const Geometry &g, const DeviceArrays &d, const void *x, void *y, const SpmvOptions &opt,
                                   hipStream_t s)
 {
     const int tail_rows_n = g.m - g.tail_start;
     const int tail_blocks = tail_rows_n > 0 ? (tail_rows_n + BLOCK - 1) / BLOCK : 0;
     WalkParams wp{d.walk_row, reinterpret_cast<const uint4 *>(d.walk_meta), d.walk_lead, d.walk_acc, d.walk_cnt, d.xwin_base,
-                  d.walk_ranges};
+                  d.col16, d.base16, d.walk_ranges};
     constexpr size_t lds = (size_t)walk_lds_bytes<VT, SIGMA, XWIN>();
-    hipLaunchKernelGGL((k_spmv_walk<VT, SIGMA, XWIN, NT, CSR5_WALK_DEPTH>), dim3(d.walk_ranges + tail_blocks), dim3(OMEGA), lds, s, g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x,
+    hipLaunchKernelGGL((k_spmv_walk<VT, SIGMA, XWIN, NT, CSR5_WALK_DEPTH, C16>), dim3(d.walk_ranges + tail_blocks), dim3(OMEGA), lds, s, g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x,
                        d.tile_ptr, d.tile_desc, d.offset_ptr, d.offset, (VT *)y, wp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !opt.walk_long_runs)
@@ -549,6 +580,9 @@ static hipError_t launch_walk_sigma(const Geometry &g, const DeviceArrays &d, co
     switch (g.sigma) {
 #define CSR5_WALK_CASE(S)                                                                                                      \
     case S:                                                                                                                    \
+        if constexpr (col16_sigma(S))                                                                                          \
+            if (opt.walk_x_window && opt.col16 && d.col16)                                                                     \
+                return launch_walk_one<VT, S, true, false, true>(g, d, x, y, opt, s);                                          \
         if (opt.walk_x_window)                                                                                                 \
             return opt.stream_nt ? launch_walk_one<VT, S, true, true>(g, d, x, y, opt, s)                                      \
                                  : launch_walk_one<VT, S, true, false>(g, d, x, y, opt, s);                                    \

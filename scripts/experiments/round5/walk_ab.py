@@ -48,9 +48,9 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     for w in args.workloads:
-        dtype_name = "f32" if w == "nd24k" else "f64"
+        dtype_name = "f32" if w in ("nd24k", "nd24kx4") else "f64"
         npd = np.float32 if dtype_name == "f32" else np.float64
-        mat = {"nd24k": lambda: M.nd24k_like(dtype=npd), "scircuit": lambda: M.scircuit_like(dtype=npd),
+        mat = {"nd24k": lambda: M.nd24k_like(dtype=npd), "nd24kx4": lambda: M.nd24k_like(scale=4.0, dtype=npd), "scircuit": lambda: M.scircuit_like(dtype=npd),
                "webbase": lambda: M.webbase_like(dtype=npd),
                "rmat20": lambda: M.rmat(20, 16, seed=4, dtype=npd)}[w]()
         rows = []

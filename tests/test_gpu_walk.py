@@ -42,20 +42,23 @@ def test_walk_zoo_integer_data_bit_exact(oracle, sigma):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_walk_x_window_variant(oracle, dtype):
     """x-window variant (forced; sigma 4, 8, 12, 16) on matrices with and without column locality, non-temporal streams on and
-    off: integer data exact, real data within tolerance and bit-reproducible."""
+    off, with the 16-bit column codes (sigma 8, 12, 16) and without: integer data exact, real data within tolerance and
+    bit-reproducible."""
     tol = 1e-12 if dtype == np.float64 else 1e-5
     mats = zoo.small_zoo() + [M.nd24k_like(scale=0.03, dtype=np.float64)]
     for mat in mats:
         for sigma in (4, 8, 12, 16):
-            for nt, ranges in ((0, 3), (2, 0)):
+            for nt, ranges, narrow_cols in ((0, 3, None), (2, 0, None), (0, 5, 0)):
                 val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=30, mode="int")
                 if dtype == np.float32:  # keep every partial sum below 2^24
                     val, x = (val % 3).astype(np.float32), (x % 3).astype(np.float32)
                 fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
                 info = {}
                 _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=2, nt=nt, walk=2, walk_ranges=ranges,
-                                   slabs=0, info_out=info)
+                                   slabs=0, info_out=info, narrow_cols=narrow_cols)
                 assert info["tile_walk"] == (1 if fmt.p > 1 else 0) and info["walk_x_window"] == info["tile_walk"]
+                # 16-bit column codes (every tile of these matrices spans < 65 536 columns): the sigmas k_col16 serves, unless off
+                assert info["narrow_columns"] == (1 if fmt.p > 1 and sigma in (8, 12, 16) and narrow_cols is None else 0), info
                 exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
                 assert np.array_equal(ys[0], exp), (mat.name, sigma, nt, ranges, np.flatnonzero(ys[0] != exp)[:8])
             val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=31, mode="real")
