@@ -529,6 +529,14 @@ k_calibrate(Geometry g, const uint32_t *__restrict__ tile_ptr, const uint4 *__re
     int len = 0;
     bool has_first = false;
     int r = 0;
+    // deferred carries make this launch part of every SpMV of some matrices: the words a run of <= 2 parked partials needs
+    // (nearly all of them: a row cut once or twice) are requested WITH the meta word instead of after it -- one round trip less
+    VT spec_first = 0, spec0 = 0, spec1 = 0;
+    if (LONG_ONLY && t < g.p) {
+        spec_first = acc[t];
+        spec0 = calibrator[t];
+        spec1 = calibrator[t + 1 < g.p ? t + 1 : t];
+    }
     if (t < g.p) {
         const uint4 mt = meta[t];
         head = (int)mt.y == t;
@@ -546,7 +554,12 @@ k_calibrate(Geometry g, const uint32_t *__restrict__ tile_ptr, const uint4 *__re
     }
     // (LONG_ONLY also serves the runs whose parties were told to park although they are short: deferred carries,
     //  CSR5HIP_OPT_DEFER_CARRIES -- the closing partial waits in acc[head], as for a long run)
-    if (head && len <= RUN_SERIAL_MAX)
+    if (LONG_ONLY && head && len <= 2) {
+        VT total = has_first ? spec_first + spec0 : spec0; // (sum_run's association)
+        if (len == 2)
+            total += spec1;
+        y[r] = total;
+    } else if (head && len <= RUN_SERIAL_MAX)
         y[r] = sum_run<VT, false>(calibrator, t, len, has_first, has_first ? (LONG_ONLY ? acc[t] : y[r]) : (VT)0, lane, lane);
     unsigned long long todo = __ballot(head && len > RUN_SERIAL_MAX);
     while (todo) {
