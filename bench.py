@@ -242,7 +242,8 @@ class Problem:
             _ck(A.setSlabShift(args.slab_shift), "setSlabShift")
         _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
         _ck(A.setTileWalk({"off": 0, "auto": 1, "force": 2}[getattr(args, "tile_walk", "off")]), "setTileWalk")
-        _ck(A.setDeferCarries({"off": 0, "auto": 1, "force": 2}[getattr(args, "defer_carries", "auto")]), "setDeferCarries")
+        if getattr(args, "defer_carries", "auto") != "auto":  # (auto = the library's default)
+            _ck(A.setDeferCarries({"off": 0, "force": 2}[args.defer_carries]), "setDeferCarries")
         _ck(A.setWalkRanges(int(getattr(args, "walk_ranges", 0))), "setWalkRanges")
         rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 0)))
         if rc != 0 and not os.environ.get("CSR5HIP_LIB"):  # (an older library build under A/B test does not know the option)
@@ -344,8 +345,11 @@ def roofline_dict(prob, ev_ms_per_step, wall_ms_per_step, extra=None):
         "clock": "HIP events on the launch stream around the K timed steps (frac_wall: the same from the wall clock)",
         "frac_wall": round(prob.b_alg / (wall_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "traffic": None,
-        "kernel": ("csr5::k_spmv_range + csr5::k_range_finish" if info.slab_hot else "csr5::k_spmv") +
-                  (" + csr5::k_slab_combine (all inside the step time)" if info.column_slabs else ""),
+        "kernel": ((("csr5::k_x_permute + " if info.slab_x_permuted and not info.x_snapshot else "") +
+                    "csr5::k_spmv_range + csr5::k_range_finish") if info.slab_hot else "csr5::k_spmv") +
+                  (" + csr5::k_calibrate (deferred carries)" if info.carries_deferred and not info.column_slabs else "") +
+                  (" + csr5::k_slab_combine" if info.column_slabs else "") +
+                  (" (all inside the step time)" if info.column_slabs or info.carries_deferred else ""),
         "algorithmic_bytes_per_launch": prob.b_alg,
         # diagnostic: what the kernels of one step actually move, by array (computed from the structure's sizes,
         # not measured; `traffic` below is the measured total).  B_alg stays the roofline's numerator.
