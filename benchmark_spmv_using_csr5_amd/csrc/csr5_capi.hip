@@ -119,8 +119,6 @@ struct csr5hip_handle_s {
     int walk_ranges_request = 0; // CSR5HIP_OPT_WALK_RANGES: 0 = default
     // deferred carries (csr5_format.hip k_defer_carries): decided at conversion
     int defer_request = 1;       // CSR5HIP_OPT_DEFER_CARRIES: 0 off, 1 auto (default), 2 force
-    unsigned multi_heads = 0;    // run heads at which >= 2 partials meet
-    bool carries_deferred = false;
     // narrow column codes of the x-window kernel (csr5_format.hip k_col16): built when that kernel is selected
     int col16_request = 1;       // CSR5HIP_OPT_NARROW_COLUMNS: 0 off, 1 auto (default)
     bool col16_built = false;    // the codes of the current conversion exist
@@ -522,6 +520,7 @@ static int derive_geometry(csr5hip_handle h, int sigma)
     g.tile_elems = OMEGA * g.sigma;
     g.p = (int)(((long long)g.nnz + g.tile_elems - 1) / g.tile_elems);
     g.tail_start = g.m;
+    g.defer = 0;
     h->num_offsets = 0;
     h->xwin_tiles = 0;
     h->xwin_covered = 0;
@@ -714,6 +713,20 @@ static int prepare_walk(csr5hip_handle h)
 // what the fused kernel needs on top of the reference's format arrays: carry meta, x windows, tile headers
 static int derive_kernel_tables(csr5hip_handle h)
 {
+    // Deferred carries (CSR5HIP_OPT_DEFER_CARRIES), decided BEFORE the carry meta is written: forced, or (auto) a fused-mode matrix
+    // of many tiles.  There the cut rows cost the one-tile kernel twice: a returning atomic at the end of a tile for every
+    // hand-shake, and -- for the short-spill ownership that avoids most hand-shakes -- two scattered loads and a gather of the
+    // NEXT tile's first 64 elements in every tile (sigma cache lines each: + 2/3 of a sigma = 24 fp32 tile's own lines).  With
+    // the flag set no tile finishes its neighbour's spill, every meeting of partials is parked with plain stores and
+    // k_calibrate (one thread per tile, ~3 us) adds them: nd24k-like fp32 cold 50.5 -> 37.5 us.  Small matrices keep the
+    // in-launch protocol: a second launch costs them more than it saves (rule: csr5_internal.h DEFER_AUTO_*).
+    {
+        const Geometry &g0 = h->g;
+        const bool long_rows = (long long)g0.nnz >= (long long)DEFER_AUTO_LONG_ROW * (g0.m > 0 ? g0.m : 1);
+        const bool pays = long_rows ? g0.p - 1 >= DEFER_AUTO_MIN_TILES_LONG
+                                    : (long long)(g0.p - 1) * g0.sigma >= DEFER_AUTO_MIN_TILE_SIGMA;
+        h->g.defer = !h->is_child && h->opt.mode == 1 && g0.p > 1 && (h->defer_request == 2 || (h->defer_request == 1 && pays)) ? 1 : 0;
+    }
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
     if (!h->host_words) {
@@ -739,17 +752,8 @@ static int derive_kernel_tables(csr5hip_handle h)
     h->xwin_lines = (long long)w[5];
     h->walk_xwin_tiles = (int)w[6];
     h->walk_xwin_covered = (long long)w[7];
-    h->multi_heads = w[20];
-    // deferred carries: forced, or (auto) on a matrix of many tiles most of which take part in a multi-party handshake -- there
-    // the returning atomics at the end of every tile cost more than the second launch that replaces them (k_defer_carries)
-    h->carries_deferred = false;
-    if (!h->is_child && h->opt.mode == 1 && g.p > 1 && h->multi_heads > 0 &&
-        (h->defer_request == 2 ||
-         (h->defer_request == 1 && g.p - 1 >= DEFER_AUTO_MIN_TILES && (long long)h->multi_heads * 2 >= (long long)(g.p - 1)))) {
-        HIP_TRY(launch_defer_carries(g, h->d, s)); // (stream-ordered in front of every SpMV)
-        h->carries_deferred = true;
-        h->opt.long_runs = 1;
-    }
+    if (g.defer)
+        h->opt.long_runs = 1; // (the parties of every cut row park: k_calibrate is part of each SpMV)
     // phase times from the kernels' wall-clock stamps (k_row_scan, k_tile_desc, k_transpose, k_tile_tables); a phase
     // whose kernel did not run (single-tile matrices) has no stamp and takes the next one's
     unsigned long long st[4];
@@ -1820,7 +1824,7 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_cold_entries = info->slab_x_permuted ? h->cold_total : 0;
     info->x_snapshot = h->x_snapshot;
     info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
-    info->carries_deferred = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->carries_deferred ? 1 : 0;
+    info->carries_deferred = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->g.defer ? 1 : 0;
     info->narrow_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.col16 &&
                                    (h->opt.walk ? h->opt.walk_x_window && h->g.sigma <= WALK_MAX_SIGMA : h->opt.x_window)
                                ? 1

@@ -376,7 +376,7 @@ __device__ uint4 tile_carry_meta(const Geometry &g, const int32_t *__restrict__ 
     const bool head = head_idx == t;
     uint4 meta = make_uint4(0u, (unsigned)head_idx, 0u, 0u);
     int len = 0;
-    if (short_spill(t, &len)) {
+    if (!g.defer && short_spill(t, &len)) {
         meta.x |= 1u << 28;
     } else if (head && r < g.m) {
         lo = t + 1, hi = t + 1; // first tile after t whose row is larger (p if none), galloping forward
@@ -403,6 +403,8 @@ __device__ uint4 tile_carry_meta(const Geometry &g, const int32_t *__restrict__ 
             expected += 1; // row r starts inside tile t-1, whose closing segment also arrives
             meta.x |= 1u << 27;
         }
+        if (g.defer && expected >= 2u)
+            meta.x |= 1u << 26; // deferred carries: every meeting of partials is finished by k_calibrate
         meta.x |= expected;
     }
     if (t + 1 < g.p) {
@@ -410,7 +412,7 @@ __device__ uint4 tile_carry_meta(const Geometry &g, const int32_t *__restrict__ 
         // the closing segment of tile t belongs to row rn iff rn starts before (t+1)*T
         if (rn != r && (long long)row_ptr[rn] != (long long)(t + 1) * T) {
             meta.x |= 1u << 30;
-            if (short_spill(t + 1, &len)) {
+            if (!g.defer && short_spill(t + 1, &len)) {
                 meta.x |= 1u << 29;
                 meta.z = (unsigned)len;
             }
@@ -553,9 +555,6 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
             walk_lo = pick_window(WALK_XWIN_ELEMS, WALK_XWIN_ELEMS / 8, &walk_inside);
     }
     if (lane == 0) {
-        // bit 31 of the statistics word: >= 2 partials meet at this run head (not a short-spill head, whose row the previous tile owns)
-        if ((int)meta.y == t && !((meta.x >> 28) & 1u) && (meta.x & 0x00FFFFFFu) >= 2u)
-            stats |= 0x80000000u;
         meta.w = window;
         if (xwin_base) { // dense arrays for the range-walking kernel: one scalar load per tile
             xwin_base[t] = walk_lo;
@@ -581,17 +580,15 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
                                                        uint32_t *__restrict__ host_words, int export_only,
                                                        const int32_t *__restrict__ xwin_cover)
 {
-    __shared__ unsigned part[16][6];
-    unsigned on = 0, in = 0, lines = 0, won = 0, win = 0, multi = 0; // (won / win: tiles with / non-zeros inside a walking-kernel
-                                                                      // window; multi: run heads at which >= 2 partials meet)
+    __shared__ unsigned part[16][5];
+    unsigned on = 0, in = 0, lines = 0, won = 0, win = 0; // (won / win: tiles with / non-zeros inside a walking-kernel window)
     if (export_only)
         stamp_phase(counters, 3); // (k_tile_tables, which stamps this phase, did not run)
     for (int t = blockIdx.x * 1024 + threadIdx.x; t < (export_only ? 0 : g.p - 1); t += gridDim.x * 1024) {
         const unsigned v = hdr[8 * (size_t)t + 7];
-        on += (v & 0x7FFFFFFFu) != 0;
+        on += v != 0;
         in += v & 0xFFFFu;
-        lines += (v >> 16) & 0x7FFFu;
-        multi += v >> 31;
+        lines += v >> 16;
         if (xwin_cover) {
             const unsigned w = (unsigned)xwin_cover[t];
             won += w != 0;
@@ -603,9 +600,7 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
     lines = (unsigned)wave_sum_i32((int)lines);
     won = (unsigned)wave_sum_i32((int)won);
     win = (unsigned)wave_sum_i32((int)win);
-    multi = (unsigned)wave_sum_i32((int)multi);
     if ((threadIdx.x & (OMEGA - 1)) == 0) {
-        part[threadIdx.x >> 6][5] = multi;
         part[threadIdx.x >> 6][0] = on;
         part[threadIdx.x >> 6][1] = in;
         part[threadIdx.x >> 6][2] = lines;
@@ -615,9 +610,9 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
     __syncthreads();
     if (threadIdx.x != 0)
         return;
-    on = in = lines = won = win = multi = 0;
+    on = in = lines = won = win = 0;
     for (int w = 0; w < 16; w++)
-        on += part[w][0], in += part[w][1], lines += part[w][2], won += part[w][3], win += part[w][4], multi += part[w][5];
+        on += part[w][0], in += part[w][1], lines += part[w][2], won += part[w][3], win += part[w][4];
     if (gridDim.x > 1) { // (one workgroup up to 16 k tiles: no atomics, no fence)
         if (on | in) {
             atomicAdd(counters + 0, on);
@@ -628,8 +623,6 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
             atomicAdd(counters + 6, won);
             atomicAdd(counters + 7, win);
         }
-        if (multi)
-            atomicAdd(counters + 16, multi);
         __threadfence();
         if (atomicAdd(counters + 4, 1u) + 1u != gridDim.x)
             return; // not the last workgroup
@@ -639,7 +632,6 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
         lines = __hip_atomic_load(counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         won = __hip_atomic_load(counters + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         win = __hip_atomic_load(counters + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        multi = __hip_atomic_load(counters + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!host_words)
         return;
@@ -649,7 +641,6 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
     out[1] = make_uint4(counters[2], lines, won, win);
     out[2] = stamps[0]; // phase stamps 0, 1 (64-bit each)
     out[3] = stamps[1]; // phase stamps 2, 3
-    out[5] = make_uint4(multi, 0u, 0u, 0u); // host word 20 (word 16 belongs to k_walk_tables)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -696,37 +687,6 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_col16(Geometry g, const int32_t *
         const int at = dd < 4 * G4 ? (dd >> 2) * 4 * OMEGA + lane * 4 + (dd & 3) : G4 * 4 * OMEGA + lane * 2 + (dd - 4 * G4);
         out[at] = (a & 0xFFFFu) | (b << 16);
     }
-}
-
-// Deferred carries (CSR5HIP_OPT_DEFER_CARRIES).  The arrival protocol of the fused kernel costs every party of a cut row one
-// RETURNING device-scope atomic at the very end of its tile -- a memory-side round trip the wavefront cannot retire before.  On a
-// matrix of many tiles whose rows are mostly cut by tile boundaries (nd24k-like: 399 non-zeros per row, 84 % of the tiles take
-// part in a 2-party handshake) that is 11-13 % of the kernel (timing probe without the atomics: 40.7 -> 35.5 us warm, 50 -> 44.5
-// cold), more than a second launch.  This kernel marks every run head at which >= 2 partials meet as a LONG run (bit 26, in
-// carry_meta and in both header copies): the parties then park their partials with plain stores and k_calibrate<LONG_ONLY> -- the
-// launch long runs already use -- adds them in tile order.  Same association as the in-kernel finisher: bit-identical results.
-__global__ void __launch_bounds__(256) k_defer_carries(Geometry g, uint4 *__restrict__ carry_meta, uint32_t *__restrict__ hdr)
-{
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= g.p)
-        return;
-    const uint4 mt = carry_meta[t];
-    if ((int)mt.y != t || ((mt.x >> 28) & 1u) || (mt.x & 0x00FFFFFFu) < 2u)
-        return;
-    const uint32_t x = mt.x | (1u << 26);
-    carry_meta[t].x = x;
-    hdr[8 * (size_t)t] = x;
-    if (t > 0)
-        hdr[8 * (size_t)(t - 1) + 4] = x; // the copy the closing party of tile t-1 reads
-}
-
-hipError_t launch_defer_carries(const Geometry &g, const DeviceArrays &d, hipStream_t s)
-{
-    if (g.p <= 1)
-        return hipSuccess;
-    hipLaunchKernelGGL(k_defer_carries, dim3((g.p + 255) / 256), dim3(256), 0, s, g, reinterpret_cast<uint4 *>(d.carry_meta),
-                       d.tile_hdr);
-    return hipGetLastError();
 }
 
 hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col16, int32_t *base16, uint32_t *wide_tiles,

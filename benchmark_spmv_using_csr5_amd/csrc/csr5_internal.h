@@ -23,7 +23,7 @@ constexpr int FMT_BLOCK = OMEGA * FMT_WAVES_PER_BLOCK;
 constexpr int BIT_SS = 6;                     // bits of scansum_offset at omega = 64
 constexpr uint32_t ROW_MASK = 0x7FFFFFFFu;    // tile_ptr bit 31 = "tile has empty rows"
 constexpr int STAMP_WORD = 8;                 // counters[8..15]: wall-clock stamps of the conversion phases
-constexpr int COUNTER_WORDS = 24;            // [16] = run heads at which >= 2 partials meet (summed by k_stats_export)
+constexpr int COUNTER_WORDS = 16;
 constexpr int NUM_XCD = 8;
 constexpr int RUN_SERIAL_MAX = 64;            // carry runs up to this many tiles resolve in-kernel; longer ones in k_calibrate
 #ifndef CSR5_XWIN_BYTES
@@ -51,6 +51,8 @@ struct Geometry {
     int p;            // number of tiles, the last one (p-1) is the CSR tail
     int tile_elems;   // omega * sigma
     int tail_start;   // first row of the tail tile
+    int defer;        // 1 = deferred carries (fused mode, decided at conversion): no tile finishes its neighbour's short spill and
+                      // every run head at which >= 2 partials meet is marked like a long run -- the parties park, k_calibrate adds
 };
 
 // Device arrays of the CSR5 format plus our own launch helpers.
@@ -121,9 +123,6 @@ hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int valu
 hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col16, int32_t *base16, uint32_t *wide_tiles,
                         hipStream_t s);
 constexpr bool col16_sigma(int sigma) { return sigma == 8 || sigma == 12 || sigma == 16 || sigma == 24 || sigma == 32; }
-// deferred carries: every run head at which >= 2 partials meet is marked like a long run (carry_meta bit 26, in the array and in
-// the tile headers), so that its parties park their partials with plain stores and k_calibrate adds them
-hipError_t launch_defer_carries(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 hipError_t launch_warmup(hipStream_t s);
 // flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)
 hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,
@@ -172,7 +171,12 @@ struct SpmvOptions {
     int walk_long_runs; // resolved: some row spans > RUN_SERIAL_MAX ranges (the walking kernel adds k_calibrate)
     int walk_x_window;  // resolved: the walking kernel stages its (larger, rarely restaged) slice of x in LDS
 };
-constexpr int DEFER_AUTO_MIN_TILES = 8192;  // auto: carries are deferred to k_calibrate from this many tiles on (when most tiles hand-shake)
+// deferred carries, auto rule (measured break-evens, scripts/experiments/round5/defer_ab.py): what deferral saves grows with the
+// number of tiles -- per tile the two scattered spill loads (sigma cache lines each) and, where rows are too long for short-spill
+// ownership, the hand-shake atomics -- what it costs is one small launch (2-2.5 us)
+constexpr int DEFER_AUTO_LONG_ROW = 128;          // average non-zeros per row from which most cut rows hand-shake ...
+constexpr int DEFER_AUTO_MIN_TILES_LONG = 3000;   // ... and deferral pays from this many tiles on (nd24k-like: 3 741 tiles -2.4 us)
+constexpr int DEFER_AUTO_MIN_TILE_SIGMA = 250000; // shorter rows: from tiles x sigma >= this (27 per row, sigma 16: ~15 k tiles)
 #ifndef CSR5_WALK_XWIN_BYTES
 #define CSR5_WALK_XWIN_BYTES 16384
 #endif

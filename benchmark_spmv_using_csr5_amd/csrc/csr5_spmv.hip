@@ -123,7 +123,8 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         const size_t nb = (size_t)(t + 1) * T;
         size_t pos = (t + 1 == g.p - 1) ? nb + lane : nb + (size_t)(lane % sigma) * OMEGA + lane / sigma;
         spill_pos = pos < (size_t)g.nnz ? pos : (size_t)g.nnz - 1;
-        spill_c = col[spill_pos];
+        if (!g.defer) // (deferred carries: nobody finishes a neighbour's spill -- see derive_kernel_tables)
+            spill_c = col[spill_pos];
     }
     constexpr int NREG = SIGMA > 0 ? SIGMA : 1;
     int32_t c[NREG];
@@ -161,7 +162,8 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     const uint32_t w0 = d[lane];
     const uint32_t w1 = num_packet > 1 ? d[OMEGA + lane] : 0u;
     if constexpr (FUSED) {
-        spill_v = val[spill_pos];
+        if (!g.defer)
+            spill_v = val[spill_pos];
         if constexpr (SIGMA > 0)
             __builtin_amdgcn_sched_barrier(0); // keep it AHEAD of the value stream (see the pin below)
     }
@@ -258,8 +260,10 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
             // gather x for exactly those lanes; the other lanes re-read x[0] (one cache line), so the
             // gather is unconditional and rides in the same round trip as the tile's own gathers
             const int L = ((mt.x >> 29) & 1u) ? (int)mt.z : 0;
-            const VT sx = gather(lane < L ? spill_c : 0);
-            lead_next = lane < L ? spill_v * sx : (VT)0;
+            if (!g.defer) {
+                const VT sx = gather(lane < L ? spill_c : 0);
+                lead_next = lane < L ? spill_v * sx : (VT)0;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -130,13 +130,14 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       conversion when the x-window kernel is selected (sigma 8, 12, 16, 24 or 32); +2 bytes per non-zero of
                                       device memory.  1 = auto (default), 0 = off.  csr5hip_info.narrow_columns says what happened. */
 
-#define CSR5HIP_OPT_DEFER_CARRIES 16 /* fused mode, plain path.  A row cut by a tile boundary is finished inside the launch by an arrival
-                                      protocol that costs each party one returning device-scope atomic at the end of its tile.  On
-                                      matrices of many tiles whose rows are mostly longer than a tile's reach (banded / blocked, hundreds
-                                      of non-zeros per row) those round trips are 11-13 % of the kernel: there the parties PARK their
-                                      partials with plain stores and a second small launch (k_calibrate, the one rows spanning > 64 tiles
-                                      already use) adds them in tile order -- bit-identical results, spmv() stays one call.
-                                      1 = auto (default: >= 8 192 tiles and at least half of them hand-shake), 0 = off, 2 = force.
+#define CSR5HIP_OPT_DEFER_CARRIES 16 /* fused mode, plain path.  A row cut by a tile boundary is normally finished inside the launch: a tile
+                                      re-reads a short spill (<= 64 elements) of its last row from the next tile and owns the row, other
+                                      cut rows meet in an arrival protocol (one returning atomic per party at the end of its tile).  On
+                                      matrices of many tiles both cost more than they save (the spill loads touch sigma cache lines each
+                                      in EVERY tile): there no tile finishes a neighbour's spill, every party parks its partial with a
+                                      plain store and a second small launch (k_calibrate, the one rows spanning > 64 tiles already use)
+                                      adds them in tile order -- the association of the two-pass mode, bit-identical to it; spmv() stays
+                                      one call.  1 = auto (default: by tiles, sigma and average row length), 0 = off, 2 = force.
                                       Takes effect at asCSR5(): set it while the matrix is in CSR form.
                                       csr5hip_info.carries_deferred says what happened. */
 

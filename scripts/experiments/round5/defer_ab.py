@@ -22,18 +22,27 @@ def main():
     for w in args.workloads:
         dtype_name = "f32" if w in ("nd24k", "nd24kx4") else "f64"
         npd = np.float32 if dtype_name == "f32" else np.float64
-        slabs = "0" if w.endswith("p") else args.slabs
 
         def fem(rows, per_row):
             rng = np.random.default_rng(5)
             return M.csr_from_row_lengths(np.full(rows, per_row), rows, rng, band=0.9, dtype=npd)
 
+        slabs = "0" if w.endswith("p") else args.slabs
+
+        if ":" in w:  # "nd24k:0.25", "nd24k64:0.25", "fem81:100000" -- the stand-in at another size
+            name, arg = w.split(":")
+            dtype_name = "f32" if name == "nd24k" else "f64"
+            npd = np.float32 if dtype_name == "f32" else np.float64
+            sized = {"nd24k": lambda: M.nd24k_like(scale=float(arg), dtype=npd), "nd24k64": lambda: M.nd24k_like(scale=float(arg), dtype=npd),
+                     "fem27": lambda: fem(int(arg), 27), "fem81": lambda: fem(int(arg), 81), "fem200": lambda: fem(int(arg), 200),
+                     "scircuit": lambda: M.scircuit_like(scale=float(arg), dtype=npd)}
         mat = {"nd24k": lambda: M.nd24k_like(dtype=npd), "nd24k64": lambda: M.nd24k_like(dtype=npd),
                "nd24kx4": lambda: M.nd24k_like(scale=4.0, dtype=npd), "fem27": lambda: fem(2_000_000, 27),
                "fem81": lambda: fem(1_000_000, 81), "fem200": lambda: fem(300_000, 200),
                "rmat22p": lambda: M.rmat(22, 16, seed=4, dtype=npd), "rmat20p": lambda: M.rmat(20, 16, seed=4, dtype=npd),
                "scircuit": lambda: M.scircuit_like(dtype=npd), "webbase": lambda: M.webbase_like(dtype=npd),
-               "rmat20": lambda: M.rmat(20, 16, seed=4, dtype=npd), "rmat22": lambda: M.rmat(22, 16, seed=4, dtype=npd)}[w]()
+               "rmat20": lambda: M.rmat(20, 16, seed=4, dtype=npd), "rmat22": lambda: M.rmat(22, 16, seed=4, dtype=npd)}
+        mat = (sized[w.split(":")[0]] if ":" in w else mat[w])()
         ys = {}
         for mode in args.modes.split(","):
             a = base_args(sigma=args.sigma, slabs=slabs, tile_walk="off", defer_carries=mode)
