@@ -129,8 +129,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     constexpr int NREG = SIGMA > 0 ? SIGMA : 1;
     int32_t c[NREG];
     VT v[NREG];
-    uint32_t cw16[C16 ? NREG / 2 : 1]; // narrow column codes, two per word
-    int32_t base_c16 = 0;
+    int32_t base_c16 = 0; // (narrow column codes: word d of the lane waits in c[d] until it is decoded in place)
     if constexpr (SIGMA > 0) {
         if constexpr (NT) {
 #pragma unroll
@@ -145,11 +144,11 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
 #pragma unroll
             for (int k = 0; k < G4; k++) {
                 const uint4 q = reinterpret_cast<const uint4 *>(ctile)[k * OMEGA + lane];
-                cw16[4 * k] = q.x, cw16[4 * k + 1] = q.y, cw16[4 * k + 2] = q.z, cw16[4 * k + 3] = q.w;
+                c[4 * k] = (int32_t)q.x, c[4 * k + 1] = (int32_t)q.y, c[4 * k + 2] = (int32_t)q.z, c[4 * k + 3] = (int32_t)q.w;
             }
             if constexpr (W % 4 != 0) {
                 const uint2 q = reinterpret_cast<const uint2 *>(ctile + G4 * 4 * OMEGA)[lane];
-                cw16[4 * G4] = q.x, cw16[4 * G4 + 1] = q.y;
+                c[4 * G4] = (int32_t)q.x, c[4 * G4 + 1] = (int32_t)q.y;
             }
             base_c16 = base16[t + vz];
         } else {
@@ -202,9 +201,10 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         if constexpr (C16) {
             const int32_t base = __builtin_amdgcn_readfirstlane(base_c16);
 #pragma unroll
-            for (int dd = 0; dd < SIGMA / 2; dd++) {
-                c[2 * dd] = base + (int32_t)(cw16[dd] & 0xFFFFu);
-                c[2 * dd + 1] = base + (int32_t)(cw16[dd] >> 16);
+            for (int dd = SIGMA / 2 - 1; dd >= 0; dd--) { // (downwards: word dd sits in c[dd], below the slots it decodes into)
+                const uint32_t w = (uint32_t)c[dd];
+                c[2 * dd + 1] = base + (int32_t)(w >> 16);
+                c[2 * dd] = base + (int32_t)(w & 0xFFFFu);
             }
         }
         VT xv[NREG];
