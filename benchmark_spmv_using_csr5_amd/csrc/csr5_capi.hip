@@ -117,7 +117,7 @@ struct csr5hip_handle_s {
     uint32_t *host_words = nullptr;    // 32 pinned, device-visible words the last conversion kernels export into
     int walk_request = 0;        // CSR5HIP_OPT_TILE_WALK: 0 off (default), 1 auto, 2 force
     int walk_ranges_request = 0; // CSR5HIP_OPT_WALK_RANGES: 0 = default
-    // deferred carries (csr5_format.hip k_defer_carries): decided at conversion
+    // deferred carries (Geometry.defer; classification in csr5_format.hip tile_carry_meta): decided at conversion
     int defer_request = 1;       // CSR5HIP_OPT_DEFER_CARRIES: 0 off, 1 auto (default), 2 force
     // narrow column codes of the x-window kernel (csr5_format.hip k_col16): built when that kernel is selected
     int col16_request = 1;       // CSR5HIP_OPT_NARROW_COLUMNS: 0 off, 1 auto (default)

@@ -157,8 +157,8 @@ class anonymouslibHandle:
         return self.setOption(_capi.OPT_NARROW_VALUES, int(value))
 
     def setDeferCarries(self, value: int) -> int:
-        """cut rows finished by a second small launch instead of in-kernel arrival atomics: 0 = off, 1 = auto (default), 2 = force;
-        set before asCSR5 (csr5hip.h CSR5HIP_OPT_DEFER_CARRIES)"""
+        """cut rows finished by a second small launch instead of inside the SpMV launch (no short-spill re-reads, no arrival
+        atomics): 0 = off, 1 = auto (default), 2 = force; set before asCSR5 (csr5hip.h CSR5HIP_OPT_DEFER_CARRIES)"""
         return self.setOption(_capi.OPT_DEFER_CARRIES, int(value))
 
     def setNarrowColumns(self, value: int) -> int:
