@@ -318,12 +318,12 @@ int csr5hip_set_x(csr5hip_handle h, const void *d_x)
 // columns are local; fp32 rows are half as wide, so a tile of the same byte size holds twice the elements: short rows
 // (k <= 8) with local columns ran 5-8 % faster at sigma = 8 than at 6, at no cost with random columns.  Beyond 256
 // non-zeros per row sigma = 32 would gain 3-7 % on random columns but loses 10 % on the nd24k-like stand-in (x-window +
-// jitter): u = 16 for fp64.  fp32, round 5 (x-window kernel with narrow column codes, same-call pairs on nd24k-like: sigma 16 /
-// 20 / 24 / 32 = 52.4-53.0 / 53.7 / 51.1-51.6 / 52.4 us cold, 39.4-40.1 / 40.4 / 39.4-39.8 / 42.8 warm): u = 24 -- a 6-KB tile
-// like fp64's sigma = 16 ... 8.
+// jitter): u = 16 for fp64.  fp32: 24 won by 3 % for a while in round 5 (a 6-KB tile like fp64's sigma = 16); since the narrow
+// codes carry the row-start flags the sigma = 24 kernel needs 136 VGPRs (3 wavefronts per SIMD) and sigma = 16 (78 VGPRs, 6 per
+// SIMD) wins: nd24k-like 29.1 / 37.0 us warm / cold against 31.7 / 38.9: u = 16 again.
 int csr5hip_auto_sigma(int m, int nnz, int value_type)
 {
-    const int r = value_type == CSR5HIP_F32 ? 8 : 6, s = 16, t = 256, u = value_type == CSR5HIP_F32 ? 24 : 16;
+    const int r = value_type == CSR5HIP_F32 ? 8 : 6, s = 16, t = 256, u = 16;
     const int k = m > 0 ? nnz / m : 0;
     if (k <= r) return r;
     if (k <= s) return k;

@@ -645,14 +645,16 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
 
 // ---------------------------------------------------------------------------------------------
 // Narrow column codes (ours; a kernel-side table like the x-window, the format arrays are untouched).  A tile of a banded /
-// blocked matrix spans far fewer than 2^16 columns: column - (smallest column of the tile) fits 16 bits, and the x-window
-// kernel then streams 2 bytes per non-zero instead of 4 (fp32: 6 instead of 8 bytes per non-zero in all).  One wavefront per
+// blocked matrix spans far fewer than 2^15 columns: column - (smallest column of the tile) fits 15 bits, the 16th carries the
+// element's row-start flag, and the x-window kernel then streams 2 bytes per non-zero instead of 4 and no descriptor words
+// (fp32: 6 instead of 8.25 bytes per non-zero in all).  One wavefront per
 // tile t < p-1: minimum and maximum of the tile's column words, the codes of a lane's elements (2 dd, 2 dd + 1) in its word dd
 // (element i of lane l = position i * 64 + l of the tile-ordered column_index, so a code pairs with the value there whether or
 // not the tile was transposed), a lane's words in 16-byte pieces, base16[t]; a tile that spans 65 536 columns or more counts
 // into *wide_tiles -- the codes are used only when that stays 0.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(FMT_BLOCK) k_col16(Geometry g, const int32_t *__restrict__ col, uint32_t *__restrict__ col16,
+__global__ void __launch_bounds__(FMT_BLOCK) k_col16(Geometry g, const int32_t *__restrict__ col,
+                                                 const uint32_t *__restrict__ tile_desc, uint32_t *__restrict__ col16,
                                                  int32_t *__restrict__ base16, uint32_t *__restrict__ wide_tiles)
 {
     const int lane = threadIdx.x & (OMEGA - 1);
@@ -674,18 +676,25 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_col16(Geometry g, const int32_t *
     }
     if (lane == 0) {
         base16[t] = lo;
-        if (hi - lo >= 65536)
+        if (hi - lo >= COL16_SPAN)
             atomicAdd(wide_tiles, 1u);
     }
     // word dd of a lane (codes of its elements 2 dd, 2 dd + 1): the lane's words in 16-byte pieces, piece k of all lanes
     // together (the kernel reads a piece with ONE 16-byte load per lane, 1 KB per wave instruction); sigma / 2 not a multiple
     // of 4 (sigma = 12): the last two words as an 8-byte piece
+    // bit 15 of a code = the element starts a row: the lane's bit flags of the reference's descriptor (format_cuda.h:129-360,
+    // element i -> bit 31 - i once the y_offset / scansum fields are shifted out), so that the kernel reads no descriptor word
+    const uint32_t *dw = tile_desc + (size_t)t * OMEGA * g.num_packet + lane;
+    uint32_t flags = dw[0] << g.bit_all;
+    if (g.num_packet > 1)
+        flags |= dw[OMEGA] >> (32 - g.bit_all);
     uint32_t *out = col16 + (size_t)t * (g.tile_elems / 2);
     const int W = g.sigma / 2, G4 = W / 4;
     for (int dd = 0; dd < W; dd++) {
         const uint32_t a = (uint32_t)(c[(2 * dd) * OMEGA] - lo), b = (uint32_t)(c[(2 * dd + 1) * OMEGA] - lo);
+        const uint32_t fa = (flags >> (31 - 2 * dd)) & 1u, fb = (flags >> (30 - 2 * dd)) & 1u;
         const int at = dd < 4 * G4 ? (dd >> 2) * 4 * OMEGA + lane * 4 + (dd & 3) : G4 * 4 * OMEGA + lane * 2 + (dd - 4 * G4);
-        out[at] = (a & 0xFFFFu) | (b << 16);
+        out[at] = (a & 0x7FFFu) | (fa << 15) | ((b & 0x7FFFu) << 16) | (fb << 31);
     }
 }
 
@@ -694,7 +703,7 @@ hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col1
 {
     if (g.p <= 1)
         return hipSuccess;
-    hipLaunchKernelGGL(k_col16, dim3((g.p - 1 + FMT_WAVES_PER_BLOCK - 1) / FMT_WAVES_PER_BLOCK), dim3(FMT_BLOCK), 0, s, g, d.col, col16, base16,
+    hipLaunchKernelGGL(k_col16, dim3((g.p - 1 + FMT_WAVES_PER_BLOCK - 1) / FMT_WAVES_PER_BLOCK), dim3(FMT_BLOCK), 0, s, g, d.col, d.tile_desc, col16, base16,
                        wide_tiles);
     return hipGetLastError();
 }

@@ -122,6 +122,7 @@ hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int valu
 // narrow column codes: codes + per-tile base from the tile-ordered column_index; *wide_tiles += tiles that span >= 65 536 columns
 hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col16, int32_t *base16, uint32_t *wide_tiles,
                         hipStream_t s);
+constexpr int COL16_SPAN = 32768; // columns a tile may span for the narrow codes: 15 bits of column, bit 15 = row-start flag
 constexpr bool col16_sigma(int sigma) { return sigma == 8 || sigma == 12 || sigma == 16 || sigma == 24 || sigma == 32; }
 hipError_t launch_warmup(hipStream_t s);
 // flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)

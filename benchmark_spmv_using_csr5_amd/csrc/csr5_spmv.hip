@@ -158,8 +158,13 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    const uint32_t w0 = d[lane];
-    const uint32_t w1 = num_packet > 1 ? d[OMEGA + lane] : 0u;
+    // (narrow column codes carry the bit flags themselves and y_offset is recomputed from them: no descriptor load)
+    uint32_t w0 = 0, w1 = 0;
+    if constexpr (!C16) {
+        w0 = d[lane];
+        w1 = num_packet > 1 ? d[OMEGA + lane] : 0u;
+    }
+    uint32_t flags16 = 0;
     if constexpr (FUSED) {
         if (!g.defer)
             spill_v = val[spill_pos];
@@ -201,10 +206,13 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
         if constexpr (C16) {
             const int32_t base = __builtin_amdgcn_readfirstlane(base_c16);
 #pragma unroll
+            for (int dd = 0; dd < SIGMA / 2; dd++) // the row-start flags (bits 15 and 31 of a word) first, into one register
+                flags16 |= (((uint32_t)c[dd] >> 15) & 1u) << (31 - 2 * dd) | ((uint32_t)c[dd] >> 31) << (30 - 2 * dd);
+#pragma unroll
             for (int dd = SIGMA / 2 - 1; dd >= 0; dd--) { // (downwards: word dd sits in c[dd], below the slots it decodes into)
                 const uint32_t w = (uint32_t)c[dd];
-                c[2 * dd + 1] = base + (int32_t)(w >> 16);
-                c[2 * dd] = base + (int32_t)(w & 0xFFFFu);
+                c[2 * dd + 1] = base + (int32_t)((w >> 16) & 0x7FFFu);
+                c[2 * dd] = base + (int32_t)(w & 0x7FFFu);
             }
         }
         VT xv[NREG];
@@ -302,9 +310,21 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     uint32_t flags = w0 << bit_all; // element i -> bit 31-i
     if (num_packet > 1)
         flags |= w1 >> (32 - bit_all);
+    if constexpr (C16)
+        flags = flags16;
     int y_off = (int)(w0 >> (32 - bit_y));
     const bool f0 = (flags >> 31) | (lane == 0);
     const bool present = f0 | ((flags & 0x7FFFFFFFu) != 0);
+    if constexpr (C16) {
+        // y_offset of the reference's descriptor (format_cuda.h:161-267) from the flags: segments that start in the lane,
+        // exclusive wave prefix, minus one for lanes > 0 (as k_spmv_range does; equal to the stored field on every lane that
+        // owns a flag)
+        const int stop = __builtin_popcount(flags & 0x7FFFFFFFu);
+        int segn = stop - (f0 ? 0 : 1) + (present ? 1 : 0);
+        segn = segn > 0 ? segn : 0;
+        const int incl = wave_scan_incl(segn);
+        y_off = lane ? incl - segn - 1 : 0;
+    }
     const unsigned long long pmask = __ballot(present);
     VT spill = 0;
     if constexpr (FUSED) {

@@ -118,7 +118,7 @@ struct WalkTile {
     __device__ __forceinline__ int32_t column(int i) const
     {
         if constexpr (C16)
-            return cbase + (int32_t)(((uint32_t)c[i >> 1] >> (16 * (i & 1))) & 0xFFFFu);
+            return cbase + (int32_t)(((uint32_t)c[i >> 1] >> (16 * (i & 1))) & 0x7FFFu); // (bit 15: row-start flag, unused here)
         else
             return c[i];
     }

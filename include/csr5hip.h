@@ -123,12 +123,13 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
 #define CSR5HIP_OPT_WALK_RANGES 14 /* number of tile ranges (= wavefronts) of the walking kernel: 0 = default (2 048 = 8 per CU),
                                       else 1 .. 16 384; never more than p - 1 */
 
-#define CSR5HIP_OPT_NARROW_COLUMNS 15 /* x-window kernel: when EVERY tile 0 .. p-2 spans fewer than 65 536 columns (banded / blocked
-                                      matrices; any matrix with n <= 65 536) the kernel streams 16-bit column codes -- column minus the
-                                      tile's smallest column, two per word, kept in a private array next to column_index -- instead of the
-                                      32-bit column words: 2 bytes less per non-zero, the same gathers, bit-identical results.  Built at
-                                      conversion when the x-window kernel is selected (sigma 8, 12, 16, 24 or 32); +2 bytes per non-zero of
-                                      device memory.  1 = auto (default), 0 = off.  csr5hip_info.narrow_columns says what happened. */
+#define CSR5HIP_OPT_NARROW_COLUMNS 15 /* x-window kernel: when EVERY tile 0 .. p-2 spans fewer than 32 768 columns (banded / blocked
+                                      matrices; any matrix with n <= 32 768) the kernel streams 16-bit column codes -- 15 bits of column
+                                      minus the tile's smallest column + the element's row-start flag, two per word, kept in a private
+                                      array next to column_index -- instead of the 32-bit column words and the descriptor words: 2.25
+                                      bytes less per non-zero, the same gathers, bit-identical results.  Built at conversion when a
+                                      windowed kernel is selected (sigma 8, 12, 16, 24 or 32); +2 bytes per non-zero of device memory.
+                                      1 = auto (default), 0 = off.  csr5hip_info.narrow_columns says what happened. */
 
 #define CSR5HIP_OPT_DEFER_CARRIES 16 /* fused mode, plain path.  A row cut by a tile boundary is normally finished inside the launch: a tile
                                       re-reads a short spill (<= 64 elements) of its last row from the next tile and owns the row, other

@@ -12,7 +12,7 @@ export KFILTER="k_spmv"
 export KLAST=40
 echo "#### $W tile-walk=$V (cold launches)"
 A="--workload $W --slabs 0 --tile-walk $V --no-sub-configs --no-side-figures"
-[ "$W" = nd24k ] && A="$A --sigma 16"   # (the fp32 auto rule picks 24; the walking kernel exists for sigma <= 16: both kernels at 16)
+[ "$W" = nd24k ] && A="$A --sigma 16"   # (the walking kernel exists for sigma <= 16: both kernels at 16, the fp32 auto rule's choice)
 PMC="TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_READ_sum" bash scripts/gpu_pmc1.sh lat $A
 PMC="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" bash scripts/gpu_pmc1.sh l2 $A
 PMC="TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_TOTAL_ACCESSES_sum" bash scripts/gpu_pmc1.sh l1 $A

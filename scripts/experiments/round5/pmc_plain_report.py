@@ -17,7 +17,7 @@ print("""## What holds the plain-path tile kernels on the SuiteSparse-shaped sta
 ## rocprofv3 --pmc passes (one counter group per pass, counters + kernel trace only), scripts/experiments/round5/pmc_plain.sh on
 ## `bench.py --workload W --slabs 0 --tile-walk off|force --no-sub-configs --no-side-figures --steps 20 --warmup 5`; averages over the
 ## 40 COLD-protocol launches (rotating copies of matrix / x / y beyond the Infinity Cache); nd24k-like at sigma = 16 for both kernels
-## (the walking kernel is compiled for sigma <= 16; the fp32 auto rule picks 24 for the one-tile kernel since round 5).  Sums over the chip: 256 CUs (TA / TCP / SQ),
+## (the walking kernel is compiled for sigma <= 16; 16 is also the fp32 auto rule's choice).  Sums over the chip: 256 CUs (TA / TCP / SQ),
 ## 128 L2 channels (TCC), 8 XCDs (GRBM).  SQ_* counters are in units of 4 clocks per wavefront.  Clock under the profiler ~2.1 GHz.
 """)
 

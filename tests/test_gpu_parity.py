@@ -968,9 +968,9 @@ def test_deferred_carries(oracle):
 @pytest.mark.gpu
 def test_narrow_column_codes(oracle):
     """CSR5HIP_OPT_NARROW_COLUMNS: the x-window kernel streams 16-bit column codes (column - smallest column of the tile) when
-    every tile spans < 65 536 columns.  Same gathers, same arithmetic: bit-identical to the 32-bit column stream on real data,
-    exact against the oracle on integer data; matrices with and without empty rows / hub rows (the zoo: n < 65 536, so every
-    tile is narrow once the window kernel is forced); a matrix with a tile spanning > 65 535 columns keeps the 32-bit stream."""
+    every tile spans < 32 768 columns (15 bits of column, bit 15 = the element's row-start flag: no descriptor load).  Same gathers, same arithmetic: bit-identical to the 32-bit column stream on real data,
+    exact against the oracle on integer data; matrices with and without empty rows / hub rows (the zoo: n < 32 768, so every
+    tile is narrow once the window kernel is forced); a matrix with a tile spanning > 32 767 columns keeps the 32-bit stream."""
     mats = zoo.small_zoo() + [M.nd24k_like(scale=0.05, dtype=np.float64)]
     for mat in mats:
         for sigma, dtype in ((8, np.float64), (16, np.float64), (24, np.float64), (16, np.float32), (32, np.float32)):
@@ -998,7 +998,7 @@ def test_narrow_column_codes(oracle):
     val, x = (val % 3).astype(np.float32), (x % 3).astype(np.float32)
     info = {}
     _, _, _, ys = _run(nd, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, dtype=np.float32, info_out=info)
-    assert info["sigma"] == 24 and info["x_window_active"] == 1 and info["narrow_columns"] == 1, info  # (fp32, 399 per row: u = 24)
+    assert info["sigma"] == 16 and info["x_window_active"] == 1 and info["narrow_columns"] == 1, info  # (fp32, 399 per row: u = 16)
     assert np.array_equal(ys[0].astype(np.float64), oracle.csr_spmv(nd.m, nd.row_ptr, nd.col, val.astype(np.float64), x.astype(np.float64)))
     rng = np.random.default_rng(5)
     wide = M.csr_from_row_lengths(rng.integers(1, 40, size=30000), 300_000, rng, band=0.0, name="wide")

@@ -57,7 +57,7 @@ def test_walk_x_window_variant(oracle, dtype):
                 _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, xwin=2, nt=nt, walk=2, walk_ranges=ranges,
                                    slabs=0, info_out=info, narrow_cols=narrow_cols)
                 assert info["tile_walk"] == (1 if fmt.p > 1 else 0) and info["walk_x_window"] == info["tile_walk"]
-                # 16-bit column codes (every tile of these matrices spans < 65 536 columns): the sigmas k_col16 serves, unless off
+                # 16-bit column codes (every tile of these matrices spans < 32 768 columns): the sigmas k_col16 serves, unless off
                 assert info["narrow_columns"] == (1 if fmt.p > 1 and sigma in (8, 12, 16) and narrow_cols is None else 0), info
                 exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
                 assert np.array_equal(ys[0], exp), (mat.name, sigma, nt, ranges, np.flatnonzero(ys[0] != exp)[:8])
@@ -129,8 +129,7 @@ def test_walk_full_size_workloads(oracle, workload):
     nonempty = np.diff(mat.row_ptr) > 0
     for ranges in (0, 4096):
         info = {}
-        # (the fp32 rule picks sigma = 24 for nd24k-like; the walking kernel is compiled for sigma <= 16)
-        arrays, _, _, ys = _run(mat, val, x, 16 if workload == "nd24k" else H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, dtype=dtype, walk=2,
+        arrays, _, _, ys = _run(mat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, dtype=dtype, walk=2,
                                 walk_ranges=ranges, slabs=0, info_out=info, repeat=2)
         assert info["tile_walk"] == 1, info
         assert info["walk_x_window"] == (1 if workload == "nd24k" else 0), info  # auto: the banded stand-in gets windows

@@ -63,7 +63,7 @@ def test_auto_sigma_rule_shape():
     assert sig[0] == sig[1] == sig[2] == sig[3] == 6 and sig[4] == 9 and sig[5] == 16 and sig[8] == 16 and sig[9] == 16
     # fp32 has its own table, as the reference keeps one per architecture and precision: r = 8
     s32 = [lib.csr5hip_auto_sigma(1000, 1000 * k, _capi.F32) for k in (0, 1, 4, 5, 8, 9, 16, 17, 200, 256, 257, 5000)]
-    assert s32[:5] == [8] * 5 and s32[5] == 9 and s32[6] == 16 and s32[9] == 16 and s32[10] == 24 and s32[11] == 24  # u = 24
+    assert s32[:5] == [8] * 5 and s32[5] == 9 and s32[6] == 16 and s32[9] == 16 and s32[10] == 16 and s32[11] == 16  # u = 16
 
 
 def test_product_never_touches_the_oracle():
