@@ -137,3 +137,40 @@ def test_oracle_against_live_reference_on_zoo(oracle):
         y = oracle.spmv(f, mat.row_ptr, x, y0=np.full(mat.m, 777.0))
         nonempty = np.diff(mat.row_ptr) > 0
         assert np.array_equal(y[nonempty], y_ref[nonempty]), mat.name
+
+
+def test_y_offset_recomputed_from_bit_flags(oracle):
+    """The kernels that read no descriptor word (k_spmv_range; k_spmv with the narrow column codes, whose bit 15 carries the
+    row-start flag) recompute the descriptor's y_offset from the lane's bit flags: segments that start in the lane, exclusive
+    wave prefix, minus one for lanes > 0 (csr5_spmv.hip, csr5_hot.hip; reference field: format_cuda.h:161-267).  The two must
+    agree on every lane that owns a flag -- the only lanes that use it -- with and without empty rows, one and two packets."""
+    rng = np.random.default_rng(1)
+    mats = zoo.small_zoo() + [M.nd24k_like(scale=0.03, dtype=np.float64)]
+    for k in range(4):
+        lens = rng.integers(0, 60, size=3000)
+        lens[rng.random(3000) < 0.4] = 0
+        mats.append(M.csr_from_row_lengths(lens, 5000, rng, band=0.3, name=f"r{k}"))
+    checked = 0
+    for mat in mats:
+        for sigma in (8, 12, 16, 24, 32):
+            f = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, np.ones(mat.nnz))
+            if f.p < 2:
+                continue
+            bit_all = f.bit_y + f.bit_ss
+            d = f.tile_desc.reshape(f.p, f.num_packet, 64).astype(np.uint64)
+            for t in range(f.p - 1):
+                flags = (d[t, 0] << np.uint64(bit_all)) & np.uint64(0xFFFFFFFF)
+                if f.num_packet > 1:
+                    flags |= d[t, 1] >> np.uint64(32 - bit_all)
+                stored = (d[t, 0] >> np.uint64(32 - f.bit_y)).astype(np.int64)
+                bits = (flags[:, None] >> (np.uint64(31) - np.arange(sigma, dtype=np.uint64))[None, :]) & np.uint64(1)
+                f0 = bits[:, 0].astype(bool)
+                f0[0] = True
+                stop = bits[:, 1:].sum(axis=1).astype(np.int64)
+                present = f0 | (stop > 0)
+                segn = np.maximum(stop - np.where(f0, 0, 1) + np.where(present, 1, 0), 0)
+                y = np.cumsum(segn) - segn - 1
+                y[0] = 0
+                assert np.array_equal(y[present], stored[present]), (mat.name, sigma, t)
+                checked += 1
+    assert checked > 1000
