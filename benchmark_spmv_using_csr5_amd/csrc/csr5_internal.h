@@ -177,7 +177,8 @@ struct SpmvOptions {
 // ownership, the hand-shake atomics -- what it costs is one small launch (2-2.5 us)
 constexpr int DEFER_AUTO_LONG_ROW = 128;          // average non-zeros per row from which most cut rows hand-shake ...
 constexpr int DEFER_AUTO_MIN_TILES_LONG = 3000;   // ... and deferral pays from this many tiles on (nd24k-like: 3 741 tiles -2.4 us)
-constexpr int DEFER_AUTO_MIN_TILE_SIGMA = 250000; // shorter rows: from tiles x sigma >= this (27 per row, sigma 16: ~15 k tiles)
+constexpr int DEFER_AUTO_MIN_TILE_SIGMA = 500000; // shorter rows: from tiles x sigma >= this (27 per row, sigma 16: loses 2 us at 21 k
+                                                  // tiles, wins 8 at 53 k; 81 per row even at 24 k; R-MAT 20 at 16 k would win 5 %)
 #ifndef CSR5_WALK_XWIN_BYTES
 #define CSR5_WALK_XWIN_BYTES 16384
 #endif

@@ -41,6 +41,10 @@ def main():
                "fem81": lambda: fem(1_000_000, 81), "fem200": lambda: fem(300_000, 200),
                "rmat22p": lambda: M.rmat(22, 16, seed=4, dtype=npd), "rmat20p": lambda: M.rmat(20, 16, seed=4, dtype=npd),
                "scircuit": lambda: M.scircuit_like(dtype=npd), "webbase": lambda: M.webbase_like(dtype=npd),
+               "longrand": lambda: M.csr_from_row_lengths(np.random.default_rng(7).integers(500, 4000, size=6000), 400_000,
+                                                          np.random.default_rng(8), band=0.0, dtype=npd),
+               "mixed": lambda: M.csr_from_row_lengths(np.where(np.random.default_rng(9).random(400_000) < 0.02, 900, 12), 400_000,
+                                                       np.random.default_rng(10), band=0.5, dtype=npd),
                "rmat20": lambda: M.rmat(20, 16, seed=4, dtype=npd), "rmat22": lambda: M.rmat(22, 16, seed=4, dtype=npd)}
         mat = (sized[w.split(":")[0]] if ":" in w else mat[w])()
         ys = {}

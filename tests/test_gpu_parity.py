@@ -422,6 +422,19 @@ def test_large_rmat_size_independent_properties(scale):
             torch.cuda.synchronize()
             assert torch.equal(mat.col, col0) and torch.equal(val, val0)
             A.close()
+    if scale == 22:
+        # the plain path at size (no slab structure): 65 536 tiles x sigma 16 -> the auto rule defers the carries
+        A = H.anonymouslibHandle(mat.m, mat.n)
+        assert A.inputCSR(mat.nnz, mat.row_ptr, mat.col, val) == 0
+        assert A.setX(x) == 0 and A.setSigma(H.ANONYMOUSLIB_AUTO_TUNED_SIGMA) == 0 and A.setColumnSlabs(0) == 0
+        assert A.asCSR5() == 0
+        assert A.info().column_slabs == 0 and A.info().carries_deferred == 1, A.info()
+        y = torch.full((mat.m,), -3.0, dtype=torch.float64, device=DEV)
+        assert A.spmv(1.0, y) == 0 and A.spmv(1.0, y) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(y[nonempty], ref[nonempty])
+        assert A.destroy() == 0
+        A.close()
     # real-valued data at full size, default options (column slabs + hot table where the auto rule picks them):
     # |y - y_ref| <= 1e-12 * sum|a x| against the independent device product, and bit-reproducible run to run
     valr = torch.rand(mat.nnz, generator=g, device=DEV, dtype=torch.float64) * 2 - 1
@@ -951,8 +964,8 @@ def test_deferred_carries(oracle):
     for mk, dtype, sigma, expect in ((lambda: M.nd24k_like(scale=0.25, dtype=np.float32), np.float32, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, 1),
                                      (lambda: M.nd24k_like(scale=0.05, dtype=np.float32), np.float32, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, 0),
                                      (lambda: M.scircuit_like(), np.float64, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, 0),
-                                     (lambda: M.rmat(18, 16, seed=4), np.float64, 16, 0),      # 4 096 tiles x 16
-                                     (lambda: M.rmat(20, 16, seed=4), np.float64, 16, 1)):     # 16 384 tiles x 16
+                                     (lambda: M.rmat(18, 16, seed=4), np.float64, 16, 0)):     # 4 096 tiles x 16: short rows,
+        # too few tiles (the positive short-row case needs >= 32 M non-zeros: test_large_rmat_size_independent_properties)
         mat = mk()
         val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=73, mode="int")
         if dtype == np.float32:
