@@ -40,6 +40,7 @@ def main():
                "nd24kx4": lambda: M.nd24k_like(scale=4.0, dtype=npd), "fem27": lambda: fem(2_000_000, 27),
                "fem81": lambda: fem(1_000_000, 81), "fem200": lambda: fem(300_000, 200),
                "rmat22p": lambda: M.rmat(22, 16, seed=4, dtype=npd), "rmat20p": lambda: M.rmat(20, 16, seed=4, dtype=npd),
+               "rmat18p": lambda: M.rmat(18, 16, seed=4, dtype=npd), "rmat19p": lambda: M.rmat(19, 16, seed=4, dtype=npd),
                "scircuit": lambda: M.scircuit_like(dtype=npd), "webbase": lambda: M.webbase_like(dtype=npd),
                "longrand": lambda: M.csr_from_row_lengths(np.random.default_rng(7).integers(500, 4000, size=6000), 400_000,
                                                           np.random.default_rng(8), band=0.0, dtype=npd),
