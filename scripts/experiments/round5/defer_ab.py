@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--slabs", default="auto")
     ap.add_argument("--no-cold", action="store_true")
     ap.add_argument("--modes", default="off,force,auto")
+    ap.add_argument("--x-window", default="auto")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     for w in args.workloads:
@@ -50,7 +51,7 @@ def main():
         mat = (sized[w.split(":")[0]] if ":" in w else mat[w])()
         ys = {}
         for mode in args.modes.split(","):
-            a = base_args(sigma=args.sigma, slabs=slabs, tile_walk="off", defer_carries=mode)
+            a = base_args(sigma=args.sigma, slabs=slabs, tile_walk="off", defer_carries=mode, x_window=args.x_window)
             warm, cold, desc, b = measure(mat, w, dtype_name, a, dev, cold=not args.no_cold)
             a.values = "real"  # (rounding-sensitive data for the comparison)
             prob = B.Problem(mat, w, dtype_name, a, dev, 14)
