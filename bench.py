@@ -108,9 +108,6 @@ def parse_args():
                          "spmv (x is read live, as the reference reads it); 1 = once per setX, which the reference CLI's protocol "
                          "allows (setX once, NUM_RUN spmv calls on the same x: CSR5_cuda/main.cu:63-99) -- reported as the side "
                          "figure roofline.x_snapshot_once_per_setX")
-    ap.add_argument("--tile-walk", default="off", choices=["auto", "off", "force"],
-                    help="plain path: the range-walking pipelined tile kernel (CSR5HIP_OPT_TILE_WALK)")
-    ap.add_argument("--walk-ranges", type=int, default=0, help="tile ranges of the walking kernel, 0 = default")
     ap.add_argument("--defer-carries", default="auto", choices=["auto", "off", "force"],
                     help="plain path: cut rows finished by a second small launch instead of arrival atomics (CSR5HIP_OPT_DEFER_CARRIES)")
     ap.add_argument("--zero-empty", type=int, default=0, choices=[0, 1],
@@ -241,10 +238,8 @@ class Problem:
         if args.slab_shift is not None:
             _ck(A.setSlabShift(args.slab_shift), "setSlabShift")
         _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
-        _ck(A.setTileWalk({"off": 0, "auto": 1, "force": 2}[getattr(args, "tile_walk", "off")]), "setTileWalk")
         if getattr(args, "defer_carries", "auto") != "auto":  # (auto = the library's default)
             _ck(A.setDeferCarries({"off": 0, "force": 2}[args.defer_carries]), "setDeferCarries")
-        _ck(A.setWalkRanges(int(getattr(args, "walk_ranges", 0))), "setWalkRanges")
         rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 0)))
         if rc != 0 and not os.environ.get("CSR5HIP_LIB"):  # (an older library build under A/B test does not know the option)
             _ck(rc, "setXSnapshot")
@@ -403,7 +398,7 @@ def config_dict(prob, args, ingest_ms=None):
         "m_per_gpu": prob.m, "n": prob.n, "nnz_per_gpu": prob.nnz, "sigma": info.sigma, "tiles": info.p,
         "spmv_mode": args.mode, "launch": args.launch,
         "lds_x_window": bool(info.x_window_active), "x_window_cover_pct": info.x_window_cover_pct,
-        "narrow_columns": bool(info.narrow_columns), "tile_walk": bool(info.tile_walk), "carries_deferred": bool(info.carries_deferred), "walk_ranges": info.walk_ranges, "walk_x_window": bool(info.walk_x_window),
+        "narrow_columns": bool(info.narrow_columns), "carries_deferred": bool(info.carries_deferred),
         "column_slabs": info.column_slabs, "slab_shift": info.slab_shift, "slab_segments": info.slab_segments,
         "slab_sigma": info.slab_sigma, "slab_build_ms": round(info.t_slab_ms, 3),
         "slab_hot_table": bool(info.slab_hot), "slab_hot_cover_pct": info.slab_hot_cover_pct,
@@ -736,7 +731,7 @@ def main():
                                   "warm_frac": w.get("frac"), "warm_us": w.get("launch_us"),
                                   "traffic_ratio": (round(r["traffic"] / r["algorithmic_bytes_per_launch"], 3) if r.get("traffic") else None),
                                   "kernel": r.get("kernel"), "sigma": sc["config"]["sigma"], "column_slabs": sc["config"]["column_slabs"],
-                                  "tile_walk": sc["config"].get("tile_walk"), "data": sc.get("data")})
+                                  "data": sc.get("data")})
             out["roofline"]["configs"] = summary
         print(json.dumps(out), flush=True)
     else:

@@ -39,8 +39,6 @@ OPT_SLAB_HOT = 9
 OPT_SLAB_MEMORY_MIB = 10
 OPT_X_SNAPSHOT = 11
 OPT_NARROW_VALUES = 12
-OPT_TILE_WALK = 13
-OPT_WALK_RANGES = 14
 OPT_NARROW_COLUMNS = 15
 OPT_DEFER_CARRIES = 16
 MULTI_OPT_ROW_WEIGHT = 100  # csr5hip_multi_set_option only (before input_csr)
@@ -67,10 +65,6 @@ class Csr5Info(C.Structure):
         ("slab_values_narrowed", C.c_int),
         ("carries_deferred", C.c_int),
         ("narrow_columns", C.c_int),
-        ("tile_walk", C.c_int),
-        ("walk_ranges", C.c_int),
-        ("walk_x_window", C.c_int),
-        ("walk_x_window_cover_pct", C.c_int),
     ]
 
 

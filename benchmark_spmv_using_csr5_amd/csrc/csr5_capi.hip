@@ -115,17 +115,13 @@ struct csr5hip_handle_s {
     size_t scan_tmp_bytes = 0;
     uint32_t scalar_words[2] = {0, 0}; // landing zone of the two 4-byte reads of the conversion (checkpoint loading)
     uint32_t *host_words = nullptr;    // 32 pinned, device-visible words the last conversion kernels export into
-    int walk_request = 0;        // CSR5HIP_OPT_TILE_WALK: 0 off (default), 1 auto, 2 force
-    int walk_ranges_request = 0; // CSR5HIP_OPT_WALK_RANGES: 0 = default
     // deferred carries (Geometry.defer; classification in csr5_format.hip tile_carry_meta): decided at conversion
     int defer_request = 1;       // CSR5HIP_OPT_DEFER_CARRIES: 0 off, 1 auto (default), 2 force
     // narrow column codes of the x-window kernel (csr5_format.hip k_col16): built when that kernel is selected
     int col16_request = 1;       // CSR5HIP_OPT_NARROW_COLUMNS: 0 off, 1 auto (default)
     bool col16_built = false;    // the codes of the current conversion exist
-    unsigned col16_wide = 0;     // tiles that span >= 65 536 columns (the codes are used only when there is none)
+    unsigned col16_wide = 0;     // tiles that span >= 32 768 columns (the codes are used only when there is none)
     Buffer b_col16;              // codes [(p-1) * T / 2 words], then base16 [p]
-    int walk_xwin_tiles = 0;     // tiles that got one of the walking kernel's (16-KB) x-windows at conversion
-    long long walk_xwin_covered = 0; // non-zeros inside those windows
     double wall_clock_khz = 0;         // rate of the device's constant wall clock (phase stamps)
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -345,14 +341,9 @@ int csr5hip_set_sigma(csr5hip_handle h, int sigma)
 
 static int build_slabs(csr5hip_handle h);
 static int build_slabs_impl(csr5hip_handle h);
-static int prepare_walk(csr5hip_handle h);
 static int prepare_col16(csr5hip_handle h);
-// kernel-side tables of the plain (non-slab) path that are built on demand: narrow column codes, walking-kernel ranges
-static int prepare_plain(csr5hip_handle h)
-{
-    const int rc = prepare_walk(h); // (first: which kernel runs decides whether the narrow column codes are of use)
-    return rc != CSR5HIP_SUCCESS ? rc : prepare_col16(h);
-}
+// kernel-side tables of the plain (non-slab) path that are built on demand: the narrow column codes
+static int prepare_plain(csr5hip_handle h) { return prepare_col16(h); }
 
 int csr5hip_set_option(csr5hip_handle h, int option, int value)
 {
@@ -471,23 +462,6 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
                 return rc;
         }
         break;
-    case CSR5HIP_OPT_TILE_WALK:
-    case CSR5HIP_OPT_WALK_RANGES:
-        if (option == CSR5HIP_OPT_TILE_WALK) {
-            if (value < 0 || value > 2)
-                return CSR5HIP_INVALID_ARGUMENT;
-            h->walk_request = value;
-        } else {
-            if (value < 0 || value > WALK_MAX_RANGES)
-                return CSR5HIP_INVALID_ARGUMENT;
-            h->walk_ranges_request = value;
-        }
-        if (h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0) {
-            const int rc = prepare_plain(h); // (the walking kernel's tables, then the column codes of whichever kernel runs)
-            if (rc != CSR5HIP_SUCCESS)
-                return rc;
-        }
-        break;
     case CSR5HIP_OPT_SLAB_MEMORY_MIB:
         if (value < 0)
             return CSR5HIP_INVALID_ARGUMENT;
@@ -557,16 +531,8 @@ static int reserve_aux(csr5hip_handle h)
     // zero-initialised part first
     const size_t o_desc = take(desc_words * 4), o_offp = take(p1 * 4), o_cal = take(p1 * h->vsize()),
                  o_acc = take(p1 * h->vsize()), o_cnt = take(p1 * 4), o_counters = take(COUNTER_WORDS * 4), o_tp = take(p1 * 4), o_offset = take(offset_cap * 4);
-    // range-walking kernel (csr5_walk.hip): arrival words of the ranges (zero between launches), then its tables -- only when
-    // the kernel is enabled at conversion time (CSR5HIP_OPT_TILE_WALK != 0 before asCSR5): its 16-KB windows are found by the
-    // same pass as the one-tile kernel's and would cost every conversion a second scoring of every tile
-    const bool walk_tables = !h->is_child && h->walk_request != 0;
-    const size_t wr = walk_tables ? (size_t)WALK_MAX_RANGES + 2 : 0;
-    const size_t o_wacc = take(wr * h->vsize()), o_wcnt = take(wr * 4);
     const size_t zero_bytes = off;
     const size_t o_meta = take(p1 * 16), o_hdr = take(p1 * 32), o_scan = take(h->scan_tmp_bytes);
-    const size_t o_wrow = take(wr * 4), o_wmeta = take(wr * 16), o_wlead = take(wr * h->vsize()),
-                 o_xwin = take(walk_tables ? p1 * 4 : 0), o_xcov = take(walk_tables ? p1 * 4 : 0);
     HIP_TRY(h->b_arena.reserve(off));
     char *base = (char *)h->b_arena.ptr;
     h->d.tile_desc = (uint32_t *)(base + o_desc);
@@ -580,14 +546,6 @@ static int reserve_aux(csr5hip_handle h)
     h->d.carry_meta = (uint32_t *)(base + o_meta);
     h->d.tile_hdr = (uint32_t *)(base + o_hdr);
     h->scan_tmp = base + o_scan;
-    h->d.walk_ranges = 0;
-    h->d.walk_acc = walk_tables ? base + o_wacc : nullptr;
-    h->d.walk_cnt = walk_tables ? (uint32_t *)(base + o_wcnt) : nullptr;
-    h->d.walk_row = walk_tables ? (uint32_t *)(base + o_wrow) : nullptr;
-    h->d.walk_meta = walk_tables ? (uint32_t *)(base + o_wmeta) : nullptr;
-    h->d.walk_lead = walk_tables ? base + o_wlead : nullptr;
-    h->d.xwin_base = walk_tables ? (int32_t *)(base + o_xwin) : nullptr;
-    h->d.xwin_cover = walk_tables ? (int32_t *)(base + o_xcov) : nullptr;
     HIP_TRY(hipMemsetAsync(base, 0, zero_bytes, s));
     return CSR5HIP_SUCCESS; // stream-ordered: the conversion kernels follow on the same stream
 }
@@ -625,18 +583,30 @@ static int prepare_col16(csr5hip_handle h)
     h->d.col16 = nullptr;
     h->d.base16 = nullptr;
     const Geometry &g = h->g;
-    // (a windowed kernel serves spmv(): the one-tile kernel's 4-KB windows, or the walking kernel with its 16-KB ones)
-    const bool windowed = h->opt.walk ? h->opt.walk_x_window != 0 : h->opt.x_window != 0;
+    const bool windowed = h->opt.x_window != 0;
     if (h->col16_request == 0 || h->is_child || g.p <= 1 || h->opt.mode != 1 || !windowed || !col16_sigma(g.sigma))
         return CSR5HIP_SUCCESS;
     const size_t code_words = (size_t)(g.p - 1) * (g.tile_elems / 2);
     if (!h->col16_built) {
-        HIP_TRY(h->b_col16.reserve((code_words + (size_t)g.p + 1) * 4));
+        // The codes are an optional accelerator (2 bytes per non-zero of device memory): when they cannot be built the handle
+        // stays on the 32-bit column words -- csr5hip_last_error() says so -- instead of failing asCSR5() / setOption().
         uint32_t *wide = h->d.counters + 5;
-        HIP_TRY(hipMemsetAsync(wide, 0, 4, h->stream));
-        HIP_TRY(launch_col16(g, h->d, (uint32_t *)h->b_col16.ptr, (int32_t *)h->b_col16.ptr + code_words, wide, h->stream));
-        HIP_TRY(hipMemcpyAsync(&h->col16_wide, wide, 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        hipError_t e = h->b_col16.reserve((code_words + (size_t)g.p + 1) * 4);
+        if (e == hipSuccess)
+            e = hipMemsetAsync(wide, 0, 4, h->stream);
+        if (e == hipSuccess)
+            e = launch_col16(g, h->d, (uint32_t *)h->b_col16.ptr, (int32_t *)h->b_col16.ptr + code_words, wide, h->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(&h->col16_wide, wide, 4, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError(); // clear the sticky allocation / launch error
+            h->b_col16.release();
+            set_last_error(std::string("narrow column codes not built, 32-bit column words in use: ") + hipGetErrorString(e));
+            h->drop_graphs();
+            return CSR5HIP_SUCCESS;
+        }
         h->col16_built = true;
     }
     if (h->col16_wide == 0) {
@@ -644,68 +614,6 @@ static int prepare_col16(csr5hip_handle h)
         h->d.base16 = (const int32_t *)h->b_col16.ptr + code_words;
         h->opt.col16 = 1;
     }
-    h->drop_graphs();
-    return CSR5HIP_SUCCESS;
-}
-
-// ---- the range-walking pipelined kernel (csr5_walk.hip) ------------------------------------------------------------------
-// its x-window variant: forced with the one-tile kernel's (CSR5HIP_OPT_X_WINDOW = 2), or (auto) when the 16-KB windows found at
-// conversion cover at least 70 % of the non-zeros of tiles 0 .. p-2.  No sigma / spread conditions as for the one-tile kernel: a
-// walking wavefront restages its slice of x once per range or so, not once per tile.
-static int walk_xwin_decision(const csr5hip_handle_s *h)
-{
-    if (h->xwin_request == 2)
-        return 1;
-    if (h->xwin_request != 1 || h->walk_xwin_tiles <= 0)
-        return 0;
-    return h->walk_xwin_covered * 100 >= (long long)(h->g.p - 1) * h->g.tile_elems * 70;
-}
-// how many ranges (= wavefronts, one per workgroup) the tiles 0 .. p-2 are dealt to: as set, or 8 per CU -- fewer when the
-// wavefronts' LDS (y-compaction region + 16-KB slice of x) does not let eight of them share a CU's 160 KB
-static int walk_ranges_for(const csr5hip_handle_s *h)
-{
-    int want = h->walk_ranges_request;
-    if (want <= 0) {
-        int dev = 0, cus = 0; // (asked once per conversion: no process-wide cache to race on or to go stale)
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            cus <= 0) {
-            (void)hipGetLastError();
-            cus = 256;
-        }
-        const int lds = walk_wave_lds_bytes(h->g.sigma, (int)h->vsize(), h->opt.walk_x_window);
-        int per_cu = (160 * 1024) / (lds > 0 ? lds : 1);
-        per_cu = per_cu > WALK_DEFAULT_WAVES_PER_CU ? WALK_DEFAULT_WAVES_PER_CU : (per_cu < 1 ? 1 : per_cu);
-        want = cus * per_cu;
-    }
-    want = want > WALK_MAX_RANGES ? WALK_MAX_RANGES : want;
-    return want < h->g.p - 1 ? want : h->g.p - 1;
-}
-// Decides whether spmv() runs the walking kernel and, if so, builds its range tables (one small kernel + one synchronisation:
-// the number of rows spanning more than RUN_SERIAL_MAX ranges comes back in host_words[16]).  Forced, or (auto) when every
-// range gets enough tiles for the pipeline to pay -- with fewer, all tiles are resident at once anyway and the one-tile
-// kernel's short-spill ownership saves the ranges' arrival atomics.  No partial is parked between SpMVs, so the arrival words
-// are all zero whenever the ranges change.
-static int prepare_walk(csr5hip_handle h)
-{
-    h->opt.walk = 0;
-    h->opt.walk_long_runs = 0;
-    h->opt.walk_x_window = 0;
-    h->d.walk_ranges = 0;
-    if (h->walk_request == 0 || h->is_child || h->slab_S > 0 || !h->d.walk_row || h->opt.mode != 1 || h->opt.hot ||
-        !walk_supported(h->g, (int)h->vsize()))
-        return CSR5HIP_SUCCESS;
-    h->opt.walk_x_window = walk_xwin_decision(h);
-    const int ranges = walk_ranges_for(h);
-    if (ranges <= 0)
-        return CSR5HIP_SUCCESS;
-    if (h->walk_request != 2 && (long long)(h->g.p - 1) < (long long)WALK_AUTO_MIN_TILES_PER_RANGE * ranges)
-        return CSR5HIP_SUCCESS;
-    h->d.walk_ranges = ranges;
-    h->host_words[16] = 0;
-    HIP_TRY(launch_walk_tables(h->g, h->d, h->host_words + 16, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    h->opt.walk_long_runs = h->host_words[16] != 0;
-    h->opt.walk = 1;
     h->drop_graphs();
     return CSR5HIP_SUCCESS;
 }
@@ -750,8 +658,6 @@ static int derive_kernel_tables(csr5hip_handle h)
     h->xwin_covered = (long long)w[3];
     h->opt.long_runs = w[4] != 0;
     h->xwin_lines = (long long)w[5];
-    h->walk_xwin_tiles = (int)w[6];
-    h->walk_xwin_covered = (long long)w[7];
     if (g.defer)
         h->opt.long_runs = 1; // (the parties of every cut row park: k_calibrate is part of each SpMV)
     // phase times from the kernels' wall-clock stamps (k_row_scan, k_tile_desc, k_transpose, k_tile_tables); a phase
@@ -853,7 +759,7 @@ int csr5hip_as_csr5(csr5hip_handle h)
     }
     resolve_variants(h);
     h->format = CSR5HIP_FORMAT_CSR5;
-    rc = build_slabs(h); // (ends with prepare_walk when the plain path serves spmv())
+    rc = build_slabs(h); // (ends with prepare_plain when the plain path serves spmv())
     if (rc != CSR5HIP_SUCCESS) {
         // only when the structure was requested explicitly: a failed asCSR5 leaves CSR, as in the reference
         // (anonymouslib_cuda.h:105-220 returns before _format changes)
@@ -949,7 +855,7 @@ static int build_slabs(csr5hip_handle h)
 {
     h->slab_fallback = false;
     const int rc = build_slabs_impl(h);
-    if (rc == CSR5HIP_SUCCESS) // (the plain path serves spmv() when no structure is active: its walking kernel's tables, if wanted)
+    if (rc == CSR5HIP_SUCCESS) // (the plain path serves spmv() when no structure is active: its narrow column codes, if of use)
         return h->slab_S > 0 || h->is_child ? rc : prepare_plain(h);
     const std::string why = g_last_error;
     (void)hipGetLastError(); // clear a sticky allocation error
@@ -1539,7 +1445,7 @@ int csr5hip_load(const char *path, csr5hip_handle *out, csr5hip_csr *arrays)
     fclose(f);
     resolve_variants(h);
     h->format = CSR5HIP_FORMAT_CSR5;
-    rc = build_slabs(h); // (ends with prepare_walk when the plain path serves spmv())
+    rc = build_slabs(h); // (ends with prepare_plain when the plain path serves spmv())
     if (rc != CSR5HIP_SUCCESS) {
         csr5hip_free(h);
         csr5hip_csr_release(arrays);
@@ -1825,17 +1731,7 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->x_snapshot = h->x_snapshot;
     info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
     info->carries_deferred = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->g.defer ? 1 : 0;
-    info->narrow_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.col16 &&
-                                   (h->opt.walk ? h->opt.walk_x_window && h->g.sigma <= WALK_MAX_SIGMA : h->opt.x_window)
-                               ? 1
-                               : 0;
-    info->tile_walk = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.walk ? 1 : 0;
-    info->walk_ranges = h->format == CSR5HIP_FORMAT_CSR5 ? h->d.walk_ranges : 0;
-    info->walk_x_window = info->tile_walk && h->opt.walk_x_window ? 1 : 0;
-    {
-        const long long body = (long long)(h->g.p > 1 ? h->g.p - 1 : 0) * h->g.tile_elems;
-        info->walk_x_window_cover_pct = h->format == CSR5HIP_FORMAT_CSR5 && body > 0 ? (int)(h->walk_xwin_covered * 100 / body) : 0;
-    }
+    info->narrow_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.col16 && h->opt.x_window ? 1 : 0;
     long long bytes = (long long)h->b_arena.cap;
     for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_val32, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
                             &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_range_head, &h->b_slab_tmp,

@@ -1,6 +1,5 @@
-// csr5_carry.h -- the carry protocol between parties that hold partial sums of one row, and the CSR tail tile; shared by the
-// one-tile-per-wavefront kernel (csr5_spmv.hip: parties = tiles) and the range-walking kernel (csr5_walk.hip: parties = the
-// tile ranges of the wavefronts).  gfx950 only; not a public header.
+// csr5_carry.h -- the carry protocol between parties that hold partial sums of one row (the one-tile-per-wavefront kernel of
+// csr5_spmv.hip: parties = tiles), and the CSR tail tile.  gfx950 only; not a public header.
 #pragma once
 
 #include "csr5_internal.h"

@@ -450,8 +450,7 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
                                                        const int32_t *__restrict__ col,
                                                        uint4 *__restrict__ carry_meta, uint32_t *__restrict__ hdr,
                                                        uint32_t *__restrict__ counters, int XWIN_ELEMS,
-                                                       int line_shift, int WALK_XWIN_ELEMS,
-                                                       int32_t *__restrict__ xwin_base, int32_t *__restrict__ xwin_cover)
+                                                       int line_shift)
 {
     stamp_phase(counters, 3);
     uint32_t *const long_run_counter = counters + 2;
@@ -469,49 +468,30 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
     const unsigned next_x = (unsigned)__builtin_amdgcn_readlane((int)meta.x, 1);
 
     // window selection for XE columns: {first column, non-zeros inside} of the best candidate, {-1, 0} if it covers less than
-    // XWIN_MIN_COVER_PCT % of the tile.  quantum > 1: bases are multiples of it, so that consecutive tiles whose columns drift
-    // slowly (banded matrices) ask for the SAME slice of x, which the range-walking kernel keeps staged (csr5_walk.hip).
-    auto pick_window = [&](int XE, int quantum, int *inside_out) -> int {
+    // XWIN_MIN_COVER_PCT % of the tile
+    auto pick_window = [&](int XE, int *inside_out) -> int {
         const int hi_limit = g.n > XE ? g.n - XE : 0;
         auto window_of = [&](int centre) {
             int lo = centre - XE / 2;
             lo = lo < 0 ? 0 : (lo > hi_limit ? hi_limit : lo);
-            return quantum > 1 ? lo / quantum * quantum : lo & ~3;
+            return lo & ~3;
         };
-        int lo, best_score;
-        if (quantum > 1) {
-            // the walking kernel's window: centred on the MEDIAN of the 64 samples -- robust against the few far-off columns of
-            // a banded tile, so the quantised base moves only when the band itself has drifted by a quantum (a best-of-64
-            // choice flips between equally good bases from tile to tile, and every flip is a 16-KB restage)
-            int rank = 0;
+        // score every lane's candidate on the 64 samples (v_readlane broadcasts, no LDS shuffles)
+        const int my_lo = window_of(sample);
+        int score = 0;
 #pragma unroll
-            for (int j = 0; j < OMEGA; j++) {
-                const int o = __builtin_amdgcn_readlane(sample, j);
-                rank += o < sample || (o == sample && j < lane);
-            }
-            const unsigned long long mid = __ballot(rank == OMEGA / 2);
-            const int median = __builtin_amdgcn_readlane(sample, __builtin_ctzll(mid));
-            lo = window_of(median);
-            int in = (unsigned)(sample - lo) < (unsigned)XE;
-            best_score = __popcll(__ballot(in));
-        } else {
-            // score every lane's candidate on the 64 samples (v_readlane broadcasts, no LDS shuffles)
-            const int my_lo = window_of(sample);
-            int score = 0;
+        for (int j = 0; j < OMEGA; j++)
+            score += (unsigned)(__builtin_amdgcn_readlane(sample, j) - my_lo) < (unsigned)XE;
+        // best candidate: highest score, lowest lane on ties (deterministic)
+        int best = score * OMEGA + (OMEGA - 1 - lane);
 #pragma unroll
-            for (int j = 0; j < OMEGA; j++)
-                score += (unsigned)(__builtin_amdgcn_readlane(sample, j) - my_lo) < (unsigned)XE;
-            // best candidate: highest score, lowest lane on ties (deterministic)
-            int best = score * OMEGA + (OMEGA - 1 - lane);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const int o = __shfl_xor(best, d, OMEGA);
-                best = o > best ? o : best;
-            }
-            const int best_all = __builtin_amdgcn_readfirstlane(best);
-            lo = __builtin_amdgcn_readlane(my_lo, OMEGA - 1 - (best_all % OMEGA));
-            best_score = best_all / OMEGA;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(best, d, OMEGA);
+            best = o > best ? o : best;
         }
+        const int best_all = __builtin_amdgcn_readfirstlane(best);
+        const int lo = __builtin_amdgcn_readlane(my_lo, OMEGA - 1 - (best_all % OMEGA));
+        const int best_score = best_all / OMEGA;
         *inside_out = 0;
         // The 64 samples are every sigma-th element of the tile.  A window that holds fewer than a quarter of the samples
         // it would need cannot cover XWIN_MIN_COVER_PCT % of the tile: such tiles (every tile of a matrix with scattered
@@ -528,10 +508,9 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
         return lo;
     };
     unsigned window = 0, stats = 0;
-    int walk_lo = -1, walk_inside = 0;
     if (windowed) {
         int inside = 0;
-        const int lo = pick_window(XWIN_ELEMS, 1, &inside);
+        const int lo = pick_window(XWIN_ELEMS, &inside);
         if (lo >= 0) {
             // How many distinct 128-byte lines of x do the in-window lanes of ONE gather instruction (the 64 samples)
             // touch?  That is what the window replaces: a gather spread over 30+ lines costs 60+ clk in the
@@ -550,16 +529,9 @@ __global__ void __launch_bounds__(FMT_BLOCK) k_tile_tables(Geometry g, const int
             window = (unsigned)lo + 1u;
             stats = (unsigned)inside | ((unsigned)lines << 16);
         }
-        // the range-walking kernel's own, larger window (a wavefront that walks a range of tiles restages rarely)
-        if (xwin_base)
-            walk_lo = pick_window(WALK_XWIN_ELEMS, WALK_XWIN_ELEMS / 8, &walk_inside);
     }
     if (lane == 0) {
         meta.w = window;
-        if (xwin_base) { // dense arrays for the range-walking kernel: one scalar load per tile
-            xwin_base[t] = walk_lo;
-            xwin_cover[t] = walk_inside;
-        }
         carry_meta[t] = meta;
         reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t] = meta;
         reinterpret_cast<uint4 *>(hdr)[2 * (size_t)t + 1] = make_uint4(next_x, tile_ptr[t], tile_ptr[t + 1], stats);
@@ -577,11 +549,10 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
                                                        const uint32_t *__restrict__ hdr,
                                                        const int32_t *__restrict__ offset_ptr,
                                                        uint32_t *__restrict__ counters,
-                                                       uint32_t *__restrict__ host_words, int export_only,
-                                                       const int32_t *__restrict__ xwin_cover)
+                                                       uint32_t *__restrict__ host_words, int export_only)
 {
-    __shared__ unsigned part[16][5];
-    unsigned on = 0, in = 0, lines = 0, won = 0, win = 0; // (won / win: tiles with / non-zeros inside a walking-kernel window)
+    __shared__ unsigned part[16][3];
+    unsigned on = 0, in = 0, lines = 0;
     if (export_only)
         stamp_phase(counters, 3); // (k_tile_tables, which stamps this phase, did not run)
     for (int t = blockIdx.x * 1024 + threadIdx.x; t < (export_only ? 0 : g.p - 1); t += gridDim.x * 1024) {
@@ -589,39 +560,26 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
         on += v != 0;
         in += v & 0xFFFFu;
         lines += v >> 16;
-        if (xwin_cover) {
-            const unsigned w = (unsigned)xwin_cover[t];
-            won += w != 0;
-            win += w;
-        }
     }
     on = (unsigned)wave_sum_i32((int)on);
     in = (unsigned)wave_sum_i32((int)in);
     lines = (unsigned)wave_sum_i32((int)lines);
-    won = (unsigned)wave_sum_i32((int)won);
-    win = (unsigned)wave_sum_i32((int)win);
     if ((threadIdx.x & (OMEGA - 1)) == 0) {
         part[threadIdx.x >> 6][0] = on;
         part[threadIdx.x >> 6][1] = in;
         part[threadIdx.x >> 6][2] = lines;
-        part[threadIdx.x >> 6][3] = won;
-        part[threadIdx.x >> 6][4] = win;
     }
     __syncthreads();
     if (threadIdx.x != 0)
         return;
-    on = in = lines = won = win = 0;
+    on = in = lines = 0;
     for (int w = 0; w < 16; w++)
-        on += part[w][0], in += part[w][1], lines += part[w][2], won += part[w][3], win += part[w][4];
+        on += part[w][0], in += part[w][1], lines += part[w][2];
     if (gridDim.x > 1) { // (one workgroup up to 16 k tiles: no atomics, no fence)
         if (on | in) {
             atomicAdd(counters + 0, on);
             atomicAdd(counters + 1, in);
             atomicAdd(counters + 3, lines);
-        }
-        if (won) {
-            atomicAdd(counters + 6, won);
-            atomicAdd(counters + 7, win);
         }
         __threadfence();
         if (atomicAdd(counters + 4, 1u) + 1u != gridDim.x)
@@ -630,15 +588,13 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
         on = __hip_atomic_load(counters + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         in = __hip_atomic_load(counters + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lines = __hip_atomic_load(counters + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        won = __hip_atomic_load(counters + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        win = __hip_atomic_load(counters + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!host_words)
         return;
     uint4 *out = reinterpret_cast<uint4 *>(host_words);
     const uint4 *stamps = reinterpret_cast<const uint4 *>(counters + STAMP_WORD);
     out[0] = make_uint4(tile_ptr[g.p - 1], (uint32_t)offset_ptr[g.p], on, in);
-    out[1] = make_uint4(counters[2], lines, won, win);
+    out[1] = make_uint4(counters[2], lines, 0u, 0u);
     out[2] = stamps[0]; // phase stamps 0, 1 (64-bit each)
     out[3] = stamps[1]; // phase stamps 2, 3
 }
@@ -915,20 +871,19 @@ hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int valu
         return hipSuccess;
     if (export_only) {
         hipLaunchKernelGGL(k_stats_export, dim3(1), dim3(1024), 0, s, g, d.tile_ptr, d.tile_hdr, d.offset_ptr, d.counters,
-                           host_words, 1, (const int32_t *)nullptr);
+                           host_words, 1);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(k_tile_tables, dim3(div_up(g.p, FMT_WAVES_PER_BLOCK)), dim3(FMT_BLOCK), 0, s, g, d.row_ptr,
                        d.tile_ptr, d.col, reinterpret_cast<uint4 *>(d.carry_meta), d.tile_hdr, d.counters,
-                       xwin_elems(value_size), value_size == 8 ? 4 : 5, WALK_XWIN_BYTES / value_size, d.xwin_base,
-                       d.xwin_cover);
+                       xwin_elems(value_size), value_size == 8 ? 4 : 5);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
     int blocks = div_up(g.p, 1024 * 16);
     blocks = blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks);
     hipLaunchKernelGGL(k_stats_export, dim3(blocks), dim3(1024), 0, s, g, d.tile_ptr, d.tile_hdr, d.offset_ptr,
-                       d.counters, host_words, 0, (const int32_t *)d.xwin_cover);
+                       d.counters, host_words, 0);
     return hipGetLastError();
 }
 

@@ -91,16 +91,7 @@ struct DeviceArrays {
     int cold_total;
     // CSR5HIP_OPT_NARROW_VALUES: the hot child's values (tile order, like val) as fp32 -- every one of them exactly; else nullptr
     const float *val32;
-    // range-walking tile kernel on the plain format (csr5_walk.hip): tiles 0 .. p-2 dealt to walk_ranges contiguous ranges
-    int walk_ranges;           // 0 = tables not built
-    uint32_t *walk_row;        // [walk_ranges + 1] first row of every range | WALK_EXACT; the last entry = the CSR tail
-    uint32_t *walk_meta;       // [walk_ranges + 1] x uint4: arrival protocol of the ranges (layout of carry_meta)
-    void *walk_lead;           // [walk_ranges + 1] of vT: parked leading partials
-    void *walk_acc;            // [walk_ranges + 1] of vT: parked closing partials / exchange words, all zero between launches
-    uint32_t *walk_cnt;        // [walk_ranges + 1] arrival counters, all zero between launches
-    int32_t *xwin_base;        // [p] the walking kernel's x-window of every tile (first column, -1 = none); nullptr = not built
-    int32_t *xwin_cover;       // [p] non-zeros of the tile inside that window
-    // narrow column codes of the x-window kernel (csr5_spmv.hip C16): every tile 0 .. p-2 spans fewer than 65 536 columns
+    // narrow column codes of the x-window kernel (csr5_spmv.hip C16): every tile 0 .. p-2 spans fewer than 32 768 columns
     const uint32_t *col16;     // [(p-1) * T / 2] two 16-bit codes per word: elements (2d, lane) | (2d+1, lane) << 16 of tile t at
                                // t * T/2 + d * 64 + lane, code = column - base16[t]; nullptr = not built
     const int32_t *base16;     // [p] smallest column of every tile
@@ -119,7 +110,7 @@ hipError_t launch_transpose(const Geometry &g, const DeviceArrays &d, int value_
 hipError_t launch_transpose_values(const Geometry &g, const DeviceArrays &d, int value_type, hipStream_t s);
 hipError_t launch_tile_tables(const Geometry &g, const DeviceArrays &d, int value_size, uint32_t *host_words, bool export_only,
                               hipStream_t s);
-// narrow column codes: codes + per-tile base from the tile-ordered column_index; *wide_tiles += tiles that span >= 65 536 columns
+// narrow column codes: codes + per-tile base from the tile-ordered column_index; *wide_tiles += tiles that span >= 32 768 columns
 hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col16, int32_t *base16, uint32_t *wide_tiles,
                         hipStream_t s);
 constexpr int COL16_SPAN = 32768; // columns a tile may span for the narrow codes: 15 bits of column, bit 15 = row-start flag
@@ -168,9 +159,6 @@ struct SpmvOptions {
     int long_runs;   // resolved: the matrix has rows spanning > RUN_SERIAL_MAX tiles (fused mode adds k_calibrate)
     int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_range + k_range_finish
     int col16;       // resolved: 1 = the x-window kernel streams 16-bit column codes (2 bytes per non-zero less)
-    int walk;        // resolved: 1 = the range-walking pipelined kernel (csr5_walk.hip) instead of one tile per wavefront
-    int walk_long_runs; // resolved: some row spans > RUN_SERIAL_MAX ranges (the walking kernel adds k_calibrate)
-    int walk_x_window;  // resolved: the walking kernel stages its (larger, rarely restaged) slice of x in LDS
 };
 // deferred carries, auto rule (measured break-evens, scripts/experiments/round5/defer_ab.py): what deferral saves grows with the
 // number of tiles -- per tile the two scattered spill loads (sigma cache lines each) and, where rows are too long for short-spill
@@ -179,17 +167,6 @@ constexpr int DEFER_AUTO_LONG_ROW = 128;          // average non-zeros per row f
 constexpr int DEFER_AUTO_MIN_TILES_LONG = 3000;   // ... and deferral pays from this many tiles on (nd24k-like: 3 741 tiles -2.4 us)
 constexpr int DEFER_AUTO_MIN_TILE_SIGMA = 500000; // shorter rows: from tiles x sigma >= this (27 per row, sigma 16: loses 2 us at 21 k
                                                   // tiles, wins 8 at 53 k; 81 per row even at 24 k; R-MAT 20 at 16 k would win 5 %)
-#ifndef CSR5_WALK_XWIN_BYTES
-#define CSR5_WALK_XWIN_BYTES 16384
-#endif
-#ifndef CSR5_WALK_WAVES_PER_CU
-#define CSR5_WALK_WAVES_PER_CU 8
-#endif
-constexpr int WALK_XWIN_BYTES = CSR5_WALK_XWIN_BYTES;      // the walking kernel's slice of x in LDS per wavefront: 4 096 fp32 / 2 048 fp64 columns
-constexpr int WALK_MAX_SIGMA = 16;          // one descriptor packet per lane, two register sets of sigma elements
-constexpr int WALK_MAX_RANGES = 16384;      // upper bound of CSR5HIP_OPT_WALK_RANGES (k_walk_tables: one workgroup)
-constexpr int WALK_DEFAULT_WAVES_PER_CU = CSR5_WALK_WAVES_PER_CU; // default number of ranges = 8 per CU (fewer when their LDS does not fit)
-constexpr int WALK_AUTO_MIN_TILES_PER_RANGE = 4; // auto: the walking kernel runs when every range gets at least this many tiles
 constexpr int HOT_LDS_BYTES = 128 * 1024;  // upper bound of the LDS table of hot x entries per workgroup (k_spmv_range)
 constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_range
 // Wavefronts of the persistent workgroup (one workgroup per CU).  The kernel is bound by the L1's outstanding requests,
@@ -226,17 +203,6 @@ struct HotParams {
 constexpr int hot_child_sigma(int value_size) { return HOT_WAVE_LDS / (OMEGA * value_size); }
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s);
-// csr5_walk.hip: range-walking pipelined kernel on the plain format arrays
-bool walk_supported(const Geometry &g, int value_size);
-int walk_wave_lds_bytes(int sigma, int value_size, int x_window);
-hipError_t launch_walk_tables(const Geometry &g, const DeviceArrays &d, uint32_t *long_runs_out, hipStream_t s);
-hipError_t launch_spmv_walk_f64(const Geometry &g, const DeviceArrays &d, const void *x, void *y, const SpmvOptions &opt,
-                                hipStream_t s);
-hipError_t launch_spmv_walk_f32(const Geometry &g, const DeviceArrays &d, const void *x, void *y, const SpmvOptions &opt,
-                                hipStream_t s);
-// csr5_spmv.hip: k_calibrate on `count` parties whose runs longer than RUN_SERIAL_MAX only parked their partials
-hipError_t launch_calibrate_long(int count, int m, int value_type, const uint32_t *party_row, const uint32_t *meta,
-                                 const void *parked_lead, const void *parked_closing, void *y, hipStream_t s);
 // csr5_hot.hip: the slab child's SpMV when its column words are hot-encoded (persistent range kernel + finish)
 hipError_t launch_spmv_hot(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, void *y,
                            const SpmvOptions &opt, hipStream_t s);

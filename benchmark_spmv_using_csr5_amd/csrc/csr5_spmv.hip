@@ -689,30 +689,11 @@ hipError_t launch_spmv_f32(const Geometry &g, const DeviceArrays &d, const void 
 hipError_t launch_spmv_f32(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
                            const SpmvOptions &opt, hipStream_t s);
 
-hipError_t launch_calibrate_long(int count, int m, int value_type, const uint32_t *party_row, const uint32_t *meta,
-                                 const void *parked_lead, const void *parked_closing, void *y, hipStream_t s)
-{
-    Geometry g{};
-    g.p = count;
-    g.m = m;
-    if (value_type == CSR5HIP_F64)
-        hipLaunchKernelGGL((k_calibrate<double, true>), dim3((count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, g, party_row,
-                           reinterpret_cast<const uint4 *>(meta), (const double *)parked_lead, (const double *)parked_closing,
-                           (double *)y);
-    else
-        hipLaunchKernelGGL((k_calibrate<float, true>), dim3((count + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, g, party_row,
-                           reinterpret_cast<const uint4 *>(meta), (const float *)parked_lead, (const float *)parked_closing,
-                           (float *)y);
-    return hipGetLastError();
-}
-
 hipError_t launch_spmv(const Geometry &g, const DeviceArrays &d, int value_type, const void *x,
                        void *y, const SpmvOptions &opt, hipStream_t s)
 {
     if (g.p <= 0)
         return hipSuccess;
-    if (opt.walk && opt.mode == 1 && !opt.hot)
-        return value_type == CSR5HIP_F64 ? launch_spmv_walk_f64(g, d, x, y, opt, s) : launch_spmv_walk_f32(g, d, x, y, opt, s);
     if (opt.hot) // column words are hot-encoded: only the persistent range kernel understands them (csr5_hot.hip)
         return opt.mode == 1 ? launch_spmv_hot(g, d, value_type, x, y, opt, s) : hipErrorInvalidValue;
     return value_type == CSR5HIP_F64 ? launch_spmv_f64(g, d, x, y, opt, s) : launch_spmv_f32(g, d, x, y, opt, s);

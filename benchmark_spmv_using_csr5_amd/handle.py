@@ -162,18 +162,9 @@ class anonymouslibHandle:
         return self.setOption(_capi.OPT_DEFER_CARRIES, int(value))
 
     def setNarrowColumns(self, value: int) -> int:
-        """x-window kernel: 1 = auto (default) stream 16-bit column codes when every tile spans < 65 536 columns, 0 = off
+        """x-window kernel: 1 = auto (default) stream 16-bit column codes (15 bits of column + the row-start flag) when every tile spans < 32 768 columns, 0 = off
         (csr5hip.h CSR5HIP_OPT_NARROW_COLUMNS)"""
         return self.setOption(_capi.OPT_NARROW_COLUMNS, int(value))
-
-    def setTileWalk(self, value: int) -> int:
-        """plain path: 0 = one tile per wavefront, 1 = auto (default), 2 = force the range-walking pipelined kernel
-        (csr5hip.h CSR5HIP_OPT_TILE_WALK)"""
-        return self.setOption(_capi.OPT_TILE_WALK, int(value))
-
-    def setWalkRanges(self, value: int) -> int:
-        """tile ranges (= wavefronts) of the walking kernel, 0 = default (csr5hip.h CSR5HIP_OPT_WALK_RANGES)"""
-        return self.setOption(_capi.OPT_WALK_RANGES, int(value))
 
     def setZeroEmptyRows(self, value: int) -> int:
         """1 = spmv() also stores 0 into rows without non-zeros (solver coupling); 0 = reference behaviour"""

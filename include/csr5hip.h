@@ -108,20 +108,8 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       8-byte one the roofline's algorithmic bytes count.  csr5hip_info.slab_values_narrowed
                                       says what happened.  +4 bytes per non-zero of device memory. */
 
-#define CSR5HIP_OPT_TILE_WALK 13  /* fused mode, plain (non-slab) path: the range-walking, software-pipelined tile kernel -- one wavefront
-                                      owns a contiguous range of tiles, the next tile's streams are requested before this tile's
-                                      gathers, the open row stays in registers, one leading partial per RANGE goes through the
-                                      arrival protocol -- instead of one tile per wavefront.  Same format arrays, same results up to
-                                      the association of cut rows' partial sums (bit-reproducible run to run either way).
-                                      0 = off (default), 1 = auto (on when every range gets >= 4 tiles and sigma is in 4..16), 2 = force
-                                      (still needs sigma in 4..16).  Set it BEFORE asCSR5(): the kernel's tables are built by the
-                                      conversion only when the option is non-zero then (turning it on afterwards has no effect
-                                      until the next conversion).  Off by default because on MI355X it measured 5-15 % SLOWER
-                                      than the one-tile kernel on every BASELINE stand-in (profiles/r05_walk.md): with ~2 500
-                                      issue cycles of per-tile work a wavefront is instruction-bound, and the 2-3 wavefronts per
-                                      SIMD its registers and LDS leave room for hide less of that than the one-tile kernel's 7. */
-#define CSR5HIP_OPT_WALK_RANGES 14 /* number of tile ranges (= wavefronts) of the walking kernel: 0 = default (2 048 = 8 per CU),
-                                      else 1 .. 16 384; never more than p - 1 */
+/* (option numbers 13 and 14 belonged to the range-walking kernel of round 5, which measured slower on every shape and was taken
+   out of the product: scripts/experiments/round5/walk_kernel/) */
 
 #define CSR5HIP_OPT_NARROW_COLUMNS 15 /* x-window kernel: when EVERY tile 0 .. p-2 spans fewer than 32 768 columns (banded / blocked
                                       matrices; any matrix with n <= 32 768) the kernel streams 16-bit column codes -- 15 bits of column
@@ -183,10 +171,6 @@ typedef struct csr5hip_info {
     int slab_values_narrowed;      /* 1 = CSR5HIP_OPT_NARROW_VALUES took effect: the slab kernel streams fp32 values       */
     int carries_deferred;          /* 1 = cut rows are finished by a second small launch (CSR5HIP_OPT_DEFER_CARRIES)             */
     int narrow_columns;            /* 1 = the x-window kernel streams 16-bit column codes (CSR5HIP_OPT_NARROW_COLUMNS)            */
-    int tile_walk;                 /* 1 = spmv() launches the range-walking pipelined kernel (CSR5HIP_OPT_TILE_WALK)           */
-    int walk_ranges;               /* tile ranges (wavefronts) of that kernel; 0 = its tables were not built                   */
-    int walk_x_window;             /* 1 = it gathers through its 16-KB LDS slice of x (rarely restaged: 4 096 fp32 / 2 048 fp64 columns) */
-    int walk_x_window_cover_pct;   /* share of the non-zeros (tiles 0..p-2) inside their tile's 16-KB window                    */
 } csr5hip_info;
 
 /* anonymouslibHandle(m, n) -- anonymouslib_cuda.h:15.  Uses the current HIP device. */

@@ -14,8 +14,6 @@ for f in csr5_format csr5_capi csr5_ingest csr5_slab csr5_multi csr5_hot; do
 done
 /opt/rocm/bin/hipcc $HIPFLAGS -DCSR5_SPMV_ONLY_F64 -c $src/csr5_spmv.hip -o $out/csr5_spmv_f64.o & pids+=($!)
 /opt/rocm/bin/hipcc $HIPFLAGS -DCSR5_SPMV_ONLY_F32 -c $src/csr5_spmv.hip -o $out/csr5_spmv_f32.o & pids+=($!)
-/opt/rocm/bin/hipcc $HIPFLAGS -DCSR5_WALK_ONLY_F64 -c $src/csr5_walk.hip -o $out/csr5_walk_f64.o & pids+=($!)
-/opt/rocm/bin/hipcc $HIPFLAGS -DCSR5_WALK_ONLY_F32 -c $src/csr5_walk.hip -o $out/csr5_walk_f32.o & pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o $root/scripts/probes/libcsr5hip_$name.so $out/*.o -ldl
 ls -la $root/scripts/probes/libcsr5hip_$name.so

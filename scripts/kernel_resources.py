@@ -27,7 +27,6 @@ def main():
     args = ap.parse_args()
     rows = []
     for src, defs in (("csr5_spmv.hip", ["-DCSR5_SPMV_ONLY_F64"]), ("csr5_spmv.hip", ["-DCSR5_SPMV_ONLY_F32"]),
-                      ("csr5_walk.hip", ["-DCSR5_WALK_ONLY_F64"]), ("csr5_walk.hip", ["-DCSR5_WALK_ONLY_F32"]),
                       ("csr5_slab.hip", []), ("csr5_hot.hip", [])):
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
                f"-I{ROOT}/include", "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src),
