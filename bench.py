@@ -103,11 +103,12 @@ def parse_args():
     ap.add_argument("--slabs", default="auto", help="column slabs: auto (default), 0 = off, 2..64 = that many")
     ap.add_argument("--slab-shift", type=int, default=None)
     ap.add_argument("--slab-hot", default="auto", choices=["auto", "off", "force"], help="LDS hot table of the slab kernel")
-    ap.add_argument("--x-snapshot", type=int, default=0, choices=[0, 1],
+    ap.add_argument("--x-snapshot", type=int, default=None, choices=[0, 1],
                     help="hot-table slab kernel: 0 (default = the LIBRARY default) = its permuted copy of x is re-taken by every "
                          "spmv (x is read live, as the reference reads it); 1 = once per setX, which the reference CLI's protocol "
                          "allows (setX once, NUM_RUN spmv calls on the same x: CSR5_cuda/main.cu:63-99) -- reported as the side "
-                         "figure roofline.x_snapshot_once_per_setX")
+                         "figure roofline.x_snapshot_once_per_setX.  N > 1 defaults to 1: every rank's x is the replica the ONE "
+                         "broadcast filled, which nothing writes afterwards -- the multi-GPU contract of csr5hip_multi_set_x")
     ap.add_argument("--defer-carries", default="auto", choices=["auto", "off", "force"],
                     help="plain path: cut rows finished by a second small launch instead of arrival atomics (CSR5HIP_OPT_DEFER_CARRIES)")
     ap.add_argument("--zero-empty", type=int, default=0, choices=[0, 1],
@@ -129,6 +130,8 @@ def parse_args():
     ap.add_argument("--no-side-figures", action="store_true",
                     help="skip roofline.x_live / roofline.narrowed_values (profiling runs: only the headline protocol's kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-n1-leg", action="store_true",
+                    help="N > 1: skip rank 0's whole-matrix leg (the N = 1 step under the same x protocol + CSR5_avx2 on the whole matrix)")
     return ap.parse_args()
 
 
@@ -138,6 +141,7 @@ def parse_args():
 # SuiteSparse files the BASELINE configs name (none is obtainable offline): when $CSR5_MTX_DIR holds them they are used
 # instead of the synthetic stand-ins, through the native Matrix Market ingest (values replaced by rand()%10 integers as
 # the reference CLI does, CSR5_avx2/main.cpp:283-295)
+SUB_CONFIGS = ("scircuit", "webbase", "nd24k", "nd24k_f64")  # the other single-GPU BASELINE configs (+ nd24k-like in fp64)
 REAL_FILES = {"scircuit": "scircuit.mtx", "webbase": "webbase-1M.mtx", "nd24k": "nd24k.mtx"}
 
 
@@ -240,7 +244,7 @@ class Problem:
         _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
         if getattr(args, "defer_carries", "auto") != "auto":  # (auto = the library's default)
             _ck(A.setDeferCarries({"off": 0, "force": 2}[args.defer_carries]), "setDeferCarries")
-        rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 0)))
+        rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 0) or 0))
         if rc != 0 and not os.environ.get("CSR5HIP_LIB"):  # (an older library build under A/B test does not know the option)
             _ck(rc, "setXSnapshot")
         if getattr(args, "zero_empty", 0):
@@ -267,6 +271,9 @@ class Problem:
             samples.append((time.perf_counter() - t0) * 1e3)
         self.convert_ms = sorted(samples)[len(samples) // 2]
         self.info = A.info()
+        if self.info.x_snapshot and hasattr(A, "snapshotX"):
+            _ck(A.snapshotX(), "snapshotX")  # the permuted copy of x: once, here (behind the broadcast at N > 1), never inside a step
+            torch.cuda.synchronize()
 
     def close(self):
         self.A.destroy()
@@ -448,6 +455,8 @@ def sub_config(name, args, dev):
     a = copy.copy(args)
     a.sigma, a.slabs, a.slab_shift, a.values, a.slab_hot = "-1", "auto", None, "int", "auto"
     dtype_name = "f32" if name == "nd24k" else "f64"
+    if name == "nd24k_f64":  # the fp64 sibling of BASELINE config 5 (same stand-in, 8-byte values)
+        name = "nd24k"
     np_dtype = np.float32 if dtype_name == "f32" else np.float64
     real = real_file_for(name)
     ingest_ms = None
@@ -530,6 +539,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    # long host-side waits (rank 0's CPU baseline and whole-matrix leg) go through a gloo group: an RCCL barrier would keep the
+    # other GPUs spinning on rank 0's memory while rank 0 times its own GPU
+    host_group = dist.new_group(backend="gloo") if (dist is not None and not share_gpu) else None
 
     is_rmat = args.workload.startswith("rmat")
     big = is_rmat and int(args.workload[4:] or 24) >= 22
@@ -538,6 +550,8 @@ def main():
     scaling = args.scaling or ("strong" if is_rmat else "weak")
     dtype_name = args.dtype or ("f32" if args.workload == "nd24k" else "f64")
     np_dtype = np.float64 if dtype_name == "f64" else np.float32
+    if args.x_snapshot is None:
+        args.x_snapshot = 1 if world > 1 else 0
 
     ingest_ms = None
     data = "synthetic"
@@ -577,8 +591,33 @@ def main():
     # correctness run (kept for the cpu_baseline comparison), then the timed region
     _ck(prob.A.spmv(1.0, prob.yd), "spmv")
     torch.cuda.synchronize()
-    y_first = prob.yd.cpu().numpy() if rank == 0 else None
+    y_first = prob.yd.cpu().numpy() if (rank == 0 or world > 1) else None
     wall_s, ev_ms = timed(prob, steps, warmup, args.launch, dist)
+
+    # N > 1: EVERY rank checks its own row block against the reference's compiled CSR5_avx2 (oracle/_ref; our C port of it
+    # where that binary is absent) on the same block and the same x -- exact on the CLI's integer data -- all ranks at once,
+    # each on its share of the host cores; the worst error of any rank goes into the line (all_reduce MAX)
+    host = None
+    check = None
+    if world > 1 and not args.no_cpu_baseline:
+        host = host_copy(prob)
+        threads = max(1, min(32, (os.cpu_count() or 8) // world))
+        try:
+            err, kind = block_error_vs_cpu(host, y_first, threads)
+        except Exception as e:  # (a rank without the checker must not hang the others in the collective below)
+            print(f"bench.py: rank {rank}: CPU check failed: {e!r}", file=sys.stderr, flush=True)
+            err, kind = float("inf"), "error"
+        ck_t = torch.tensor([err, {"reference": 0.0, "port": 1.0}.get(kind, 2.0)], dtype=torch.float64,
+                            device="cpu" if share_gpu else dev)
+        ck_rows = [torch.zeros_like(ck_t) for _ in range(world)]
+        dist.all_gather(ck_rows, ck_t)
+        dist.all_reduce(ck_t, op=dist.ReduceOp.MAX)
+        check = {"max_rel_err_gpu_vs_cpu": float(ck_t[0]),
+                 "checker": {0.0: "reference", 1.0: "port"}.get(float(ck_t[1]), "error"),
+                 "per_rank_max_rel_err": [float(r[0]) for r in ck_rows], "threads_per_rank": threads,
+                 "note": "every rank's y (first SpMV) against CSR5_avx2 on that rank's own row block and the same x; "
+                         "integer data: exact (0.0) expected; all ranks checked at once, then all_reduce(MAX)"}
+        dist.barrier(group=host_group)  # rank 0 times its CPU baseline only after every rank's check has left the host cores
 
     stats = torch.tensor([wall_s, ev_ms, float(prob.nnz), float(prob.b_alg)], dtype=torch.float64,
                          device="cpu" if share_gpu else dev)
@@ -667,6 +706,11 @@ def main():
                 "x replicated by one RCCL broadcast, no per-step collective")
         cfg = {"workload": f"{label}: CSR->CSR5 (omega=64, sigma={info.sigma}) + CSR5 SpMV, {part}",
                **config_dict(prob, args, ingest_ms)}
+        if world > 1:
+            cfg["x_protocol"] = ("x is generated on rank 0 and replicated by ONE broadcast before the loop; every rank's kernel-side "
+                                 "(permuted) copy of it is taken once, right behind the broadcast (CSR5HIP_OPT_X_SNAPSHOT = 1, the "
+                                 "contract of csr5hip_multi_set_x: a replica cannot change under the handle), not inside the steps"
+                                 if info.x_snapshot else "x read live by every step (--x-snapshot 0)")
         out = {
             "metric": f"{'fp64' if dtype_name == 'f64' else 'fp32'} SpMV GFLOPS",
             "value": round(gflops, 3),
@@ -705,17 +749,39 @@ def main():
                            "roofline_frac": round(r[5] / (r[7] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if r[7] > 0 else None}
                           for r in per_rank],
             }
-        if world == 1 and not args.no_cpu_baseline:
+        roof.update(conversion_roofline(prob, ev_per_step))
+        if "x_snapshot_once_per_setX" in roof:
+            roof["x_snapshot_frac"] = roof["x_snapshot_once_per_setX"]["frac"]
+        if check is not None:
+            out["multi_gpu"].update(check)
+        if not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(prob, y_first, args.cpu_seconds)
+                if world == 1:
+                    out["cpu_baseline"] = cpu_baseline(prob, y_first, args.cpu_seconds)
+                else:  # the other ranks wait in the barrier below: the host cores are rank 0's
+                    out["cpu_baseline"] = cpu_baseline(prob, y_first, args.cpu_seconds / 2, host=host,
+                                                       what=f"rank 0's row block of {world} ({prob.nnz} of {int(total_nnz)} nnz)")
+                    out["cpu_baseline"]["scope"] = "rank 0's row block; the whole matrix: cpu_baseline.whole_matrix"
             except Exception as e:  # the baseline leg must never cost the headline line
                 out["cpu_baseline"] = {"error": repr(e)}
+        if world == 1 and "x_snapshot_once_per_setX" in roof:
+            # the N = 1 point of the curve under the protocol the N > 1 points run (x captured once per setX / broadcast)
+            out["value_multi_gpu_protocol"] = round(2.0 * prob.nnz / (roof["x_snapshot_once_per_setX"]["launch_us"] * 1e-6) / 1e9, 3)
         prob.close()
         del prob
+        host = None
         torch.cuda.empty_cache()
+        if world > 1 and is_rmat and scaling == "strong" and not args.no_n1_leg:
+            # rank 0 alone (the other ranks wait): the WHOLE matrix on this one GPU under the same protocol -> the speed-up of
+            # this N-GPU line over N = 1 with no protocol difference booked as scaling; and CSR5_avx2 on the whole matrix
+            try:
+                out["multi_gpu"].update(whole_matrix_leg(args, dev, label, dtype_name, x_dev, steps, warmup, ev_per_step,
+                                                         out.get("cpu_baseline")))
+            except Exception as e:
+                out["multi_gpu"]["n1_same_protocol"] = {"error": repr(e)}
         if world == 1 and not args.no_sub_configs and not real and args.workload == "rmat24":
             subs = []
-            for name in ("scircuit", "webbase", "nd24k"):
+            for name in SUB_CONFIGS:
                 try:
                     subs.append(sub_config(name, args, dev))
                 except Exception as e:  # a sub-config must never cost the headline line
@@ -723,7 +789,7 @@ def main():
             out["configs"] = subs
             # the same figures, compact, where the driver's record keeps them (it drops top-level keys it does not know)
             summary = {}
-            for name, sc in zip(("scircuit", "webbase", "nd24k"), subs):
+            for name, sc in zip(SUB_CONFIGS, subs):
                 r = sc.get("roofline") or {}
                 w = r.get("warm") or {}
                 summary[name] = ({"error": sc["error"]} if "error" in sc else
@@ -733,27 +799,114 @@ def main():
                                   "kernel": r.get("kernel"), "sigma": sc["config"]["sigma"], "column_slabs": sc["config"]["column_slabs"],
                                   "data": sc.get("data")})
             out["roofline"]["configs"] = summary
+            # ... and FLAT, as scalar keys of `roofline` (the driver's parsed record keeps scalars only)
+            for name, e in summary.items():
+                for src, dst in (("cold_frac", "cold_frac"), ("warm_frac", "warm_frac"), ("traffic_ratio", "traffic_ratio"),
+                                 ("cold_us", "cold_us")):
+                    if e.get(src) is not None:
+                        out["roofline"][f"{name}_{dst}"] = e[src]
         print(json.dumps(out), flush=True)
     else:
         prob.close()
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=host_group)
         dist.destroy_process_group()
 
 
-def cpu_baseline(prob, y_gpu, budget_s: float) -> dict:
+def conversion_roofline(prob, spmv_ms: float) -> dict:
+    """The conversion is on the hot path (north_star): its own bytes over its own time, as flat scalar keys of `roofline`.
+    B_conv = the in-place tile transpose reads and writes column_index and value once each (2 * (4 + sizeof vT) per non-zero,
+    format_cuda.h:525-744) + row_ptr read once + the three descriptor arrays written once.  `conversion_ms` is the whole
+    asCSR5() call -- host-timed median, kernel-side tables and (R-MAT) the column-slab structure included;
+    `conversion_format_ms` is the three format phases alone, from the kernels' wall-clock stamps."""
+    i = prob.info
+    b_conv = 2 * (4 + prob.vsize) * prob.nnz + 4 * (prob.m + 1) + 4 * (i.p + 1) * 2 + 4 * i.p * 64 * max(i.num_packet, 1)
+    fmt_ms = i.t_tile_ptr_ms + i.t_tile_desc_ms + i.t_transpose_ms
+    d = {"conversion_ms": round(prob.convert_ms, 4), "conversion_in_spmvs": round(prob.convert_ms / spmv_ms, 2),
+         "conversion_bytes": int(b_conv),
+         "conversion_frac": round(b_conv / (prob.convert_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if fmt_ms > 0:
+        d["conversion_format_ms"] = round(fmt_ms, 4)
+        d["conversion_format_frac"] = round(b_conv / (fmt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    if i.column_slabs:
+        d["conversion_slab_structure_ms"] = round(i.t_slab_ms, 4)
+    return d
+
+
+def host_copy(prob):
+    """(m, n, nnz, row_ptr, col, val64, x64) on the host, in plain CSR order (the handle's in-place transpose undone)."""
+    import torch
+    _ck(prob.A.asCSR(), "asCSR")
+    torch.cuda.synchronize()
+    return (prob.m, prob.n, prob.nnz, prob.rp.cpu().numpy(), prob.ci.cpu().numpy(),
+            prob.va.cpu().numpy().astype(np.float64), prob.xd.cpu().numpy().astype(np.float64))
+
+
+def max_rel_err(y_gpu, y_cpu, row_ptr) -> float:
+    nonempty = np.diff(row_ptr) > 0
+    if not nonempty.any():
+        return 0.0
+    denom = np.maximum(np.abs(y_cpu[nonempty]), 1e-300)
+    return float(np.max(np.abs(y_gpu[nonempty].astype(np.float64) - y_cpu[nonempty]) / denom))
+
+
+def block_error_vs_cpu(host, y_gpu, threads: int):
+    """One CSR5_avx2 SpMV (oracle/_ref; our C port where it is absent) on the rank's block -> (max relative error, checker)."""
+    from oracle.csr5_oracle import Oracle, Reference
+    m, n, nnz, row_ptr, col, val64, x64 = host
+    if Reference.available():
+        ref = Reference()
+        ref.avx2_set_threads(max(1, min(threads, ref.avx2_threads())))
+        y, _, _ = ref.avx2_spmv(m, n, row_ptr, col, val64, x64, y0=np.zeros(m))
+        return max_rel_err(y_gpu, y, row_ptr), "reference"
+    orc = Oracle()
+    y = orc.spmv(orc.convert(4, 16, m, row_ptr, col, val64), row_ptr, x64)
+    return max_rel_err(y_gpu, y, row_ptr), "port"
+
+
+def whole_matrix_leg(args, dev, label, dtype_name, x_dev, steps, warmup, job_ms_per_step, block_baseline) -> dict:
+    """N > 1, rank 0 only, the other ranks idle: the same global matrix WHOLE on this one GPU under the job's x protocol
+    (its N = 1 step time -> speedup_vs_n1_same_protocol) and the reference's CSR5_avx2 on the whole matrix on the host."""
+    import copy
+    import torch
+    from benchmark_spmv_using_csr5_amd import matrices as M
+    a = copy.copy(args)
+    sc = int(args.workload[4:] or 24)
+    mat = M.rmat_device_shard(sc, 16, args.seed, 0, 1, dev)
+    prob = Problem(mat, label, dtype_name, a, dev, args.seed + 13, x_dev=x_dev)
+    _ck(prob.A.spmv(1.0, prob.yd), "spmv")
+    torch.cuda.synchronize()
+    y1 = prob.yd.cpu().numpy()
+    k = max(5, min(steps, 50))
+    wall_s, ev_ms = timed(prob, k, min(warmup, 5), args.launch, None)
+    n1_ms = ev_ms / k
+    out = {"n1_same_protocol": {"ms_per_step": round(n1_ms, 6), "steps": k, "gflops": round(2.0 * prob.nnz / (n1_ms * 1e-3) / 1e9, 3),
+                                "roofline_frac": round(prob.b_alg / (n1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "column_slabs": prob.info.column_slabs, "slab_hot": int(prob.info.slab_hot),
+                                "x_snapshot": int(prob.info.x_snapshot),
+                                "note": "the whole matrix on rank 0's GPU alone, same x, same x protocol, same options, timed in this run "
+                                        "while the other ranks wait"},
+           "speedup_vs_n1_same_protocol": round(n1_ms / job_ms_per_step, 3)}
+    if not args.no_cpu_baseline:
+        try:
+            whole = cpu_baseline(prob, y1, args.cpu_seconds / 2, what=f"the WHOLE matrix ({prob.nnz} nnz)")
+            if isinstance(block_baseline, dict) and "error" not in block_baseline:
+                block_baseline["whole_matrix"] = whole
+                block_baseline["whole_matrix_value"] = whole["value"]
+            else:
+                out["cpu_baseline_whole_matrix"] = whole
+        except Exception as e:
+            out["cpu_baseline_whole_matrix"] = {"error": repr(e)}
+    prob.close()
+    return out
+
+
+def cpu_baseline(prob, y_gpu, budget_s: float, host=None, what=None) -> dict:
     """CSR5 at omega=4 / sigma=16, fp64, OpenMP on this node's host cores, same matrix and vectors (copied back
     from the device).  Prefers the reference's own CSR5_avx2 build (oracle/_ref); falls back to our C port of it."""
-    import torch
     from oracle.csr5_oracle import Oracle, Reference
 
-    m, n, nnz = prob.m, prob.n, prob.nnz
-    _ck(prob.A.asCSR(), "asCSR")  # undo the handle's in-place transpose: plain CSR order for the CPU side
-    torch.cuda.synchronize()
-    row_ptr = prob.rp.cpu().numpy()
-    col = prob.ci.cpu().numpy()
-    val64 = prob.va.cpu().numpy().astype(np.float64)
-    x64 = prob.xd.cpu().numpy().astype(np.float64)
+    m, n, nnz, row_ptr, col, val64, x64 = host if host is not None else host_copy(prob)
     big = nnz > 50_000_000
     if Reference.available():
         ref = Reference()
@@ -792,15 +945,13 @@ def cpu_baseline(prob, y_gpu, budget_s: float) -> dict:
         conv_ms = None
         tried = {cores: round(ms, 4)}
         kind = "port"
-    nonempty = np.diff(row_ptr) > 0
-    denom = np.maximum(np.abs(y[nonempty]), 1e-300)
-    max_rel = float(np.max(np.abs(y_gpu[nonempty].astype(np.float64) - y[nonempty]) / denom)) if nonempty.any() else 0.0
+    max_rel = max_rel_err(y_gpu, y, row_ptr)
     return {
         "value": round(2.0 * nnz / (ms * 1e-3) / 1e9, 3),
         "unit": "GFLOPS",
         "cores": cores,
         "kind": kind,
-        "sample": f"same matrix ({nnz} nnz), CSR5_avx2 omega=4 sigma=16 fp64 OpenMP, {runs} timed SpMV after warm-up",
+        "sample": f"{what or f'same matrix ({nnz} nnz)'}, CSR5_avx2 omega=4 sigma=16 fp64 OpenMP, {runs} timed SpMV after warm-up",
         # short probes per thread count (ms per SpMV).  They can be several times faster than the long timed run:
         # the box's container throttles sustained multi-thread CPU use, short bursts escape it.  A reported
         # baseline, not a target: the GPU/CPU ratio says nothing about kernel quality, roofline.frac does.

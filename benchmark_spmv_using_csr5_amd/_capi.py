@@ -113,6 +113,7 @@ SYMBOLS = [
     ("csr5hip_spmv", C.c_int, [_H, C.c_double, C.c_void_p]),
     ("csr5hip_spmv_repeat", C.c_int, [_H, C.c_double, C.c_void_p, C.c_int]),
     ("csr5hip_spmv_rotate", C.c_int, [C.POINTER(_H), C.POINTER(C.c_void_p), C.c_int, C.c_double, C.c_int]),
+    ("csr5hip_snapshot_x", C.c_int, [_H]),
     ("csr5hip_destroy", C.c_int, [_H]),
     ("csr5hip_autotune_sigma", C.c_int, [_H, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     ("csr5hip_set_option", C.c_int, [_H, C.c_int, C.c_int]),

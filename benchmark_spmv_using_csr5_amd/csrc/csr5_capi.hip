@@ -1490,6 +1490,16 @@ int csr5hip_spmv(csr5hip_handle h, double alpha, void *d_y)
     return CSR5HIP_SUCCESS;
 }
 
+int csr5hip_snapshot_x(csr5hip_handle h)
+{
+    if (!h)
+        return CSR5HIP_INVALID_ARGUMENT;
+    if (h->format != CSR5HIP_FORMAT_CSR5 || !h->x)
+        return CSR5HIP_SUCCESS; // (nothing to copy yet: the first spmv() after asCSR5 / setX takes it)
+    HIP_TRY(ensure_x_snapshot(h, h->stream));
+    return CSR5HIP_SUCCESS;
+}
+
 int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count)
 {
     if (!h || !d_y || count < 0)

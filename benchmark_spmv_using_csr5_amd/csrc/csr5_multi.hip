@@ -143,8 +143,12 @@ struct csr5hip_multi_s {
     bool distinct = true;     // no device id listed twice
     int broadcast_kind = 0;   // what the last set_x used: 1 = RCCL broadcast, 2 = device-to-device copies
     bool own_replicas = false; // CSR5HIP_MULTI_OPT_OWN_REPLICAS: shards on devices[0] get a replica of x too
+    bool live_x_borrowers = false; // set_option(CSR5HIP_OPT_X_SNAPSHOT, 0): the shards that BORROW the caller's x read it live
     size_t vsize() const { return value_type == CSR5HIP_F64 ? 8 : 4; }
 };
+
+// does shard g read the caller's own vector (it lives on devices[0] and no replica was asked for)?
+static bool borrows_x(const csr5hip_multi_s *mh, int g) { return mh->dev[g] == mh->dev[0] && !mh->own_replicas; }
 
 extern "C" {
 
@@ -270,6 +274,10 @@ int csr5hip_multi_input_csr(csr5hip_multi mh, int nnz, const int32_t *d_row_ptr,
         MRC(csr5hip_create(&mh->h[g], mg, mh->n, mh->value_type));
         MRC(csr5hip_set_stream(mh->h[g], mh->stream[g]));
         MRC(csr5hip_input_csr(mh->h[g], nz, (int32_t *)mh->row_ptr[g], (int32_t *)mh->col[g], mh->val[g]));
+        // the multi handle's x contract: set_x captures x (the replicas are ours; see csr5hip_multi_set_x)
+        MRC(csr5hip_set_option(mh->h[g], CSR5HIP_OPT_X_SNAPSHOT, mh->live_x_borrowers && borrows_x(mh, g) ? 0 : 1));
+        if (mh->x[g]) // (a matrix replaced under an x that is already distributed)
+            MRC(csr5hip_set_x(mh->h[g], mh->x[g]));
     }
     mh->cut[G] = cut[G];
     for (int g = 0; g < G; g++) {
@@ -306,10 +314,16 @@ int csr5hip_multi_set_option(csr5hip_multi mh, int option, int value)
         mh->row_weight = value;
         return CSR5HIP_SUCCESS;
     }
+    if (option == CSR5HIP_OPT_X_SNAPSHOT) {
+        if (value != 0 && value != 1)
+            return CSR5HIP_INVALID_ARGUMENT;
+        mh->live_x_borrowers = value == 0; // a library-owned replica cannot change under the handle: those shards stay at 1
+    }
     for (int g = 0; g < mh->G; g++)
         if (mh->h[g]) {
             MHIP(hipSetDevice(mh->dev[g]));
-            MRC(csr5hip_set_option(mh->h[g], option, value));
+            const int v = option == CSR5HIP_OPT_X_SNAPSHOT && !borrows_x(mh, g) ? 1 : value;
+            MRC(csr5hip_set_option(mh->h[g], option, v));
         }
     return CSR5HIP_SUCCESS;
 }
@@ -324,6 +338,7 @@ int csr5hip_multi_as_csr5(csr5hip_multi mh)
             return CSR5HIP_UNKOWN_FORMAT;
         MHIP(hipSetDevice(mh->dev[g]));
         MRC(csr5hip_as_csr5(mh->h[g]));
+        MRC(csr5hip_snapshot_x(mh->h[g])); // (x distributed before the conversion: the copy is taken now, not by the first spmv)
     }
     MHIP(hipSetDevice(mh->dev[0]));
     return CSR5HIP_SUCCESS;
@@ -420,8 +435,13 @@ int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x)
     }
     for (int g = 0; g < G; g++) {
         MHIP(hipSetDevice(mh->dev[g]));
-        if (mh->h[g])
+        if (mh->h[g]) {
             MRC(csr5hip_set_x(mh->h[g], mh->x[g]));
+            // (own_replicas may have changed what the shard reads: only a shard that borrows the caller's vector may read live)
+            MRC(csr5hip_set_option(mh->h[g], CSR5HIP_OPT_X_SNAPSHOT, mh->live_x_borrowers && borrows_x(mh, g) ? 0 : 1));
+            // the shard's permuted copy of x, ONCE, right behind the broadcast on the shard's stream
+            MRC(csr5hip_snapshot_x(mh->h[g]));
+        }
         MHIP(hipStreamSynchronize(mh->stream[g]));
     }
     MHIP(hipSetDevice(mh->dev[0]));

@@ -93,6 +93,10 @@ class anonymouslibHandle:
     def spmv_repeat(self, alpha, y, count: int) -> int:
         return self._lib.csr5hip_spmv_repeat(self._h, float(alpha), _ptr(y), int(count))
 
+    def snapshotX(self) -> int:
+        """X_SNAPSHOT mode: take the permuted copy of x now, on the handle's stream (csr5hip.h csr5hip_snapshot_x)"""
+        return self._lib.csr5hip_snapshot_x(self._h)
+
     @staticmethod
     def spmv_rotate(handles, ys, count: int) -> int:
         """`count` SpMVs from one hipGraph, the i-th on handles[i % k] into ys[i % k] (cold-cache protocol, csr5hip.h)."""

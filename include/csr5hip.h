@@ -205,6 +205,10 @@ int csr5hip_spmv_repeat(csr5hip_handle h, double alpha, void *d_y, int count);
  * exceeds the 256-MiB Infinity Cache, every SpMV streams its operands from HBM instead of finding them cached from
  * the previous launch (the reference's timed loop, CSR5_cuda/main.cu:96-99, re-reads one matrix). */
 int csr5hip_spmv_rotate(csr5hip_handle *hs, void **d_ys, int k, double alpha, int count);
+/* CSR5HIP_OPT_X_SNAPSHOT = 1 only: take the permuted copy of x NOW, on the handle's stream, instead of in front of the first
+ * spmv() after setX (so that no spmv() of a timed loop carries it).  A no-op for handles without a hot table, in live-x mode,
+ * before asCSR5 / setX, or when the copy is current. */
+int csr5hip_snapshot_x(csr5hip_handle h);
 /* destroy() -- anonymouslib_cuda.h:286-291 (== asCSR) */
 int csr5hip_destroy(csr5hip_handle h);
 
@@ -313,6 +317,11 @@ int csr5hip_load(const char *path, csr5hip_handle *h, csr5hip_csr *arrays);
  * plain nnz balance); every block becomes an ordinary handle on its own device and stream; x is
  * replicated ONCE at set_x time by a single RCCL broadcast over xGMI (librccl is opened lazily; device-to-device
  * copies when it is absent or a device is listed twice); y stays sharded; no per-SpMV collective.
+ * x CONTRACT of the multi handle: set_x CAPTURES x's contents.  A replica is library-owned -- the caller cannot write to
+ * it -- so every shard's kernel-side (permuted) copy of x is taken once, right behind the broadcast on the shard's stream,
+ * not by every spmv() (CSR5HIP_OPT_X_SNAPSHOT = 1 is the shards' default; round 6: it was 41 of each R-MAT 24 block's ~180 us).
+ * The shards on devices[0] that borrow d_x follow the same contract: after writing to x call set_x again (same pointer).
+ * csr5hip_multi_set_option(mh, CSR5HIP_OPT_X_SNAPSHOT, 0) restores live reads for those borrowing shards only.
  * Single host thread, all calls asynchronous per device.  devices[] may list a device several times (several
  * shards on one GPU), which is how a 1-GPU box exercises this path.
  * ------------------------------------------------------------------------------------------------- */
@@ -343,7 +352,8 @@ int csr5hip_multi_set_sigma(csr5hip_multi mh, int sigma);
 #define CSR5HIP_MULTI_OPT_OWN_REPLICAS 101
 int csr5hip_multi_set_option(csr5hip_multi mh, int option, int value);
 int csr5hip_multi_as_csr5(csr5hip_multi mh);
-/* setX: d_x on devices[0], n values, borrowed by the shards that live there; ONE broadcast to the other devices */
+/* setX: d_x on devices[0], n values, borrowed by the shards that live there; ONE broadcast to the other devices, each shard's
+ * permuted copy of x (hot-table path) taken right behind it.  Call again after changing x's contents. */
 int csr5hip_multi_set_x(csr5hip_multi mh, const void *d_x);
 /* spmv on every shard, enqueued on the shards' streams (returns without waiting) */
 int csr5hip_multi_spmv(csr5hip_multi mh, double alpha);

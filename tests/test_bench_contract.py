@@ -29,7 +29,7 @@ def test_bench_line_has_the_contract_keys():
     assert "R-MAT scale 24" in d["config"]["workload"] and d["config"]["nnz_per_gpu"] == 268435456
     assert d["scaling"] == "strong"
     subs = d["configs"]
-    assert [s_["dtype"] for s_ in subs] == ["f64", "f64", "f32"] and all("error" not in s_ for s_ in subs), subs
+    assert [s_["dtype"] for s_ in subs] == ["f64", "f64", "f32", "f64"] and all("error" not in s_ for s_ in subs), subs
     for s_ in subs:
         # working sets below the Infinity Cache: the COLD protocol's figure is the roofline figure, warm is a sub-key
         r_ = s_["roofline"]
@@ -48,6 +48,11 @@ def test_bench_line_has_the_contract_keys():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r and "traffic_note" in r
     assert "warm" not in r, "R-MAT 24 is far beyond the Infinity Cache: back-to-back steps already stream from HBM"
+    # flat scalar keys (what the driver's parsed record keeps): sub-config fractions, the snapshot protocol, the conversion
+    for name in ("scircuit", "webbase", "nd24k", "nd24k_f64"):
+        assert 0 < r[f"{name}_cold_frac"] <= r[f"{name}_warm_frac"] <= 1.0, name
+    assert 0 < r["x_snapshot_frac"] < 1 and r["conversion_ms"] > 0 and r["conversion_in_spmvs"] > 0 and 0 < r["conversion_frac"] < 1
+    assert d["value_multi_gpu_protocol"] >= d["value"] * 0.98
     assert abs(d["value"] - 2.0 * d["config"]["nnz_per_gpu"] / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
@@ -71,7 +76,7 @@ def test_bench_multi_gpu_form_launches_its_own_ranks():
         _run("--gpus", "2", "--workload", "rmat16", "--steps", "5", "--warmup", "1", expect_rc=1)
     d = _run("--gpus", "2", "--workload", "rmat18", "--steps", "10", "--warmup", "2",
              env={"CSR5_BENCH_SHARE_GPU": "1"} if torch.cuda.device_count() < 2 else None)
-    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "cpu_baseline" not in d
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     assert d["config"]["nnz_per_gpu"] < (1 << 18) * 16, "rank 0 holds one row block, not the whole matrix"
     # blocks are balanced by cost = nnz + 2 per row (sharding.ROW_WEIGHT): half of (16 + 2) * 2^18 each
     cost = d["config"]["nnz_per_gpu"] + 2 * d["config"]["m_per_gpu"]
@@ -94,6 +99,19 @@ def _check_multi_gpu_keys(d, world, rows):
         assert r["event_ms_per_step"] > 0 and r["wall_ms_per_step"] > 0 and 0 < r["roofline_frac"] <= 1.0
     # the job's step time is the slowest rank's
     assert d["event_ms_per_step"] >= max(r["event_ms_per_step"] for r in ranks) * 0.999
+    # round 6: an N > 1 line carries correctness evidence and a CPU baseline like the N = 1 line -- EVERY rank's block checked
+    # against CSR5_avx2 (exact on the integer data), rank 0's block and the whole matrix timed on the host cores, and the N = 1
+    # step under the same x protocol (x captured once behind the broadcast) measured in the same run
+    assert mg["max_rel_err_gpu_vs_cpu"] == 0.0 and mg["checker"] in ("reference", "port")
+    assert len(mg["per_rank_max_rel_err"]) == world and all(e == 0.0 for e in mg["per_rank_max_rel_err"])
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample", "scope", "whole_matrix_value"):
+        assert key in c, (key, c)
+    assert "rank 0's row block" in c["sample"] and c["max_rel_err_gpu_vs_cpu"] == 0.0
+    assert c["whole_matrix"]["max_rel_err_gpu_vs_cpu"] == 0.0 and "WHOLE matrix" in c["whole_matrix"]["sample"]
+    n1 = mg["n1_same_protocol"]
+    assert n1["ms_per_step"] > 0 and abs(mg["speedup_vs_n1_same_protocol"] - n1["ms_per_step"] / d["event_ms_per_step"]) < 0.01 * mg["speedup_vs_n1_same_protocol"] + 1e-3
+    assert "broadcast" in d["config"]["x_protocol"] and "roofline" in d and "conversion_ms" in d["roofline"]
 
 
 @pytest.mark.gpu

@@ -116,8 +116,11 @@ def test_rmat24_eight_row_blocks_at_size(oracle):
     would hold; generated per shard, `matrices.rmat_device_shard`), one after the other through their own handles at the
     library's defaults.  Every block must run the headline's path (16 column slabs, LDS hot table), the blocks' costs must be
     balanced within 10 %, and every block's y must equal the reference's compiled CSR5_avx2 (oracle/_ref; the pinned oracle
-    where that is absent) on the same block, exactly, on the CLI's integer data.  Per-block times -> gpurun_out/r05_shards.txt
-    (the code path of scripts/experiments/shard_alone.py).  N > 1 on hardware stays unmeasured: these are single-GPU times."""
+    where that is absent) on the same block, exactly, on the CLI's integer data.  Round 6: the blocks run under the MULTI-GPU x
+    protocol (csr5hip_multi_set_x / bench.py --gpus N: x captured once behind the broadcast, CSR5HIP_OPT_X_SNAPSHOT = 1) -- a
+    block no longer re-permutes all 134 MB of x in every step (41 of its ~180 us in round 5).  Per-block times ->
+    gpurun_out/shards.txt (or $CSR5_SHARDS_OUT; the code path of scripts/experiments/shard_alone.py).  N > 1 on hardware stays
+    unmeasured: these are single-GPU times."""
     import importlib.util
     import json
     import os
@@ -129,7 +132,7 @@ def test_rmat24_eight_row_blocks_at_size(oracle):
     ref = Reference() if Reference.available() else None
     world, recs = 8, []
     for rank in range(world):
-        rec, out = shard_alone.measure_block(24, world, rank, torch.device(DEV), steps=30, keep_y=True)
+        rec, out = shard_alone.measure_block(24, world, rank, torch.device(DEV), steps=30, keep_y=True, x_snapshot=1)
         recs.append(rec)
         assert rec["slabs"] == 16 and rec["hot"] == 1, rec
         m = rec["m"]
@@ -143,12 +146,16 @@ def test_rmat24_eight_row_blocks_at_size(oracle):
     assert sum(r["m"] for r in recs) == 1 << 24 and sum(r["nnz"] for r in recs) == 16 << 24
     cost = np.asarray([r["nnz"] + S.ROW_WEIGHT * r["m"] for r in recs], dtype=np.float64)
     assert cost.max() <= 1.10 * cost.mean(), cost / cost.mean()
+    slow = max(r["us"] for r in recs)
+    # (live x: 165-183 us per block in round 5; a loose bound that only a step carrying k_x_permute again would break)
+    assert slow <= 170.0, [r["us"] for r in recs]
     out_dir = os.path.join(root, "gpurun_out")
-    if os.path.isdir(out_dir):
-        slow = max(r["us"] for r in recs)
-        with open(os.path.join(out_dir, "r05_shards.txt"), "w") as f:
-            f.write("# the 8 cost-balanced row blocks of R-MAT 24 (BASELINE config 4), each ALONE on one MI355X at the library's defaults "
-                    "(x read live), tests/test_gpu_full_size.py::test_rmat24_eight_row_blocks_at_size;\n# N > 1 on hardware is "
+    out_path = os.environ.get("CSR5_SHARDS_OUT") or (os.path.join(out_dir, "shards.txt") if os.path.isdir(out_dir) else None)
+    if out_path:
+        with open(out_path, "w") as f:
+            f.write("# the 8 cost-balanced row blocks of R-MAT 24 (BASELINE config 4), each ALONE on one MI355X under the multi-GPU x "
+                    "protocol (x captured once behind the broadcast: CSR5HIP_OPT_X_SNAPSHOT = 1), "
+                    "tests/test_gpu_full_size.py::test_rmat24_eight_row_blocks_at_size;\n# N > 1 on hardware is "
                     "unmeasured: an 8-GPU step would take at least the slowest block's time\n")
             for r in recs:
                 f.write(json.dumps(r) + "\n")

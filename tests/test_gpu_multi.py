@@ -129,6 +129,56 @@ def test_multi_rmat20_eight_row_blocks_on_one_device(oracle):
         assert max(nnzs) <= 1.25 * mat.nnz / 8
 
 
+def test_multi_set_x_captures_x_once(oracle):
+    """The multi handle's x contract (csr5hip.h, round 6): set_x CAPTURES x -- every shard's permuted copy of x (hot-table path)
+    is taken once behind the broadcast, not by every spmv().  Shards default to CSR5HIP_OPT_X_SNAPSHOT = 1; writing to x without
+    set_x leaves y as it was, set_x with the same pointer picks the new contents up; X_SNAPSHOT = 0 through the multi handle
+    gives the shards that BORROW the caller's vector their live reads back (a library-owned replica stays captured)."""
+    mat = M.rmat(16, 16, seed=6)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=2, mode="int")
+    x2 = (x + 1.0) % 7
+    has = np.diff(mat.row_ptr) > 0
+    ref1 = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    ref2 = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x2)
+    rp = torch.from_numpy(mat.row_ptr.astype(np.int32)).to(DEV)
+    ci = torch.from_numpy(mat.col.astype(np.int32)).to(DEV)
+    va = torch.from_numpy(val).to(DEV)
+    for own in (False, True):
+        xd = torch.from_numpy(x).to(DEV)
+        G = 2
+        A = H.MultiGpuHandle(_devices(G), mat.m, mat.n)
+        assert A.inputCSR(mat.nnz, rp, ci, va) == 0
+        assert A.setSigma(-1) == 0
+        assert A.setOption(6, 8) == 0 and A.setOption(9, 2) == 0  # 8 column slabs + LDS hot table in every shard
+        if own:
+            assert A.setOption(_capi.MULTI_OPT_OWN_REPLICAS, 1) == 0
+        assert A.setX(xd) == 0  # before the conversion: as_csr5 takes the copy
+        assert A.asCSR5() == 0
+        for g in range(G):
+            i = A.shard_info(g)
+            assert i.slab_hot == 1 and i.slab_x_permuted == 1 and i.x_snapshot == 1, (g, i.slab_hot, i.x_snapshot)
+        assert A.spmv(1.0) == 0 and A.synchronize() == 0
+        assert np.array_equal(A.gather_y()[has], ref1[has])
+        xd.copy_(torch.from_numpy(x2).to(DEV))  # the caller writes to x and does NOT tell the handle
+        torch.cuda.synchronize()
+        assert A.spmv(1.0) == 0 and A.synchronize() == 0
+        assert np.array_equal(A.gather_y()[has], ref1[has]), "x was captured at set_x"
+        assert A.setX(xd) == 0  # same pointer, new contents
+        assert A.spmv_repeat(1.0, 3) == 0 and A.synchronize() == 0
+        assert np.array_equal(A.gather_y()[has], ref2[has])
+        # live reads for borrowing shards only
+        assert A.setOption(_capi.OPT_X_SNAPSHOT, 0) == 0
+        borrowing = [not own and A.shard(g).device == A.shard(0).device for g in range(G)]
+        assert [A.shard_info(g).x_snapshot for g in range(G)] == [0 if b else 1 for b in borrowing]
+        if all(borrowing):
+            xd.copy_(torch.from_numpy(x).to(DEV))
+            torch.cuda.synchronize()
+            assert A.spmv(1.0) == 0 and A.synchronize() == 0
+            assert np.array_equal(A.gather_y()[has], ref1[has]), "live x"
+        assert A.destroy() == 0
+        A.close()
+
+
 def test_multi_real_data_fp32_and_graph_replay(oracle):
     mat = zoo.small_zoo()[14]  # scircuit-like, small
     val, x = M.fill_values(mat.nnz, mat.n, np.float32, seed=3, mode="real")
