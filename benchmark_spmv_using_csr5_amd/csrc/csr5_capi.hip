@@ -117,6 +117,7 @@ struct csr5hip_handle_s {
     uint32_t *host_words = nullptr;    // 32 pinned, device-visible words the last conversion kernels export into
     // deferred carries (Geometry.defer; classification in csr5_format.hip tile_carry_meta): decided at conversion
     int defer_request = 1;       // CSR5HIP_OPT_DEFER_CARRIES: 0 off, 1 auto (default), 2 force
+    int finish_request = 1;      // CSR5HIP_OPT_CARRY_FINISH: deferred carries are added by 0 = a second launch, 1 = trailing workgroups of the tile kernel's launch (default)
     // narrow column codes of the x-window kernel (csr5_format.hip k_col16): built when that kernel is selected
     int col16_request = 1;       // CSR5HIP_OPT_NARROW_COLUMNS: 0 off, 1 auto (default)
     bool col16_built = false;    // the codes of the current conversion exist
@@ -354,6 +355,8 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         if (value != 0 && value != 1)
             return CSR5HIP_INVALID_ARGUMENT;
         h->opt.mode = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5 && value == 1 && h->g.defer == 2) // (the two-pass kernels leave real values in the parking words)
+            HIP_TRY(launch_arm_carries(h->g, h->d, (int)h->vsize(), h->stream));
         if (h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0) {
             const int rc = prepare_plain(h);
             if (rc != CSR5HIP_SUCCESS)
@@ -451,6 +454,15 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
             return CSR5HIP_INVALID_ARGUMENT;
         }
         h->defer_request = value;
+        break;
+    case CSR5HIP_OPT_CARRY_FINISH:
+        if (value != 0 && value != 1)
+            return CSR5HIP_INVALID_ARGUMENT;
+        if (h->format == CSR5HIP_FORMAT_CSR5 && value != h->finish_request) {
+            set_last_error("CSR5HIP_OPT_CARRY_FINISH takes effect at asCSR5(): set it while the matrix is in CSR form");
+            return CSR5HIP_INVALID_ARGUMENT;
+        }
+        h->finish_request = value;
         break;
     case CSR5HIP_OPT_NARROW_COLUMNS:
         if (value != 0 && value != 1)
@@ -634,6 +646,8 @@ static int derive_kernel_tables(csr5hip_handle h)
         const bool pays = long_rows ? g0.p - 1 >= DEFER_AUTO_MIN_TILES_LONG
                                     : (long long)(g0.p - 1) * g0.sigma >= DEFER_AUTO_MIN_TILE_SIGMA;
         h->g.defer = !h->is_child && h->opt.mode == 1 && g0.p > 1 && (h->defer_request == 2 || (h->defer_request == 1 && pays)) ? 1 : 0;
+        if (h->g.defer && h->finish_request == 1)
+            h->g.defer = 2; // the parked partials are added by trailing workgroups of the same launch (csr5_carry.h calibrate_in_launch)
     }
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
@@ -647,6 +661,8 @@ static int derive_kernel_tables(csr5hip_handle h)
         else
             h->wall_clock_khz = 100000.0; // gfx9: 100 MHz
     }
+    if (g.defer == 2) // the parking words hold the "nothing parked" sentinel between launches (the consumers put it back)
+        HIP_TRY(launch_arm_carries(g, h->d, (int)h->vsize(), s));
     // carry_meta + x-windows + fused-kernel headers in one launch, then the export of the host's words
     HIP_TRY(launch_tile_tables(g, h->d, (int)h->vsize(), h->host_words, h->is_child && h->hot_enabled, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1017,10 +1033,26 @@ static int build_slabs_impl(csr5hip_handle h)
         HIP_TRY(hipStreamSynchronize(s));
         h->hot_cover_pct = (int)(covered * (unsigned long long)stride * 100 / (unsigned long long)g.nnz); // estimate
         h->hot_cover_pct = h->hot_cover_pct > 100 ? 100 : h->hot_cover_pct;
-        // worth it when a good part of the gathers leaves the vector memory path (measured, scripts/gpu_hot.sh)
-        hot = h->hot_request == 2 || h->hot_cover_pct >= 25;
-        if (!hot && auto_count)
+        // Worth it when a good part of the gathers leaves the vector memory path AND the matrix is large enough to pay for the
+        // persistent kernel's fixed costs (a table refill and a workgroup barrier per slab, the range seams, P + combine: a
+        // 3 M-nnz matrix takes 44-49 us on this path whatever its columns).  Measured break-evens, cold (round 6,
+        // scripts/experiments/round6/locality.py, profiles/r06_locality.md): R-MAT 19 (8.4 M nnz, 90 % covered) wins 13 %,
+        // webbase-like x 8 with power-law columns (25 M, 54 %) wins 9 %, the same x 4 (12 M, 50 %) loses 11 %, x 2 loses 33 %, x 1
+        // loses 60 %: the table pays from about 5 M non-zeros covered BEYOND the 25 % floor.
+        const long long beyond = (long long)g.nnz / 100 * (h->hot_cover_pct - HOT_AUTO_MIN_COVER_PCT);
+        hot = h->hot_request == 2 || (h->hot_cover_pct >= HOT_AUTO_MIN_COVER_PCT && beyond >= HOT_AUTO_MIN_COVERED_BEYOND);
+        if (!hot && auto_count) {
+            if (h->hot_cover_pct >= HOT_AUTO_MIN_COVER_PCT) {
+                // Skewed columns on a matrix too small for the table: the popular part of x stays in every XCD's L2 by itself and
+                // the plain kernel beats slabs without a table at every size measured (28.0 / 51.3 / 102 us against 32.2 / 56.2 /
+                // 110 on webbase-like x 1 / 2 / 4 with power-law columns): no structure at all.
+                const int seen = h->hot_cover_pct;
+                release_slabs(h);
+                h->hot_cover_pct = seen; // (csr5hip_info.slab_hot_cover_pct keeps the estimate that explains the choice)
+                return CSR5HIP_SUCCESS;
+            }
             S = S_plain; // the table was the reason for that slab count
+        }
     }
     int bits = 0;
     while ((1 << bits) < S)
@@ -1079,7 +1111,7 @@ static int build_slabs_impl(csr5hip_handle h)
             const size_t cold_cap = std::min(cold_words, (size_t)g.nnz);
             HIP_TRY(h->b_cold_base.reserve(((size_t)S + 1) * 4));
             HIP_TRY(h->b_cold_cols.reserve((cold_cap + 1) * 4));
-            HIP_TRY(h->b_xperm.reserve(((size_t)S * hot_capacity + cold_cap + 1) * h->vsize()));
+            HIP_TRY(h->b_xperm.reserve(((size_t)S * hot_capacity + cold_cap + (size_t)hot_T + 1) * h->vsize())); // (+ the x entries of the child's CSR tail)
             HIP_TRY(hipMemsetAsync(tb + o_ref, 0, cold_words, s));
             HIP_TRY(slab_hot_pack(g.n, g.nnz, hot_T, hot_p, S, bits, h->slab_shift, (const int32_t *)h->b_slab_off.ptr, ht.hotmap,
                                   (const uint32_t *)ht.cnt, (const uint32_t *)t.key, (int32_t *)h->b_col2.ptr, (uint16_t *)h->b_col_lo.ptr,
@@ -1203,7 +1235,7 @@ static hipError_t ensure_x_snapshot(csr5hip_handle h, hipStream_t s)
     // a caller capturing its own graph gets the copy recorded with every spmv() (enqueue_spmv)
     if (stream_is_capturing(s))
         return hipSuccess;
-    hipError_t e = launch_x_permute(h->slab_child->d, h->value_type, h->x, s);
+    hipError_t e = launch_x_permute(h->slab_child->g, h->slab_child->d, h->value_type, h->x, s);
     if (e == hipSuccess)
         h->xperm_valid = true;
     return e;
@@ -1224,7 +1256,7 @@ static hipError_t enqueue_spmv(csr5hip_handle h, void *d_y, hipStream_t s, bool 
         if (c->hot_enabled && !reuse) {
             // the packed codes index the permuted copy of x: taken by every spmv() (x is read live, as the reference reads
             // it), or -- CSR5HIP_OPT_X_SNAPSHOT -- once per setX
-            e = launch_x_permute(c->d, c->value_type, h->x, s);
+            e = launch_x_permute(c->g, c->d, c->value_type, h->x, s);
             if (e != hipSuccess)
                 return e;
         }
@@ -1740,7 +1772,7 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_cold_entries = info->slab_x_permuted ? h->cold_total : 0;
     info->x_snapshot = h->x_snapshot;
     info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
-    info->carries_deferred = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->g.defer ? 1 : 0;
+    info->carries_deferred = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 ? h->g.defer : 0;
     info->narrow_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.col16 && h->opt.x_window ? 1 : 0;
     long long bytes = (long long)h->b_arena.cap;
     for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_val32, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,

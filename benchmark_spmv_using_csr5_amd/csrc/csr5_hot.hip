@@ -514,8 +514,8 @@ k_range_heads(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__
 
 template <typename VT>
 __global__ void __launch_bounds__(256)
-k_range_finish(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-               const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ head,
+k_range_finish(Geometry g, const int32_t *__restrict__ row_ptr,
+               const VT *__restrict__ val, const VT *__restrict__ xtail, const uint32_t *__restrict__ head,
                VT *__restrict__ P, const VT *__restrict__ lead, int nranges)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -531,10 +531,8 @@ k_range_finish(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *_
     const uint32_t hme = in ? head[R] : RANGE_NONE;
     const uint32_t hprev = in && R > 0 ? head[R - 1] : 0xFFFFFFFFu;
     const uint32_t hnext = in && R < nranges ? head[R + 1] : 0xFFFFFFFFu;
-    for (int e = tid; e < E; e += 256) {
-        const int32_t c = col[first_tail + e];
-        sprod[e] = val[first_tail + e] * x[(uint32_t)c];
-    }
+    for (int e = tid; e < E; e += 256) // (xtail: the tail's x entries in element order, behind the cold region of the permuted copy)
+        sprod[e] = val[first_tail + e] * xtail[e];
     __syncthreads();
     if (g.tail_start < g.m) {
         // first tail row (it may be all of the tail): strided partial sums, then a fixed-shape reduction -- the other rows
@@ -620,17 +618,17 @@ k_range_finish(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *_
 // written coalesced.
 template <typename VT>
 __global__ void __launch_bounds__(256)
-k_x_permute(int hot_entries, int cold_total, const int32_t *__restrict__ hot_cols, const int32_t *__restrict__ cold_cols,
-            const VT *__restrict__ x, VT *__restrict__ xp)
+k_x_permute(int hot_entries, int cold_total, int tail_entries, const int32_t *__restrict__ hot_cols,
+            const int32_t *__restrict__ cold_cols, const int32_t *__restrict__ tail_cols, const VT *__restrict__ x, VT *__restrict__ xp)
 {
     constexpr int PER = 4;
-    const long long total = (long long)hot_entries + cold_total;
+    const long long hc = (long long)hot_entries + cold_total, total = hc + tail_entries;
     const long long i0 = ((long long)blockIdx.x * PER) * 256 + threadIdx.x;
     int32_t c[PER];
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const long long i = i0 + u * 256;
-        c[u] = i < hot_entries ? hot_cols[i] : (i < total ? cold_cols[i - hot_entries] : 0);
+        c[u] = i < hot_entries ? hot_cols[i] : (i < hc ? cold_cols[i - hot_entries] : (i < total ? tail_cols[i - hc] : 0));
     }
     VT v[PER];
 #pragma unroll
@@ -644,18 +642,24 @@ k_x_permute(int hot_entries, int cold_total, const int32_t *__restrict__ hot_col
     }
 }
 
-hipError_t launch_x_permute(const DeviceArrays &d, int value_type, const void *x, hipStream_t s)
+// (the x entries of the child's CSR tail -- at most one tile of them, in the tail's element order -- sit behind the cold
+// region: k_range_finish reads them there, so that NO kernel of the hot path reads the caller's vector after this copy)
+static long long tail_first(const Geometry &g) { return (long long)(g.p - 1) * g.tile_elems; }
+hipError_t launch_x_permute(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, hipStream_t s)
 {
-    const long long hot_entries = (long long)d.hot_slabs * d.hot_capacity, total = hot_entries + d.cold_total;
+    const long long hot_entries = (long long)d.hot_slabs * d.hot_capacity;
+    const int tail_entries = g.p > 0 ? (int)((long long)g.nnz - tail_first(g)) : 0;
+    const long long total = hot_entries + d.cold_total + tail_entries;
     if (total <= 0)
         return hipSuccess;
+    const int32_t *tail_cols = d.col + (g.p > 0 ? tail_first(g) : 0);
     const unsigned blocks = (unsigned)((total + 1023) / 1024);
     if (value_type == CSR5HIP_F64)
-        hipLaunchKernelGGL(k_x_permute<double>, dim3(blocks), dim3(256), 0, s, (int)hot_entries, d.cold_total, d.hot_cols,
-                           d.cold_cols, (const double *)x, (double *)const_cast<void *>(d.xperm));
+        hipLaunchKernelGGL(k_x_permute<double>, dim3(blocks), dim3(256), 0, s, (int)hot_entries, d.cold_total, tail_entries, d.hot_cols,
+                           d.cold_cols, tail_cols, (const double *)x, (double *)const_cast<void *>(d.xperm));
     else
-        hipLaunchKernelGGL(k_x_permute<float>, dim3(blocks), dim3(256), 0, s, (int)hot_entries, d.cold_total, d.hot_cols,
-                           d.cold_cols, (const float *)x, (float *)const_cast<void *>(d.xperm));
+        hipLaunchKernelGGL(k_x_permute<float>, dim3(blocks), dim3(256), 0, s, (int)hot_entries, d.cold_total, tail_entries, d.hot_cols,
+                           d.cold_cols, tail_cols, (const float *)x, (float *)const_cast<void *>(d.xperm));
     return hipGetLastError();
 }
 
@@ -741,8 +745,9 @@ static hipError_t launch_range(const Geometry &g, const DeviceArrays &d, const v
     }
     const int nranges = d.hot_slabs * HOT_RANGES_PER_SLAB;
     const int blocks = (nranges + 1 + 255) / 256;
-    hipLaunchKernelGGL(k_range_finish<VT>, dim3(blocks), dim3(256), (size_t)g.tile_elems * sizeof(VT), s, g, d.row_ptr, d.col,
-                       (const VT *)d.val, (const VT *)x, d.range_head, (VT *)y, (const VT *)d.range_lead, nranges);
+    const VT *xtail = (const VT *)d.xperm + (size_t)d.hot_slabs * d.hot_capacity + d.cold_total;
+    hipLaunchKernelGGL(k_range_finish<VT>, dim3(blocks), dim3(256), (size_t)g.tile_elems * sizeof(VT), s, g, d.row_ptr,
+                       (const VT *)d.val, xtail, d.range_head, (VT *)y, (const VT *)d.range_lead, nranges);
     return hipGetLastError();
 }
 

@@ -51,8 +51,10 @@ struct Geometry {
     int p;            // number of tiles, the last one (p-1) is the CSR tail
     int tile_elems;   // omega * sigma
     int tail_start;   // first row of the tail tile
-    int defer;        // 1 = deferred carries (fused mode, decided at conversion): no tile finishes its neighbour's short spill and
-                      // every run head at which >= 2 partials meet is marked like a long run -- the parties park, k_calibrate adds
+    int defer;        // != 0: deferred carries (fused mode, decided at conversion): no tile finishes its neighbour's short spill and
+                      // every run head at which >= 2 partials meet is marked like a long run -- the parties park their partials, and
+                      // 1 = a second launch (k_calibrate) adds them, 2 = trailing workgroups of the SAME launch do (csr5_carry.h
+                      // calibrate_in_launch: the parked words are armed with a sentinel between launches)
 };
 
 // Device arrays of the CSR5 format plus our own launch helpers.
@@ -116,6 +118,12 @@ hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col1
 constexpr int COL16_SPAN = 32768; // columns a tile may span for the narrow codes: 15 bits of column, bit 15 = row-start flag
 constexpr bool col16_sigma(int sigma) { return sigma == 8 || sigma == 12 || sigma == 16 || sigma == 24 || sigma == 32; }
 hipError_t launch_warmup(hipStream_t s);
+// every word of the two parking arrays of the carries (calibrator, carry_acc: p + 1 values each) := the "nothing parked" sentinel
+hipError_t launch_arm_carries(const Geometry &g, const DeviceArrays &d, int value_size, hipStream_t s);
+// Sentinels of an empty parking word: SIGNALLING NaNs.  A parked partial is always the result of an IEEE multiply / add / FMA,
+// which never delivers a signalling NaN (it quiets them), so no partial can look like "nothing parked".
+constexpr unsigned long long CARRY_EMPTY64 = 0x7FF4DEADBEEF5A5Aull;
+constexpr unsigned CARRY_EMPTY32 = 0x7FA5DEADu;
 // flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)
 hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,
                                hipStream_t s);
@@ -167,6 +175,8 @@ constexpr int DEFER_AUTO_LONG_ROW = 128;          // average non-zeros per row f
 constexpr int DEFER_AUTO_MIN_TILES_LONG = 3000;   // ... and deferral pays from this many tiles on (nd24k-like: 3 741 tiles -2.4 us)
 constexpr int DEFER_AUTO_MIN_TILE_SIGMA = 500000; // shorter rows: from tiles x sigma >= this (27 per row, sigma 16: loses 2 us at 21 k
                                                   // tiles, wins 8 at 53 k; 81 per row even at 24 k; R-MAT 20 at 16 k would win 5 %)
+constexpr int HOT_AUTO_MIN_COVER_PCT = 25;                  // auto rule of the LDS hot table: share of the non-zeros it must cover ...
+constexpr long long HOT_AUTO_MIN_COVERED_BEYOND = 5000000;  // ... and non-zeros covered beyond that share (csr5_capi.hip build_slabs_impl)
 constexpr int HOT_LDS_BYTES = 128 * 1024;  // upper bound of the LDS table of hot x entries per workgroup (k_spmv_range)
 constexpr int HOT_WAVE_LDS = 4096;         // per-wavefront y-compaction region of k_spmv_range
 // Wavefronts of the persistent workgroup (one workgroup per CU).  The kernel is bound by the L1's outstanding requests,
@@ -212,6 +222,6 @@ hipError_t launch_narrow(const double *v, size_t n, float *o, int tile_elems, in
 hipError_t launch_range_heads(const Geometry &g, const DeviceArrays &d, hipStream_t s);
 // the permuted copy of x behind the packed codes of a hot child: xperm[i] = x[hot_cols[i]] for the table images,
 // xperm[slabs * capacity + i] = x[cold_cols[i]] for the cold region
-hipError_t launch_x_permute(const DeviceArrays &d, int value_type, const void *x, hipStream_t s);
+hipError_t launch_x_permute(const Geometry &g, const DeviceArrays &d, int value_type, const void *x, hipStream_t s);
 
 } // namespace csr5

@@ -59,17 +59,23 @@ def fill_values(nnz: int, n: int, dtype, seed: int, mode: str = "int"):
 
 
 def csr_from_row_lengths(lengths, n: int, rng, band: float = 0.0, name="synthetic",
-                         dtype=np.float64) -> CsrMatrix:
+                         dtype=np.float64, far: str = "uniform") -> CsrMatrix:
     """CSR with the given row lengths; columns uniform over [0,n) or, with probability `band`,
     within +-64 of the diagonal.  Column order inside a row is NOT sorted (the reference keeps file
-    order, main.cpp:266-275) and duplicates may occur."""
+    order, main.cpp:266-275) and duplicates may occur.  `far` = how the columns that are NOT near the
+    diagonal are drawn: "uniform" (default) or "powerlaw" (in-degree-like: column popularity ~ rank^-1 over a
+    random relabelling of the columns, the locality-axis variant of scripts/experiments/round6/locality.py)."""
     lengths = np.asarray(lengths, dtype=np.int64)
     m = lengths.size
     row_ptr = np.zeros(m + 1, dtype=np.int64)
     np.cumsum(lengths, out=row_ptr[1:])
     nnz = int(row_ptr[m])
     assert nnz < 2**31
-    col = rng.integers(0, n, size=nnz, dtype=np.int64)
+    if far == "powerlaw" and nnz:  # popularity ~ 1 / rank: inverse-cdf sampling of a log-uniform rank, hubs relabelled at random
+        rank = np.minimum(np.floor(np.exp(rng.random(nnz) * np.log(n))).astype(np.int64) - 1, n - 1)
+        col = rng.permutation(n)[np.maximum(rank, 0)]
+    else:
+        col = rng.integers(0, n, size=nnz, dtype=np.int64)
     if band > 0.0 and nnz:
         rows = np.repeat(np.arange(m, dtype=np.int64), lengths)
         near = rng.random(nnz) < band
@@ -97,7 +103,7 @@ def _scale_to_total(lengths: np.ndarray, total: int, rng, cap: int) -> np.ndarra
 
 
 def scircuit_like(seed: int = 1, scale: float = 1.0, dtype=np.float64, row_cap: int = 353,
-                  band: float = 0.5) -> CsrMatrix:
+                  band: float = 0.5, far: str = "uniform") -> CsrMatrix:
     """SuiteSparse scircuit stand-in: 170 998 x 170 998, 958 936 nnz, heavy-tailed rows (mean 5.6,
     max ~350), no structural empty rows, half the entries near the diagonal."""
     rng = np.random.default_rng(seed)
@@ -105,11 +111,11 @@ def scircuit_like(seed: int = 1, scale: float = 1.0, dtype=np.float64, row_cap: 
     nnz = max(int(958_936 * scale), m)
     raw = 1 + np.floor(rng.pareto(2.2, size=m) * 3.0).astype(np.int64)
     raw = _scale_to_total(raw, nnz, rng, cap=row_cap)
-    name = "scircuit-like(synthetic)" if band == 0.5 else f"scircuit-like(synthetic, band={band:g})"
-    return csr_from_row_lengths(raw, m, rng, band=band, name=name, dtype=dtype)
+    name = "scircuit-like(synthetic)" if band == 0.5 and far == "uniform" else f"scircuit-like(synthetic, band={band:g}, far={far})"
+    return csr_from_row_lengths(raw, m, rng, band=band, name=name, dtype=dtype, far=far)
 
 
-def webbase_like(seed: int = 2, scale: float = 1.0, dtype=np.float64, band: float = 0.3) -> CsrMatrix:
+def webbase_like(seed: int = 2, scale: float = 1.0, dtype=np.float64, band: float = 0.3, far: str = "uniform") -> CsrMatrix:
     """SuiteSparse webbase-1M stand-in: 1 000 005 square, 3 105 536 nnz, power-law rows capped at
     4 700, >= 10 % empty rows (stresses the empty-row offsets and the segmented sum).  `band` = share of
     the links that stay within +-64 of the diagonal (default 0.3: a harsh guess, 70 % of the x gathers are
@@ -120,8 +126,8 @@ def webbase_like(seed: int = 2, scale: float = 1.0, dtype=np.float64, band: floa
     raw = np.floor(rng.pareto(1.6, size=m) * 1.6 + 1.0).astype(np.int64)
     raw[rng.random(m) < 0.12] = 0
     raw = _scale_to_total(raw, nnz, rng, cap=4700)
-    name = "webbase-1M-like(synthetic)" if band == 0.3 else f"webbase-1M-like(synthetic, band={band:g})"
-    return csr_from_row_lengths(raw, m, rng, band=band, name=name, dtype=dtype)
+    name = "webbase-1M-like(synthetic)" if band == 0.3 and far == "uniform" else f"webbase-1M-like(synthetic, band={band:g}, far={far})"
+    return csr_from_row_lengths(raw, m, rng, band=band, name=name, dtype=dtype, far=far)
 
 
 def nd24k_like(seed: int = 3, scale: float = 1.0, dtype=np.float32) -> CsrMatrix:

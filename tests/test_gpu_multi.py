@@ -36,6 +36,8 @@ def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None, row_weigh
     assert A.setSigma(sigma) == 0
     if slabs is not None:
         assert A.setOption(6, slabs) == 0
+    if narrow is not None:
+        assert A.setOption(9, 2) == 0  # LDS hot table forced (a 2 M-nnz shard is below the auto rule's size threshold)
     if narrow == "before":
         assert A.setOption(_capi.OPT_NARROW_VALUES, 1) == 0
     assert A.asCSR5() == 0
@@ -44,7 +46,7 @@ def _run_multi(mat, val, x, G, dtype=np.float64, sigma=-1, slabs=None, row_weigh
     if narrow is not None:
         narrowed = [A.shard_info(g).slab_values_narrowed for g in range(G)]
         hot = [A.shard_info(g).slab_hot for g in range(G)]
-        assert narrowed == hot, "integer data: every shard with a hot table streams fp32 values"
+        assert narrowed == hot and any(hot), "integer data: every shard with a hot table streams fp32 values"
     if own_replicas:
         assert A.setOption(_capi.MULTI_OPT_OWN_REPLICAS, 1) == 0
     assert A.setX(xd) == 0

@@ -202,14 +202,14 @@ def test_slab_hot_real_data_and_auto(oracle):
     exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
     scale = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, np.abs(val), np.abs(x))
     info = {}
-    _, _, _, y_hot = _run(mat, val, x, 16, H.SPMV_FUSED, slabs=8, hot=1, info_out=info)
+    _, _, _, y_hot = _run(mat, val, x, 16, H.SPMV_FUSED, slabs=8, hot=2, info_out=info)
     assert info["slab_hot"] == 1 and info["slab_hot_cover_pct"] >= 60, info
     assert info["slab_sigma"] == 8, "the hot child is converted at sigma <= 8 (room for the y-compaction regions in LDS)"
     # same stacked matrix at the same child sigma without the table: the same partial sums per (row, slab) up to the
     # association of the additions at tile seams (the range kernel adds a row's pieces in tile order inside one
     # wavefront, the one-tile kernel through its carry protocol); run to run the hot path is bit-reproducible
     _, _, _, y_plain = _run(mat, val, x, 8, H.SPMV_FUSED, slabs=8, hot=0)
-    _, _, _, y_again = _run(mat, val, x, 16, H.SPMV_FUSED, slabs=8, hot=1)
+    _, _, _, y_again = _run(mat, val, x, 16, H.SPMV_FUSED, slabs=8, hot=2)
     nonempty = np.diff(mat.row_ptr) > 0  # (which EMPTY rows get a 0 depends on the parent's tail start, i.e. on its sigma)
     assert np.array_equal(y_hot[0][nonempty], y_again[0][nonempty])
     assert np.all(np.abs(y_hot[0] - y_plain[0])[nonempty] <= 1e-13 * np.maximum(scale, 1.0)[nonempty])
@@ -219,6 +219,17 @@ def test_slab_hot_real_data_and_auto(oracle):
     info = {}
     _run(flat, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, slabs=8, hot=1, info_out=info, y0=0.0)
     assert info["slab_hot"] == 0, "uniformly used columns: nothing worth a table slot"
+    # the size side of the auto rule (round 6, profiles/r06_locality.md): hub columns on a matrix too SMALL for the persistent
+    # kernel's fixed costs (the table pays from ~5 M non-zeros covered beyond its 25 % floor) -> no table; and with the slab
+    # count on auto as well, no structure at all: the popular part of x stays in every XCD's L2 by itself
+    small = _hub_columns_matrix(150000, 600000, 14, 800, 5)  # 2.1 M non-zeros, x = 4.8 MB, ~2 300 tiles
+    val, x = M.fill_values(small.nnz, small.n, np.float64, seed=9, mode="int")
+    info = {}
+    _run(small, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, slabs=8, hot=1, info_out=info, y0=0.0)
+    assert info["column_slabs"] == 8 and info["slab_hot"] == 0 and info["slab_hot_cover_pct"] >= 25, info
+    info = {}
+    _run(small, val, x, H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, slabs=1, hot=1, info_out=info, y0=0.0)
+    assert info["column_slabs"] == 0 and info["slab_hot"] == 0 and info["slab_hot_cover_pct"] >= 25, info
 
 
 def test_slab_hot_rmat_device():
@@ -285,7 +296,7 @@ def test_checkpoint_of_a_matrix_with_slabs(tmp_path):
     """csr5hip_save stores the reference's arrays only; csr5hip_load re-derives them and then builds the slab structure
     (auto rule) for the loaded matrix: same slab count, hot table and y as the handle that was saved."""
     from benchmark_spmv_using_csr5_amd.handle import anonymouslibHandle
-    mat = _hub_columns_matrix(150000, 600000, 14, 800, 5)  # x = 4.8 MB: the auto rule turns the slabs on
+    mat = M.rmat(19, 16, seed=5)  # 8.4 M non-zeros, x = 4 MiB, skewed columns: the auto rule turns slabs AND the hot table on
     val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=6, mode="int")
     rp, ci, va = _device_csr(mat, val, np.float64)
     xd = torch.from_numpy(x).to(DEV)
@@ -321,7 +332,8 @@ def test_slab_build_failure_falls_back_to_plain_kernel(oracle):
     -- an AUTO request leaves a valid CSR5 matrix on the plain kernel and asCSR5 succeeds (info says so); a structure that
     was REQUESTED makes asCSR5 fail, and then the matrix is back in CSR with the caller's arrays restored, as the
     reference's failed asCSR5 leaves it (anonymouslib_cuda.h:105-220)."""
-    mat = _hub_columns_matrix(150000, 700000, 12, 3000, 11)  # x = 5.6 MB, scattered columns: auto picks slabs
+    # x = 5.6 MB, uniformly scattered columns: auto picks slabs (hub columns on a matrix this small would go to the plain kernel)
+    mat = M.csr_from_row_lengths(np.full(150000, 12), 700000, np.random.default_rng(11), band=0.0, name="scattered")
     val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=4, mode="int")
     exp = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
     nonempty = np.diff(mat.row_ptr) > 0
@@ -414,6 +426,10 @@ def test_permuted_x_live_and_snapshot(oracle):
         assert A.setX(xd) == 0
         assert A.spmv(1.0, y) == 0
         check(4, "snapshot, first call after setX")
+        xd.mul_(3)  # overwritten WITHOUT setX: no kernel of the hot path (CSR tail included) reads the caller's vector any more
+        assert A.spmv(1.0, y) == 0
+        check(4, "snapshot, x overwritten without setX: the captured contents are used")
+        xd.div_(3)
         xd.div_(4)
         assert A.setX(xd) == 0  # contents changed: setX again, same pointer
         assert A.spmv_repeat(1.0, y, 2) == 0
