@@ -111,8 +111,6 @@ def parse_args():
                          "broadcast filled, which nothing writes afterwards -- the multi-GPU contract of csr5hip_multi_set_x")
     ap.add_argument("--defer-carries", default="auto", choices=["auto", "off", "force"],
                     help="plain path: cut rows finished by a second small launch instead of arrival atomics (CSR5HIP_OPT_DEFER_CARRIES)")
-    ap.add_argument("--carry-finish", type=int, default=None, choices=[0, 1],
-                    help="deferred carries added by 1 = trailing workgroups of the same launch (library default), 0 = a second launch")
     ap.add_argument("--zero-empty", type=int, default=0, choices=[0, 1],
                     help="1 = rows without non-zeros are written as 0 (CSR5HIP_OPT_ZERO_EMPTY_ROWS; the coupled-iteration setting)")
     ap.add_argument("--scaling", default=None, choices=[None, "weak", "strong"],
@@ -246,8 +244,6 @@ class Problem:
         _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
         if getattr(args, "defer_carries", "auto") != "auto":  # (auto = the library's default)
             _ck(A.setDeferCarries({"off": 0, "force": 2}[args.defer_carries]), "setDeferCarries")
-        if getattr(args, "carry_finish", None) is not None:
-            _ck(A.setCarryFinish(args.carry_finish), "setCarryFinish")
         rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 0) or 0))
         if rc != 0 and not os.environ.get("CSR5HIP_LIB"):  # (an older library build under A/B test does not know the option)
             _ck(rc, "setXSnapshot")
@@ -353,10 +349,9 @@ def roofline_dict(prob, ev_ms_per_step, wall_ms_per_step, extra=None):
         "traffic": None,
         "kernel": ((("csr5::k_x_permute + " if info.slab_x_permuted and not info.x_snapshot else "") +
                     "csr5::k_spmv_range + csr5::k_range_finish") if info.slab_hot else "csr5::k_spmv") +
-                  (" + csr5::k_calibrate (deferred carries)" if info.carries_deferred == 1 and not info.column_slabs else "") +
-                  (" (deferred carries added by trailing workgroups of the same launch)" if info.carries_deferred == 2 and not info.column_slabs else "") +
+                  (" + csr5::k_calibrate (deferred carries)" if info.carries_deferred and not info.column_slabs else "") +
                   (" + csr5::k_slab_combine" if info.column_slabs else "") +
-                  (" (all inside the step time)" if info.column_slabs or info.carries_deferred == 1 else ""),
+                  (" (all inside the step time)" if info.column_slabs or info.carries_deferred else ""),
         "algorithmic_bytes_per_launch": prob.b_alg,
         # diagnostic: what the kernels of one step actually move, by array (computed from the structure's sizes,
         # not measured; `traffic` below is the measured total).  B_alg stays the roofline's numerator.
@@ -410,7 +405,7 @@ def config_dict(prob, args, ingest_ms=None):
         "m_per_gpu": prob.m, "n": prob.n, "nnz_per_gpu": prob.nnz, "sigma": info.sigma, "tiles": info.p,
         "spmv_mode": args.mode, "launch": args.launch,
         "lds_x_window": bool(info.x_window_active), "x_window_cover_pct": info.x_window_cover_pct,
-        "narrow_columns": bool(info.narrow_columns), "carries_deferred": int(info.carries_deferred),
+        "narrow_columns": bool(info.narrow_columns), "carries_deferred": bool(info.carries_deferred),
         "column_slabs": info.column_slabs, "slab_shift": info.slab_shift, "slab_segments": info.slab_segments,
         "slab_sigma": info.slab_sigma, "slab_build_ms": round(info.t_slab_ms, 3),
         "slab_hot_table": bool(info.slab_hot), "slab_hot_cover_pct": info.slab_hot_cover_pct,

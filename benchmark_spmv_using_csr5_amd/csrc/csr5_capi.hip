@@ -117,7 +117,6 @@ struct csr5hip_handle_s {
     uint32_t *host_words = nullptr;    // 32 pinned, device-visible words the last conversion kernels export into
     // deferred carries (Geometry.defer; classification in csr5_format.hip tile_carry_meta): decided at conversion
     int defer_request = 1;       // CSR5HIP_OPT_DEFER_CARRIES: 0 off, 1 auto (default), 2 force
-    int finish_request = 1;      // CSR5HIP_OPT_CARRY_FINISH: deferred carries are added by 0 = a second launch, 1 = trailing workgroups of the tile kernel's launch (default)
     // narrow column codes of the x-window kernel (csr5_format.hip k_col16): built when that kernel is selected
     int col16_request = 1;       // CSR5HIP_OPT_NARROW_COLUMNS: 0 off, 1 auto (default)
     bool col16_built = false;    // the codes of the current conversion exist
@@ -355,8 +354,6 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
         if (value != 0 && value != 1)
             return CSR5HIP_INVALID_ARGUMENT;
         h->opt.mode = value;
-        if (h->format == CSR5HIP_FORMAT_CSR5 && value == 1 && h->g.defer == 2) // (the two-pass kernels leave real values in the parking words)
-            HIP_TRY(launch_arm_carries(h->g, h->d, (int)h->vsize(), h->stream));
         if (h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0) {
             const int rc = prepare_plain(h);
             if (rc != CSR5HIP_SUCCESS)
@@ -454,15 +451,6 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
             return CSR5HIP_INVALID_ARGUMENT;
         }
         h->defer_request = value;
-        break;
-    case CSR5HIP_OPT_CARRY_FINISH:
-        if (value != 0 && value != 1)
-            return CSR5HIP_INVALID_ARGUMENT;
-        if (h->format == CSR5HIP_FORMAT_CSR5 && value != h->finish_request) {
-            set_last_error("CSR5HIP_OPT_CARRY_FINISH takes effect at asCSR5(): set it while the matrix is in CSR form");
-            return CSR5HIP_INVALID_ARGUMENT;
-        }
-        h->finish_request = value;
         break;
     case CSR5HIP_OPT_NARROW_COLUMNS:
         if (value != 0 && value != 1)
@@ -646,8 +634,6 @@ static int derive_kernel_tables(csr5hip_handle h)
         const bool pays = long_rows ? g0.p - 1 >= DEFER_AUTO_MIN_TILES_LONG
                                     : (long long)(g0.p - 1) * g0.sigma >= DEFER_AUTO_MIN_TILE_SIGMA;
         h->g.defer = !h->is_child && h->opt.mode == 1 && g0.p > 1 && (h->defer_request == 2 || (h->defer_request == 1 && pays)) ? 1 : 0;
-        if (h->g.defer && h->finish_request == 1)
-            h->g.defer = 2; // the parked partials are added by trailing workgroups of the same launch (csr5_carry.h calibrate_in_launch)
     }
     const Geometry &g = h->g;
     hipStream_t s = h->stream;
@@ -661,8 +647,6 @@ static int derive_kernel_tables(csr5hip_handle h)
         else
             h->wall_clock_khz = 100000.0; // gfx9: 100 MHz
     }
-    if (g.defer == 2) // the parking words hold the "nothing parked" sentinel between launches (the consumers put it back)
-        HIP_TRY(launch_arm_carries(g, h->d, (int)h->vsize(), s));
     // carry_meta + x-windows + fused-kernel headers in one launch, then the export of the host's words
     HIP_TRY(launch_tile_tables(g, h->d, (int)h->vsize(), h->host_words, h->is_child && h->hot_enabled, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1772,7 +1756,7 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_cold_entries = info->slab_x_permuted ? h->cold_total : 0;
     info->x_snapshot = h->x_snapshot;
     info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
-    info->carries_deferred = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 ? h->g.defer : 0;
+    info->carries_deferred = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->g.defer ? 1 : 0;
     info->narrow_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.col16 && h->opt.x_window ? 1 : 0;
     long long bytes = (long long)h->b_arena.cap;
     for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_val32, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,

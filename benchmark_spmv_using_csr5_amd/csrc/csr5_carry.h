@@ -32,52 +32,13 @@ namespace csr5 {
 //   longer                : first + wave_sum(lane-strided partial sums of cal[slot..]) (whole wavefront)
 // `first` = the closing partial of tile slot-1 when the row starts inside it (has_first).
 // The long form must be called by all 64 lanes with wave-uniform arguments; result valid in `leader`.
-// ---- parked partials that are consumed inside the launch that parks them (Geometry::defer == 2) ---------------------------
-// A parking word holds the sentinel (CARRY_EMPTY*, a signalling NaN no arithmetic delivers) between launches; the party stores
-// its partial with ONE write-through agent-scope store -- the payload is its own flag, so nothing has to be drained or counted --
-// and the consumer (a trailing workgroup of the same grid, calibrate_in_launch below) polls the word, takes the value and puts
-// the sentinel back.  The wait is bounded (CARRY_WAIT_TICKS of the 100-MHz wall clock): should a partial ever BE the sentinel
-// pattern (only a non-IEEE mode could deliver it) the consumer proceeds with it after that time instead of hanging.
-constexpr unsigned long long CARRY_WAIT_TICKS = 200000000ull; // 2 s
-template <typename VT>
-__device__ __forceinline__ VT take_parked(VT *p, typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type seen)
-{
-    using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
-    constexpr bits_t EMPTY = sizeof(VT) == 8 ? (bits_t)CARRY_EMPTY64 : (bits_t)CARRY_EMPTY32;
-    bits_t *w = reinterpret_cast<bits_t *>(p);
-    bits_t v = seen;
-    if (v == EMPTY) {
-        // (polls are memory-side reads: a first quick retry, then ~1 us apart -- a few hundred waiting wavefronts must not
-        //  tax the tiles that are still streaming)
-        const unsigned long long t0 = wall_clock64();
-        __builtin_amdgcn_s_sleep(8);
-        v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (v == EMPTY && wall_clock64() - t0 < CARRY_WAIT_TICKS) {
-            __builtin_amdgcn_s_sleep(32);
-            v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __hip_atomic_store(w, EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // re-arm (write-through: no dirty line stays behind)
-    return __builtin_bit_cast(VT, v);
-}
-template <typename VT>
-__device__ __forceinline__ VT take_parked(VT *p)
-{
-    using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
-    return take_parked<VT>(p, __hip_atomic_load(reinterpret_cast<bits_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// MODE: 0 = plain loads (k_calibrate, next launch), 1 = agent-scope loads (last arriver, same launch), 2 = polling loads that
-// take the word and re-arm it (calibrate_in_launch)
-template <typename VT, int MODE>
-__device__ __forceinline__ VT sum_run(VT *calibrator, int slot, int len, bool has_first, VT first,
+template <typename VT, bool ATOMIC>
+__device__ __forceinline__ VT sum_run(const VT *calibrator, int slot, int len, bool has_first, VT first,
                                       int lane, int leader)
 {
     using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
     auto load = [&](int k) -> VT {
-        if constexpr (MODE == 2)
-            return take_parked<VT>(&calibrator[slot + k]);
-        else if constexpr (MODE == 1)
+        if constexpr (ATOMIC)
             return __builtin_bit_cast(VT, __hip_atomic_load(reinterpret_cast<const bits_t *>(&calibrator[slot + k]),
                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         else
@@ -125,9 +86,7 @@ __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, VT *calibra
         // long run (> RUN_SERIAL_MAX tiles, e.g. a row with 10^5..10^7 non-zeros): park the partial with a
         // plain store; k_calibrate<.., true> (second launch, only for matrices that have such rows) sums
         // them with a whole wavefront.  No counter: 10^4 arrivals on one word would serialise.
-        // (write-through agent-scope store: with Geometry::defer == 2 a trailing workgroup of THIS launch polls the word)
-        __hip_atomic_store(reinterpret_cast<bits_t *>(is_closing ? &acc[slot] : &calibrator[my_tile]), __builtin_bit_cast(bits_t, v),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *(is_closing ? &acc[slot] : &calibrator[my_tile]) = v;
     } else if (expected == 1u) {
         *row_y = v;
     } else if (expected == 2u) {
@@ -158,80 +117,10 @@ __device__ __forceinline__ void carry_arrive(VT *acc, uint32_t *cnt, VT *calibra
             if (has_first)
                 first = __builtin_bit_cast(VT, __hip_atomic_load(reinterpret_cast<bits_t *>(&acc[slot]),
                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            const VT total = sum_run<VT, 1>(calibrator, slot, len, has_first, first, 0, 0);
+            const VT total = sum_run<VT, true>(calibrator, slot, len, has_first, first, 0, 0);
             __hip_atomic_store(&cnt[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *row_y = total;
         }
-    }
-}
-
-// ---- deferred carries finished inside the launch (Geometry::defer == 2) -----------------------------------------------------
-// k_calibrate<.., LONG_ONLY = true>'s work -- one thread per tile, the run heads add their run's parked partials in tile order:
-// the two-pass association, bit for bit -- done by TRAILING workgroups of the tile kernel's own grid instead of a second launch
-// (nd24k-like: the launch boundary was 3-5 of the step's 37 us).  Forward progress: workgroups are handed to the XCDs round robin
-// and every XCD starts its share in index order, so when a trailing workgroup runs, every tile workgroup of ITS XCD has been
-// started (it can take no slot from them), and the tile workgroups of the other XCDs precede those XCDs' own trailing
-// workgroups; a tile workgroup never waits for anybody.  Nobody but these workgroups polls, and each word has ONE consumer.
-template <typename VT>
-__device__ __forceinline__ void calibrate_in_launch(const Geometry &g, const uint32_t *__restrict__ tile_ptr,
-                                                    const uint4 *__restrict__ meta, VT *calibrator, VT *acc, VT *__restrict__ y,
-                                                    int cblk, int tile_blocks, int xcd_remap)
-{
-    using bits_t = typename std::conditional<sizeof(VT) == 8, unsigned long long, unsigned>::type;
-    constexpr bits_t EMPTY = sizeof(VT) == 8 ? (bits_t)CARRY_EMPTY64 : (bits_t)CARRY_EMPTY32;
-    const int lane = threadIdx.x & (OMEGA - 1);
-    // Trailing thread j serves the tile of the j-th STARTED tile workgroup (k_spmv's XCD remap), the tail tile last: the trailing
-    // workgroups start in index order too, so all but the last few find their words parked long ago and never poll twice.
-    int t = cblk * BLOCK + (int)threadIdx.x;
-    if (xcd_remap && WAVES_PER_BLOCK == 1 && t < tile_blocks) {
-        const int q = tile_blocks / NUM_XCD, rem = tile_blocks % NUM_XCD, xcd = t % NUM_XCD;
-        t = xcd * q + (xcd < rem ? xcd : rem) + t / NUM_XCD;
-    }
-    bool head = false, has_first = false;
-    int len = 0, r = 0;
-    // the words a run of <= 2 partials needs (nearly every run) are requested with the meta word, not after it
-    bits_t seen_first = EMPTY, seen0 = EMPTY, seen1 = EMPTY;
-    const int t1 = t + 1 < g.p ? t + 1 : t;
-    if (t < g.p) {
-        seen_first = __hip_atomic_load(reinterpret_cast<bits_t *>(&acc[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seen0 = __hip_atomic_load(reinterpret_cast<bits_t *>(&calibrator[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seen1 = __hip_atomic_load(reinterpret_cast<bits_t *>(&calibrator[t1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint4 mt = meta[t];
-        r = (int)(tile_ptr[t] & ROW_MASK);
-        if ((mt.x >> 28) & 1u) { // (k_calibrate's classification, word for word)
-            len = 1;
-            has_first = true;
-        } else {
-            has_first = (mt.x >> 27) & 1u;
-            len = (int)(mt.x & 0x00FFFFFFu) - (has_first ? 1 : 0);
-        }
-        head = (int)mt.y == t && r < g.m && len > 0 && ((mt.x >> 26) & 1u);
-    }
-    if (head && len <= 2) {
-        VT total = take_parked<VT>(&calibrator[t], seen0);
-        if (has_first)
-            total = take_parked<VT>(&acc[t], seen_first) + total; // (sum_run's association: first + cal[t] + cal[t + 1])
-        if (len == 2)
-            total += take_parked<VT>(&calibrator[t1], seen1);
-        y[r] = total;
-    } else if (head && len <= RUN_SERIAL_MAX) {
-        const VT first = has_first ? take_parked<VT>(&acc[t], seen_first) : (VT)0;
-        y[r] = sum_run<VT, 2>(calibrator, t, len, has_first, first, lane, lane);
-    }
-    unsigned long long todo = __ballot(head && len > RUN_SERIAL_MAX);
-    while (todo) {
-        const int leader = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int slot = __shfl(t, leader, OMEGA);
-        const int ln = __shfl(len, leader, OMEGA);
-        const bool hf = __shfl((int)has_first, leader, OMEGA);
-        const int row = __shfl(r, leader, OMEGA);
-        VT first = 0;
-        if (hf && lane == leader)
-            first = take_parked<VT>(&acc[slot]);
-        const VT total = sum_run<VT, 2>(calibrator, slot, ln, hf, first, lane, leader);
-        if (lane == leader)
-            y[row] = total;
     }
 }
 

@@ -896,25 +896,6 @@ hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, co
     return hipGetLastError();
 }
 
-template <typename W>
-__global__ void __launch_bounds__(256) k_fill_words(W *__restrict__ a, W *__restrict__ b, size_t n, W pattern)
-{
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        a[i] = pattern, b[i] = pattern;
-}
-hipError_t launch_arm_carries(const Geometry &g, const DeviceArrays &d, int value_size, hipStream_t s)
-{
-    const size_t n = (size_t)g.p + 1;
-    const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    if (value_size == 8)
-        hipLaunchKernelGGL(k_fill_words<unsigned long long>, dim3(blocks), dim3(256), 0, s, (unsigned long long *)d.calibrator,
-                           (unsigned long long *)d.carry_acc, n, CARRY_EMPTY64);
-    else
-        hipLaunchKernelGGL(k_fill_words<unsigned>, dim3(blocks), dim3(256), 0, s, (unsigned *)d.calibrator, (unsigned *)d.carry_acc, n,
-                           CARRY_EMPTY32);
-    return hipGetLastError();
-}
-
 hipError_t launch_warmup(hipStream_t s)
 {
     hipLaunchKernelGGL(k_warmup, dim3(4000), dim3(OMEGA), 0, s, (int *)nullptr);

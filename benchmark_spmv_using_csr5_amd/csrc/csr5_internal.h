@@ -51,10 +51,8 @@ struct Geometry {
     int p;            // number of tiles, the last one (p-1) is the CSR tail
     int tile_elems;   // omega * sigma
     int tail_start;   // first row of the tail tile
-    int defer;        // != 0: deferred carries (fused mode, decided at conversion): no tile finishes its neighbour's short spill and
-                      // every run head at which >= 2 partials meet is marked like a long run -- the parties park their partials, and
-                      // 1 = a second launch (k_calibrate) adds them, 2 = trailing workgroups of the SAME launch do (csr5_carry.h
-                      // calibrate_in_launch: the parked words are armed with a sentinel between launches)
+    int defer;        // 1 = deferred carries (fused mode, decided at conversion): no tile finishes its neighbour's short spill and
+                      // every run head at which >= 2 partials meet is marked like a long run -- the parties park, k_calibrate adds
 };
 
 // Device arrays of the CSR5 format plus our own launch helpers.
@@ -118,12 +116,6 @@ hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col1
 constexpr int COL16_SPAN = 32768; // columns a tile may span for the narrow codes: 15 bits of column, bit 15 = row-start flag
 constexpr bool col16_sigma(int sigma) { return sigma == 8 || sigma == 12 || sigma == 16 || sigma == 24 || sigma == 32; }
 hipError_t launch_warmup(hipStream_t s);
-// every word of the two parking arrays of the carries (calibrator, carry_acc: p + 1 values each) := the "nothing parked" sentinel
-hipError_t launch_arm_carries(const Geometry &g, const DeviceArrays &d, int value_size, hipStream_t s);
-// Sentinels of an empty parking word: SIGNALLING NaNs.  A parked partial is always the result of an IEEE multiply / add / FMA,
-// which never delivers a signalling NaN (it quiets them), so no partial can look like "nothing parked".
-constexpr unsigned long long CARRY_EMPTY64 = 0x7FF4DEADBEEF5A5Aull;
-constexpr unsigned CARRY_EMPTY32 = 0x7FA5DEADu;
 // flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)
 hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,
                                hipStream_t s);

@@ -492,7 +492,7 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
        const uint32_t *__restrict__ tile_desc, const int32_t *__restrict__ offset_ptr,
        const int32_t *__restrict__ offset, VT *__restrict__ calibrator, VT *__restrict__ y,
        int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta,
-       const uint32_t *__restrict__ hdr, const uint32_t *__restrict__ col16, const int32_t *__restrict__ base16, int tail_blocks)
+       const uint32_t *__restrict__ hdr, const uint32_t *__restrict__ col16, const int32_t *__restrict__ base16)
 {
     // Pull EVERY kernel argument into SGPRs with the first batch of scalar loads: an argument that is
     // first touched further down would otherwise cost its own kernarg round trip on the critical path.
@@ -503,13 +503,6 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     // dynamic LDS: the tail's product buffer (T elements) or one x-window / y-segment region per wavefront
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int blk = blockIdx.x;
-    if constexpr (FUSED) {
-        // trailing workgroups (deferred carries finished inside the launch, Geometry::defer == 2): behind the tiles and the tail
-        if (blk >= tile_blocks + tail_blocks) {
-            calibrate_in_launch<VT>(g, tile_ptr, meta, calibrator, acc, y, blk - tile_blocks - tail_blocks, tile_blocks, xcd_remap);
-            return;
-        }
-    }
     if (blk >= tile_blocks) {
         tail_rows<VT, SIGMA>(g, row_ptr, col, val, x, y, blk - tile_blocks, reinterpret_cast<VT *>(smem), [&](VT sum) {
             if constexpr (FUSED) {
@@ -591,7 +584,7 @@ k_calibrate(Geometry g, const uint32_t *__restrict__ tile_ptr, const uint4 *__re
             total += spec1;
         y[r] = total;
     } else if (head && len <= RUN_SERIAL_MAX)
-        y[r] = sum_run<VT, 0>(const_cast<VT *>(calibrator), t, len, has_first, has_first ? (LONG_ONLY ? acc[t] : y[r]) : (VT)0, lane, lane);
+        y[r] = sum_run<VT, false>(calibrator, t, len, has_first, has_first ? (LONG_ONLY ? acc[t] : y[r]) : (VT)0, lane, lane);
     unsigned long long todo = __ballot(head && len > RUN_SERIAL_MAX);
     while (todo) {
         const int leader = __builtin_ctzll(todo);
@@ -603,7 +596,7 @@ k_calibrate(Geometry g, const uint32_t *__restrict__ tile_ptr, const uint4 *__re
         VT first = 0;
         if (hf && lane == leader)
             first = LONG_ONLY ? acc[slot] : y[row];
-        const VT total = sum_run<VT, 0>(const_cast<VT *>(calibrator), slot, ln, hf, first, lane, leader);
+        const VT total = sum_run<VT, false>(calibrator, slot, ln, hf, first, lane, leader);
         if (lane == leader)
             y[row] = total;
     }
@@ -619,18 +612,16 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
     const int tail_blocks = tail_rows_n > 0 ? (tail_rows_n + BLOCK - 1) / BLOCK : 0;
     if (tile_blocks + tail_blocks == 0)
         return hipSuccess;
-    // deferred carries finished inside the launch: one trailing thread per tile (calibrate_in_launch)
-    const int cal_blocks = FUSED && g.defer == 2 ? (g.p + BLOCK - 1) / BLOCK : 0;
     size_t lds = (size_t)g.tile_elems * sizeof(VT); // tail product buffer (tail workgroups)
     if (lds < (size_t)WAVES_PER_BLOCK * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>())
         lds = (size_t)WAVES_PER_BLOCK * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>();
-    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, C16>), dim3(tile_blocks + tail_blocks + cal_blocks), dim3(BLOCK), lds, s,
+    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, C16>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), lds, s,
                        g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x, d.tile_ptr,
                        d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, tile_blocks,
                        opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt,
-                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr, d.col16, d.base16, tail_blocks);
+                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr, d.col16, d.base16);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || (FUSED && (!opt.long_runs || cal_blocks)))
+    if (e != hipSuccess || (FUSED && !opt.long_runs))
         return e;
     // second launch: two-pass mode always; fused mode only when some row spans > RUN_SERIAL_MAX tiles
     hipLaunchKernelGGL((k_calibrate<VT, FUSED>), dim3((g.p + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, g,

@@ -165,11 +165,6 @@ class anonymouslibHandle:
         atomics): 0 = off, 1 = auto (default), 2 = force; set before asCSR5 (csr5hip.h CSR5HIP_OPT_DEFER_CARRIES)"""
         return self.setOption(_capi.OPT_DEFER_CARRIES, int(value))
 
-    def setCarryFinish(self, value: int) -> int:
-        """deferred carries: the parked partials are added by 1 = trailing workgroups of the tile kernel's own launch (default),
-        0 = a second launch; set before asCSR5 (csr5hip.h CSR5HIP_OPT_CARRY_FINISH)"""
-        return self.setOption(_capi.OPT_CARRY_FINISH, int(value))
-
     def setNarrowColumns(self, value: int) -> int:
         """x-window kernel: 1 = auto (default) stream 16-bit column codes (15 bits of column + the row-start flag) when every tile spans < 32 768 columns, 0 = off
         (csr5hip.h CSR5HIP_OPT_NARROW_COLUMNS)"""

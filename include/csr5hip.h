@@ -129,12 +129,9 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       one call.  1 = auto (default: by tiles, sigma and average row length), 0 = off, 2 = force.
                                       Takes effect at asCSR5(): set it while the matrix is in CSR form.
                                       csr5hip_info.carries_deferred says what happened. */
-#define CSR5HIP_OPT_CARRY_FINISH 17  /* deferred carries only: who adds the parked partials.  1 (default) = TRAILING WORKGROUPS of the tile
-                                      kernel's own launch (one thread per tile behind the tiles and the tail in the grid; a parking word
-                                      holds a signalling-NaN sentinel between launches, a party's ONE write-through store is payload and
-                                      flag at once, the consumer polls, takes the value and puts the sentinel back: no second launch, no
-                                      counter, no drained store; same order of additions, bit-identical), 0 = the second launch
-                                      (k_calibrate).  Takes effect at asCSR5().  csr5hip_info.carries_deferred: 2 / 1. */
+/* (option number 17, CSR5HIP_OPT_CARRY_FINISH of round 6 -- the deferred carries added by trailing workgroups of the tile kernel's own
+   launch instead of a second launch -- was parity-green and bit-identical but 2 us SLOWER on nd24k-like (the parties' stores must be
+   written through to be seen inside the launch) and was taken out again: scripts/experiments/round6/carry_finish_in_launch/) */
 
 typedef struct csr5hip_handle_s *csr5hip_handle;
 
@@ -175,8 +172,7 @@ typedef struct csr5hip_info {
     int slab_cold_entries;         /* entries of that copy behind the table images (columns gathered from memory)        */
     int x_snapshot;                /* CSR5HIP_OPT_X_SNAPSHOT as set                                                      */
     int slab_values_narrowed;      /* 1 = CSR5HIP_OPT_NARROW_VALUES took effect: the slab kernel streams fp32 values       */
-    int carries_deferred;          /* CSR5HIP_OPT_DEFER_CARRIES took effect: cut rows are finished 1 = by a second small launch, 2 = by
-                                      trailing workgroups of the tile kernel's launch (CSR5HIP_OPT_CARRY_FINISH)                  */
+    int carries_deferred;          /* 1 = cut rows are finished by a second small launch (CSR5HIP_OPT_DEFER_CARRIES)             */
     int narrow_columns;            /* 1 = the x-window kernel streams 16-bit column codes (CSR5HIP_OPT_NARROW_COLUMNS)            */
 } csr5hip_info;
 

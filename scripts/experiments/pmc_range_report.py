@@ -9,6 +9,18 @@ import sys
 
 raw = open(sys.argv[1]).read()
 extra = open(sys.argv[2]).read()
+ROUND = sys.argv[3] if len(sys.argv) > 3 else "r04"
+if ROUND == "r04":
+    SOURCES = ("FINAL round-4 sources: 8 wavefronts per CU, 16 384-slot table, permuted x,\n## bit flags in the column codes -- no "
+               "descriptor load --, DPP prefix for y_offset, values in 16-byte pieces")
+    HOW = "scripts/experiments/round4/gpu_r4t.sh"
+    EARLIER = """{EARLIER}"""
+else:
+    SOURCES = (f"FINAL {ROUND} sources: round 4's kernel + round 5's dealing of 8.5 % more tiles to the first four\n## wavefronts of a "
+               "workgroup and the combine's rotated row groups; round 6 changed nothing in it but the CSR tail's x (read from the permuted copy)")
+    HOW = "scripts/experiments/round6/pmc_range.sh"
+    EARLIER = ("## Round 4's figures on the same counters (profiles/r04_pmc_range.txt): 111.5 M requests, 478 clocks, 94 in flight, queue full 68 %, "
+               "TA busy 89 %.\n")
 rng = raw[raw.index('#### k_spmv_range'):raw.index('#### k_slab_combine')]
 cmb = raw[raw.index('#### k_slab_combine'):]
 
@@ -26,9 +38,8 @@ wc, wi, wa, ai = g(rng, 'SQ_WAVE_CYCLES'), g(rng, 'SQ_WAIT_INST_ANY'), g(rng, 'S
 creq, clat, cgui = g(cmb, 'TCP_TCC_READ_REQ_sum'), g(cmb, 'TCP_TCC_READ_REQ_LATENCY_sum'), g(cmb, 'GRBM_GUI_ACTIVE') / 8
 cta, cwc, cwi, cwa = g(cmb, 'TA_TA_BUSY_sum'), g(cmb, 'SQ_WAVE_CYCLES'), g(cmb, 'SQ_WAIT_INST_ANY'), g(cmb, 'SQ_WAIT_ANY')
 lds, valu, salu, spi = g(extra, 'SQ_LDS_IDX_ACTIVE'), g(extra, 'SQ_INSTS_VALU'), g(extra, 'SQ_INSTS_SALU'), g(extra, 'SPI_RA_WAVE_SIMD_FULL_CSN')
-print(f"""## What holds k_spmv_range<double, 8, true, 2, double> (R-MAT 24, FINAL round-4 sources: 8 wavefronts per CU, 16 384-slot table, permuted x,
-## bit flags in the column codes -- no descriptor load --, DPP prefix for y_offset, values in 16-byte pieces)?
-## rocprofv3 --pmc passes (one counter group per pass, counters + kernel trace only), scripts/experiments/round4/gpu_r4t.sh on
+print(f"""## What holds k_spmv_range<double, 8, true, 2, double> (R-MAT 24, {SOURCES})?
+## rocprofv3 --pmc passes (one counter group per pass, counters + kernel trace only), {HOW} on
 ## `bench.py --no-sub-configs --no-side-figures --steps 20 --warmup 5`; average per launch over {n} launches; SUMS over the chip: 256 CUs
 ## (TA / TCP / SQ), 128 L2 channels (TCC), 8 XCDs (GRBM).  Clock under the profiler 2.1 GHz.  (This file: scripts/experiments/pmc_range_report.py.)
 {rng}
@@ -47,16 +58,12 @@ print(f"""## What holds k_spmv_range<double, 8, true, 2, double> (R-MAT 24, FINA
 ##    instruction count and the issue order all measure within 1-2 %, and why every percent of table coverage, every stream byte and every
 ##    vector-memory instruction shows (r04_probes.txt: flags in the codes -4 % stream bytes = -1..2 %; values in 16-byte loads -1.7 %;
 ##    CSR5HIP_OPT_NARROW_VALUES -36 % stream bytes = -12 %).
-## Earlier in the round: before the values moved into 16-byte pieces (8 value loads per tile) 111.5 M requests, 479 clocks, 92 in flight, 65 % full,
-## TA 89 % busy; before the flags moved into the codes 112.6 M requests, 467 clocks, 88 in flight; first measurement (16 wavefronts, 12 288 slots,
-## exact-count ranking; gpu_r4b.sh) 120.4 M requests, 451 clocks, 86 in flight, 66 % full, TCC 96.4 M hits / 30.0 M misses, LFIFO / RFIFO / TCR / TD
-## stalls 8.2 M / 0.01 M / 3.9 M / 3.0 M (nothing).
-
+{EARLIER}
 {cmb}
-## more counter groups on the combine (scripts/experiments/round4/gpu_r4aq.sh):
+## more counter groups on the combine:
 {extra}
 ## Reading: {creq/1e6:.2f} M L2 read requests of {clat/creq:.0f} clocks each (72 % miss L2: the partials were written 0.3 GB ago) in {cgui/1e3:.0f} k clocks per XCD =
 ## {clat/256/cgui:.0f} in flight per CU -- a quarter of what the L1 can hold -- with the address unit busy {cta/256/cgui*100:.0f} %, the LDS {lds/256/cgui*100:.0f} % (SQ_LDS_IDX_ACTIVE),
 ## {valu/65536:.0f} vector + {salu/65536:.0f} scalar instructions per wavefront, {cwc*4/256/cgui:.0f} wavefronts resident per CU of the 32 that fit (SQ_WAVE_CYCLES x 4 / 256 /
 ## launch clocks) although the dispatcher is almost never refused (SPI_RA_WAVE_SIMD_FULL {spi/1e6:.2f} M cycles).  {cwi/cwc*100:.0f} % of the wave time waits to issue,
-## {cwa/cwc*100:.0f} % waits for data.  What was tried on it and did not help: r04_probes.txt, last sections.""")
+## {cwa/cwc*100:.0f} % waits for data.  What was tried on it and did not help: r04_probes.txt, last sections; r05_probes.txt section 1 (the XCD skew, fixed).""")

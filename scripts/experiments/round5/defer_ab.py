@@ -21,7 +21,7 @@ def main():
     ap.add_argument("--sigma", default="-1")
     ap.add_argument("--slabs", default="auto")
     ap.add_argument("--no-cold", action="store_true")
-    ap.add_argument("--modes", default="off,force2l,force,auto")
+    ap.add_argument("--modes", default="off,force,auto")
     ap.add_argument("--x-window", default="auto")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -56,10 +56,7 @@ def main():
         mat = (sized[w.split(":")[0]] if ":" in w else mat[w])()
         ys = {}
         for mode in args.modes.split(","):
-            # "force" / "auto": the library's default finish (trailing workgroups of the same launch, round 6); "force2l" / "auto2l": the
-            # second launch (k_calibrate) of round 5
-            a = base_args(sigma=args.sigma, slabs=slabs, defer_carries=mode.replace("2l", ""), x_window=args.x_window,
-                          carry_finish=0 if mode.endswith("2l") else None)
+            a = base_args(sigma=args.sigma, slabs=slabs, defer_carries=mode, x_window=args.x_window)
             warm, cold, desc, b = measure(mat, w, dtype_name, a, dev, cold=not args.no_cold)
             a.values = "real"  # (rounding-sensitive data for the comparison)
             prob = B.Problem(mat, w, dtype_name, a, dev, 14)
@@ -74,9 +71,9 @@ def main():
             fc = b / (cold * 1e-6) / 8e12 if cold else float("nan")
             print(f"{w:9s} defer={mode:5s} ({deferred}) warm {warm:8.2f} us ({fw:.3f})  cold {cold if cold else float('nan'):8.2f} us ({fc:.3f})  {desc}",
                   flush=True)
-        if "force2l" in ys and "force" in ys:
-            same = torch.equal(ys["force2l"].view(torch.uint8), ys["force"].view(torch.uint8))
-            print(f"{w:9s} force2l == force bit for bit: {same}", flush=True)
+        if "off" in ys and "force" in ys:
+            same = torch.equal(ys["off"].view(torch.uint8), ys["force"].view(torch.uint8))
+            print(f"{w:9s} off == force bit for bit: {same}", flush=True)
 
 
 if __name__ == "__main__":

@@ -37,7 +37,7 @@ PATHS = [
 
 def base_args(**kw):
     a = types.SimpleNamespace(values="int", sigma="-1", mode="fused", x_window="auto", xcd_remap=1, lds_y="auto", stream_nt="auto",
-                              slabs="auto", slab_shift=None, slab_hot="auto", x_snapshot=0, zero_empty=0, defer_carries="auto", carry_finish=None, seed=1)
+                              slabs="auto", slab_shift=None, slab_hot="auto", x_snapshot=0, zero_empty=0, defer_carries="auto", seed=1)
     a.__dict__.update(kw)
     return a
 

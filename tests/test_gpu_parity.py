@@ -30,7 +30,7 @@ def _device_csr(mat, val, dtype):
 
 def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None, nt=None,
          slabs=None, slab_shift=None, zero_empty=None, info_out=None, hot=None, x_snapshot=None, narrow=None,
-         narrow_cols=None, defer=None, x_misaligned=False, finish=None):
+         narrow_cols=None, defer=None, x_misaligned=False):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
@@ -65,8 +65,6 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         assert A.setNarrowColumns(narrow_cols) == 0
     if defer is not None:
         assert A.setDeferCarries(defer) == 0
-    if finish is not None:
-        assert A.setCarryFinish(finish) == 0
     assert A.spmv(1.0, yd) == H.ANONYMOUSLIB_UNSUPPORTED_CSR_SPMV  # still CSR (anonymouslib_cuda.h:268-271)
     assert A.asCSR5() == 0, _capi.last_error()
     arrays = A.csr5_arrays()
@@ -425,7 +423,7 @@ def test_large_rmat_size_independent_properties(scale):
         assert A.inputCSR(mat.nnz, mat.row_ptr, mat.col, val) == 0
         assert A.setX(x) == 0 and A.setSigma(H.ANONYMOUSLIB_AUTO_TUNED_SIGMA) == 0 and A.setColumnSlabs(0) == 0
         assert A.asCSR5() == 0
-        assert A.info().column_slabs == 0 and A.info().carries_deferred == 2, A.info()
+        assert A.info().column_slabs == 0 and A.info().carries_deferred == 1, A.info()
         y = torch.full((mat.m,), -3.0, dtype=torch.float64, device=DEV)
         assert A.spmv(1.0, y) == 0 and A.spmv(1.0, y) == 0
         torch.cuda.synchronize()
@@ -940,18 +938,12 @@ def test_deferred_carries(oracle):
             arrays, col_t, val_t, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, defer=2, repeat=2,
                                             info_out=info, **kw)
             _check_format(arrays, col_t, val_t, fmt)
-            assert info["carries_deferred"] == (2 if fmt.p > 1 else 0), info  # (default: finished by trailing workgroups of the launch)
+            assert info["carries_deferred"] == (1 if fmt.p > 1 else 0), info
             exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
             assert np.array_equal(ys[0], exp) and np.array_equal(ys[1], exp), (mat.name, sigma, np.dtype(dtype).name, info)
-            info1 = {}
-            _, _, _, ys1 = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, defer=2, finish=0, repeat=2, info_out=info1, **kw)
-            assert info1["carries_deferred"] == (1 if fmt.p > 1 else 0), info1  # CSR5HIP_OPT_CARRY_FINISH = 0: the second launch
-            assert np.array_equal(ys1[0], exp) and np.array_equal(ys1[1], exp), (mat.name, sigma, "second-launch finish")
             val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=72, mode="real")
             info_off = {}
             _, _, _, yd = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, defer=2, repeat=3, **kw)
-            _, _, _, yd1 = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, defer=2, finish=0, **kw)
-            assert np.array_equal(yd[0], yd1[0]), (mat.name, sigma, "in-launch finish == second-launch finish, bit for bit")
             _, _, _, yo = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, defer=0, info_out=info_off, **kw)
             _, _, _, y2 = _run(mat, val, x, sigma, H.SPMV_TWO_PASS, dtype=dtype, slabs=0, defer=0)
             assert info_off["carries_deferred"] == 0
@@ -974,32 +966,10 @@ def test_deferred_carries(oracle):
             val, x = (val % 3).astype(np.float32), (x % 3).astype(np.float32)
         info = {}
         _, _, _, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, info_out=info)
-        assert info["carries_deferred"] == 2 * expect, (mat.name, info)
+        assert info["carries_deferred"] == expect, (mat.name, info)
         nonempty = np.diff(mat.row_ptr) > 0
         ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val.astype(np.float64), x.astype(np.float64))
         assert np.array_equal(ys[0].astype(np.float64)[nonempty], ref[nonempty]), mat.name
-
-    # switching the SpMV mode on a converted handle: the two-pass kernels leave real values in the parking words, so the way
-    # back to the fused kernel re-arms them (csr5hip_set_option CSR5HIP_OPT_SPMV_MODE)
-    mat = M.nd24k_like(scale=0.05, dtype=np.float64)
-    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=74, mode="int")
-    rp, ci, va = _device_csr(mat, val, np.float64)
-    xd = torch.from_numpy(x).to(DEV)
-    yd = torch.full((mat.m,), Y_POISON, dtype=torch.float64, device=DEV)
-    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
-    A = H.anonymouslibHandle(mat.m, mat.n)
-    assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0 and A.setSigma(16) == 0
-    assert A.setColumnSlabs(0) == 0 and A.setDeferCarries(2) == 0 and A.asCSR5() == 0
-    assert A.info().carries_deferred == 2
-    for mode in (H.SPMV_FUSED, H.SPMV_TWO_PASS, H.SPMV_FUSED, H.SPMV_FUSED, H.SPMV_TWO_PASS, H.SPMV_FUSED):
-        assert A.setSpmvMode(mode) == 0
-        yd.fill_(Y_POISON)
-        assert A.spmv(1.0, yd) == 0 and A.spmv_repeat(1.0, yd, 3) == 0
-        torch.cuda.synchronize()
-        assert np.array_equal(yd.cpu().numpy(), ref), mode
-    assert A.setCarryFinish(0) != 0  # (takes effect at asCSR5: refused on a converted handle)
-    assert A.destroy() == 0
-    A.close()
 
 
 @pytest.mark.gpu
