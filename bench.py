@@ -127,6 +127,7 @@ def parse_args():
                     help="skip the cold-cache protocol that a cache-sized working set gets by default (profiling runs: one protocol per trace)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-configs", action="store_true", help="skip the per-config array (N = 1)")
+    ap.add_argument("--no-locality-points", action="store_true", help="skip the four locality-bracket points of the sub-configs")
     ap.add_argument("--no-side-figures", action="store_true",
                     help="skip roofline.x_live / roofline.narrowed_values (profiling runs: only the headline protocol's kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -142,6 +143,11 @@ def parse_args():
 # instead of the synthetic stand-ins, through the native Matrix Market ingest (values replaced by rand()%10 integers as
 # the reference CLI does, CSR5_avx2/main.cpp:283-295)
 SUB_CONFIGS = ("scircuit", "webbase", "nd24k", "nd24k_f64")  # the other single-GPU BASELINE configs (+ nd24k-like in fp64)
+# The two power-law stand-ins at the OTHER end of the locality bracket (profiles/r06_locality.md): no SuiteSparse file exists
+# offline, so the line carries where the real matrices would plausibly land next to the harsh stand-ins above.  tag -> (workload,
+# share of entries within +-64 of the diagonal, how the far columns are drawn)
+LOCALITY_POINTS = {"webbase_b06pl": ("webbase", 0.6, "powerlaw"), "webbase_b09pl": ("webbase", 0.9, "powerlaw"),
+                   "scircuit_b08": ("scircuit", 0.8, "uniform"), "scircuit_b095": ("scircuit", 0.95, "uniform")}
 REAL_FILES = {"scircuit": "scircuit.mtx", "webbase": "webbase-1M.mtx", "nd24k": "nd24k.mtx"}
 
 
@@ -165,7 +171,7 @@ def load_real(path: str, np_dtype):
     return mat, f"{mat.name} (Matrix Market file, native ingest)", ingest_ms
 
 
-def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device, scale: float, strong: bool, band):
+def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device, scale: float, strong: bool, band, far=None):
     """The rank's row block.  Returns (matrix with numpy or device arrays, label)."""
     from benchmark_spmv_using_csr5_amd import matrices as M
 
@@ -178,6 +184,8 @@ def make_shard(workload: str, rank: int, world: int, seed: int, dtype, device, s
     kw = {} if scale == 1.0 else {"scale": scale}
     if workload in ("webbase", "scircuit") and band is not None:
         kw["band"] = band
+    if workload in ("webbase", "scircuit") and far is not None:
+        kw["far"] = far
     if strong and world > 1:  # one global matrix, cost-balanced row blocks (sharding.py)
         from benchmark_spmv_using_csr5_amd import sharding as S
         full = gen(seed=seed, dtype=dtype, **kw)
@@ -448,9 +456,9 @@ def cold_is_the_number(prob, roof, ev_step, wall_step, cold_ms, k, cold_steps):
     return roof
 
 
-def sub_config(name, args, dev):
+def sub_config(name, args, dev, band=None, far=None):
     """One of the other BASELINE GPU configs on this GPU (N = 1 only): the COLD figure is the headline of the entry, the
-    cache-warm one sits under roofline.warm."""
+    cache-warm one sits under roofline.warm.  band / far: the stand-in at another point of the locality axis."""
     import copy
     a = copy.copy(args)
     a.sigma, a.slabs, a.slab_shift, a.values, a.slab_hot = "-1", "auto", None, "int", "auto"
@@ -463,7 +471,7 @@ def sub_config(name, args, dev):
     if real:
         mat, label, ingest_ms = load_real(real, np_dtype)
     else:
-        mat, label = make_shard(name, 0, 1, args.seed, np_dtype, dev, 1.0, False, None)
+        mat, label = make_shard(name, 0, 1, args.seed, np_dtype, dev, 1.0, False, band, far)
     prob = Problem(mat, label, dtype_name, a, dev, args.seed + 13)
     steps = {"scircuit": 1000, "webbase": 400, "nd24k": 200}[name]
     wall_s, ev_ms = timed(prob, steps, 50, "graph")
@@ -805,6 +813,21 @@ def main():
                                  ("cold_us", "cold_us")):
                     if e.get(src) is not None:
                         out["roofline"][f"{name}_{dst}"] = e[src]
+            # the locality bracket of the two power-law stand-ins: three scalar keys per point (cold / warm fraction, path taken)
+            if not args.no_locality_points:
+                for tag, (wl, band, far) in LOCALITY_POINTS.items():
+                    try:
+                        sc = sub_config(wl, args, dev, band=band, far=far)
+                        r, c = sc["roofline"], sc["config"]
+                        out["roofline"][f"{tag}_cold_frac"] = r.get("frac")
+                        out["roofline"][f"{tag}_warm_frac"] = (r.get("warm") or {}).get("frac")
+                        out["roofline"][f"{tag}_path"] = ("plain" if not c["column_slabs"] else f"slabs{c['column_slabs']}" +
+                                                          ("+table" if c["slab_hot_table"] else "")) + ("+xwindow" if c["lds_x_window"] else "")
+                    except Exception as e:  # never at the cost of the headline line
+                        out["roofline"][f"{tag}_error"] = repr(e)
+                out["roofline"]["locality_note"] = ("<workload>_b<band>[pl]: the stand-in with that share of entries near the diagonal "
+                                                    "([pl]: far columns power-law instead of uniform); bracket and forced paths: "
+                                                    "profiles/r06_locality.md")
         print(json.dumps(out), flush=True)
     else:
         prob.close()

@@ -51,6 +51,10 @@ def test_bench_line_has_the_contract_keys():
     # flat scalar keys (what the driver's parsed record keeps): sub-config fractions, the snapshot protocol, the conversion
     for name in ("scircuit", "webbase", "nd24k", "nd24k_f64"):
         assert 0 < r[f"{name}_cold_frac"] <= r[f"{name}_warm_frac"] <= 1.0, name
+    # the locality bracket of the power-law stand-ins: three scalars per point, every point at or above its harsh stand-in
+    for tag, base in (("webbase_b06pl", "webbase"), ("webbase_b09pl", "webbase"), ("scircuit_b08", "scircuit"), ("scircuit_b095", "scircuit")):
+        assert r[f"{base}_cold_frac"] * 0.98 <= r[f"{tag}_cold_frac"] <= r[f"{tag}_warm_frac"] <= 1.0, (tag, r[f"{tag}_cold_frac"])
+        assert r[f"{tag}_path"] == "plain", (tag, r[f"{tag}_path"])
     assert 0 < r["x_snapshot_frac"] < 1 and r["conversion_ms"] > 0 and r["conversion_in_spmvs"] > 0 and 0 < r["conversion_frac"] < 1
     assert d["value_multi_gpu_protocol"] >= d["value"] * 0.98
     assert abs(d["value"] - 2.0 * d["config"]["nnz_per_gpu"] / (d["ms_per_step"] * 1e-3) / 1e9) < 0.02 * d["value"]
