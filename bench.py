@@ -111,6 +111,8 @@ def parse_args():
                          "broadcast filled, which nothing writes afterwards -- the multi-GPU contract of csr5hip_multi_set_x")
     ap.add_argument("--defer-carries", default="auto", choices=["auto", "off", "force"],
                     help="plain path: cut rows finished by a second small launch instead of arrival atomics (CSR5HIP_OPT_DEFER_CARRIES)")
+    ap.add_argument("--flagged-columns", default="auto", choices=["auto", "off", "force"],
+                    help="plain kernel at sigma 4..8: column words with the row-start flag in bit 31 (CSR5HIP_OPT_FLAGGED_COLUMNS)")
     ap.add_argument("--zero-empty", type=int, default=0, choices=[0, 1],
                     help="1 = rows without non-zeros are written as 0 (CSR5HIP_OPT_ZERO_EMPTY_ROWS; the coupled-iteration setting)")
     ap.add_argument("--scaling", default=None, choices=[None, "weak", "strong"],
@@ -252,6 +254,8 @@ class Problem:
         _ck(A.setSlabHot({"off": 0, "auto": 1, "force": 2}[args.slab_hot]), "setSlabHot")
         if getattr(args, "defer_carries", "auto") != "auto":  # (auto = the library's default)
             _ck(A.setDeferCarries({"off": 0, "force": 2}[args.defer_carries]), "setDeferCarries")
+        if getattr(args, "flagged_columns", "auto") != "auto":
+            _ck(A.setFlaggedColumns({"off": 0, "force": 2}[args.flagged_columns]), "setFlaggedColumns")
         rc = A.setXSnapshot(int(getattr(args, "x_snapshot", 0) or 0))
         if rc != 0 and not os.environ.get("CSR5HIP_LIB"):  # (an older library build under A/B test does not know the option)
             _ck(rc, "setXSnapshot")
@@ -386,7 +390,10 @@ def stream_breakdown(prob) -> dict:
     if not i.column_slabs:
         d = {("column_codes_16bit" if i.narrow_columns else "column_index"): (2 if i.narrow_columns else 4) * prob.nnz,
              "value": v * prob.nnz, "tile_ptr": 4 * (i.p + 1),
-             "tile_desc": 4 * i.p * 64 * i.num_packet, "x_once": v * prob.n, "y": v * prob.m}
+             "tile_desc": 0 if (i.narrow_columns or getattr(i, "flagged_columns", 0)) else 4 * i.p * 64 * i.num_packet,
+             "x_once": v * prob.n, "y": v * prob.m}
+        if getattr(i, "flagged_columns", 0):
+            d["column_index_flag_in_bit31"] = d.pop("column_index")
     elif not i.slab_hot:
         d = {"child_column_index": 4 * prob.nnz, "child_value": v * prob.nnz, "child_tile_ptr": 4 * (i.slab_tiles + 1),
              "child_tile_desc": 4 * i.slab_tiles * 64, "x_once": v * prob.n, "P_written": v * i.slab_segments,
@@ -413,7 +420,8 @@ def config_dict(prob, args, ingest_ms=None):
         "m_per_gpu": prob.m, "n": prob.n, "nnz_per_gpu": prob.nnz, "sigma": info.sigma, "tiles": info.p,
         "spmv_mode": args.mode, "launch": args.launch,
         "lds_x_window": bool(info.x_window_active), "x_window_cover_pct": info.x_window_cover_pct,
-        "narrow_columns": bool(info.narrow_columns), "carries_deferred": bool(info.carries_deferred),
+        "narrow_columns": bool(info.narrow_columns), "flagged_columns": bool(getattr(info, "flagged_columns", 0)),
+        "carries_deferred": bool(info.carries_deferred),
         "column_slabs": info.column_slabs, "slab_shift": info.slab_shift, "slab_segments": info.slab_segments,
         "slab_sigma": info.slab_sigma, "slab_build_ms": round(info.t_slab_ms, 3),
         "slab_hot_table": bool(info.slab_hot), "slab_hot_cover_pct": info.slab_hot_cover_pct,

@@ -41,6 +41,7 @@ OPT_X_SNAPSHOT = 11
 OPT_NARROW_VALUES = 12
 OPT_NARROW_COLUMNS = 15
 OPT_DEFER_CARRIES = 16
+OPT_FLAGGED_COLUMNS = 18
 MULTI_OPT_ROW_WEIGHT = 100  # csr5hip_multi_set_option only (before input_csr)
 MULTI_OPT_OWN_REPLICAS = 101  # csr5hip_multi_set_option only (before set_x): devices[0]'s shards read a broadcast replica too
 
@@ -65,6 +66,7 @@ class Csr5Info(C.Structure):
         ("slab_values_narrowed", C.c_int),
         ("carries_deferred", C.c_int),
         ("narrow_columns", C.c_int),
+        ("flagged_columns", C.c_int),
     ]
 
 

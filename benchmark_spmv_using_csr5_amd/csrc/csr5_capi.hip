@@ -122,6 +122,10 @@ struct csr5hip_handle_s {
     bool col16_built = false;    // the codes of the current conversion exist
     unsigned col16_wide = 0;     // tiles that span >= 32 768 columns (the codes are used only when there is none)
     Buffer b_col16;              // codes [(p-1) * T / 2 words], then base16 [p]
+    // flagged column words of the plain kernel at sigma 4..8 (csr5_format.hip k_col31)
+    int col31_request = 1;       // CSR5HIP_OPT_FLAGGED_COLUMNS: 0 off, 1 auto (default), 2 force
+    bool col31_built = false;
+    Buffer b_col31;              // [(p-1) * T words]
     double wall_clock_khz = 0;         // rate of the device's constant wall clock (phase stamps)
     double t_malloc = 0, t_tile_ptr = 0, t_tile_desc = 0, t_transpose = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -256,6 +260,7 @@ int csr5hip_free(csr5hip_handle h)
     release_slabs(h);
     h->b_arena.release();
     h->b_col16.release();
+    h->b_col31.release();
     if (h->host_words)
         (void)hipHostFree(h->host_words);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -342,8 +347,14 @@ int csr5hip_set_sigma(csr5hip_handle h, int sigma)
 static int build_slabs(csr5hip_handle h);
 static int build_slabs_impl(csr5hip_handle h);
 static int prepare_col16(csr5hip_handle h);
-// kernel-side tables of the plain (non-slab) path that are built on demand: the narrow column codes
-static int prepare_plain(csr5hip_handle h) { return prepare_col16(h); }
+static int prepare_col31(csr5hip_handle h);
+// kernel-side tables of the plain (non-slab) path that are built on demand: the narrow column codes of the x-window kernel,
+// else the flagged column words of the plain kernel
+static int prepare_plain(csr5hip_handle h)
+{
+    const int rc = prepare_col16(h);
+    return rc != CSR5HIP_SUCCESS ? rc : prepare_col31(h);
+}
 
 int csr5hip_set_option(csr5hip_handle h, int option, int value)
 {
@@ -462,6 +473,16 @@ int csr5hip_set_option(csr5hip_handle h, int option, int value)
                 return rc;
         }
         break;
+    case CSR5HIP_OPT_FLAGGED_COLUMNS:
+        if (value < 0 || value > 2)
+            return CSR5HIP_INVALID_ARGUMENT;
+        h->col31_request = value;
+        if (h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0) {
+            const int rc = prepare_col31(h);
+            if (rc != CSR5HIP_SUCCESS)
+                return rc;
+        }
+        break;
     case CSR5HIP_OPT_SLAB_MEMORY_MIB:
         if (value < 0)
             return CSR5HIP_INVALID_ARGUMENT;
@@ -501,6 +522,9 @@ static int derive_geometry(csr5hip_handle h, int sigma)
     h->xwin_lines = 0;
     h->opt.long_runs = 0;
     h->col16_built = false; // (the column words are about to be permuted again)
+    h->col31_built = false;
+    h->opt.col31 = 0;
+    h->d.col31 = nullptr;
     h->opt.col16 = 0;
     h->d.col16 = nullptr;
     h->d.base16 = nullptr;
@@ -614,6 +638,49 @@ static int prepare_col16(csr5hip_handle h)
         h->d.base16 = (const int32_t *)h->b_col16.ptr + code_words;
         h->opt.col16 = 1;
     }
+    h->drop_graphs();
+    return CSR5HIP_SUCCESS;
+}
+
+// ---- flagged column words (csr5_format.hip k_col31, csr5_spmv.hip C31) ----------------------------------------------------
+// The plain fused kernel at sigma 4..8 (short rows: the auto rule's r = 6 / 8) reads its column words from a kernel-side copy
+// that carries the element's row-start flag in bit 31: no descriptor load (256 B of a sigma = 6 tile's 4.9 KB and one of its
+// load instructions), y_offset recomputed from the flags by a wave prefix sum as in the narrow-codes kernel; same gathers, same
+// arithmetic, bit-identical results.  An optional accelerator (+4 bytes per non-zero of device memory): when it cannot be built
+// the handle stays on column_index + tile_desc.  Not for the x-window kernel (it has the narrow codes) nor for a slab child.
+// Auto rule (same-call A/B, scripts/experiments/round6/flagged_ab.py, profiles/r06_probes.txt section 4): the descriptor load rides
+// in the tile's first round trip, so dropping it saves BYTES, not latency, and the flag extraction + prefix sum run after the data
+// has arrived -- a matrix that streams from HBM gains (2 M rows x 27 per row, sigma 8: 168.9 -> 165.2 us, -2.2 %), the latency-bound
+// stand-ins lose (scircuit-like +0.7 % cold, webbase-like without slabs +1.1 %, their local variants +3..5 %): on only when the
+// streams exceed the Infinity Cache (the non-temporal rule's size).
+static int prepare_col31(csr5hip_handle h)
+{
+    h->opt.col31 = 0;
+    h->d.col31 = nullptr;
+    const Geometry &g = h->g;
+    const bool pays = (long long)g.nnz * (4 + (long long)h->vsize()) > 256LL * 1024 * 1024;
+    if (h->col31_request == 0 || (h->col31_request == 1 && !pays) || h->is_child || g.p <= 1 || h->opt.mode != 1 || h->opt.x_window ||
+        !col31_sigma(g.sigma)) {
+        h->drop_graphs();
+        return CSR5HIP_SUCCESS;
+    }
+    if (!h->col31_built) {
+        hipError_t e = h->b_col31.reserve((size_t)(g.p - 1) * g.tile_elems * 4);
+        if (e == hipSuccess)
+            e = launch_col31(g, h->d, (uint32_t *)h->b_col31.ptr, h->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) {
+            (void)hipGetLastError(); // clear the sticky allocation / launch error
+            h->b_col31.release();
+            set_last_error(std::string("flagged column words not built, column_index + tile_desc in use: ") + hipGetErrorString(e));
+            h->drop_graphs();
+            return CSR5HIP_SUCCESS;
+        }
+        h->col31_built = true;
+    }
+    h->d.col31 = (const uint32_t *)h->b_col31.ptr;
+    h->opt.col31 = 1;
     h->drop_graphs();
     return CSR5HIP_SUCCESS;
 }
@@ -1758,10 +1825,11 @@ int csr5hip_get_info(csr5hip_handle h, csr5hip_info *info)
     info->slab_values_narrowed = h->slab_S > 0 && h->values_narrowed ? 1 : 0;
     info->carries_deferred = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->g.defer ? 1 : 0;
     info->narrow_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.col16 && h->opt.x_window ? 1 : 0;
+    info->flagged_columns = h->format == CSR5HIP_FORMAT_CSR5 && h->slab_S <= 0 && h->opt.col31 && !h->opt.x_window && h->opt.mode == 1 ? 1 : 0;
     long long bytes = (long long)h->b_arena.cap;
     for (const Buffer *b : {&h->b_row_ptr2, &h->b_col2, &h->b_val2, &h->b_val32, &h->b_P, &h->b_rowidx, &h->b_base, &h->b_nonempty,
                             &h->b_hot_cols, &h->b_hot_count, &h->b_hot_tile0, &h->b_slab_off, &h->b_lead, &h->b_range_head, &h->b_slab_tmp,
-                            &h->b_col_lo, &h->b_col_hi, &h->b_cold_base, &h->b_cold_cols, &h->b_xperm, &h->b_col16})
+                            &h->b_col_lo, &h->b_col_hi, &h->b_cold_base, &h->b_cold_cols, &h->b_xperm, &h->b_col16, &h->b_col31})
         bytes += (long long)b->cap;
     if (h->slab_child)
         bytes += (long long)h->slab_child->b_arena.cap;

@@ -664,6 +664,35 @@ hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col1
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Flagged column words (csr5_spmv.hip C31): the tile-ordered column_index of tiles 0 .. p-2 with the element's row-start flag --
+// the lane's bit flags of the reference's descriptor (format_cuda.h:129-360) -- in bit 31.  The caller's column_index (one of
+// the reference's format arrays, exposed bit for bit) is only read.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(FMT_BLOCK) k_col31(Geometry g, const int32_t *__restrict__ col,
+                                                 const uint32_t *__restrict__ tile_desc, uint32_t *__restrict__ col31)
+{
+    const int lane = threadIdx.x & (OMEGA - 1);
+    const int t = blockIdx.x * FMT_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (t >= g.p - 1)
+        return;
+    const uint32_t *dw = tile_desc + (size_t)t * OMEGA * g.num_packet + lane;
+    uint32_t flags = dw[0] << g.bit_all;
+    if (g.num_packet > 1)
+        flags |= dw[OMEGA] >> (32 - g.bit_all);
+    const size_t base = (size_t)t * g.tile_elems + lane;
+    for (int i = 0; i < g.sigma; i++)
+        col31[base + (size_t)i * OMEGA] = (uint32_t)col[base + (size_t)i * OMEGA] | (((flags >> (31 - i)) & 1u) << 31);
+}
+
+hipError_t launch_col31(const Geometry &g, const DeviceArrays &d, uint32_t *col31, hipStream_t s)
+{
+    if (g.p <= 1)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_col31, dim3((g.p - 1 + FMT_WAVES_PER_BLOCK - 1) / FMT_WAVES_PER_BLOCK), dim3(FMT_BLOCK), 0, s, g, d.col, d.tile_desc, col31);
+    return hipGetLastError();
+}
+
 // checkpoint loading: the index arrays come from a file and are used as addresses by every later kernel
 __global__ void __launch_bounds__(256) k_validate_csr(int m, int n, int nnz, const int32_t *__restrict__ row_ptr,
                                                       const int32_t *__restrict__ col, uint32_t *__restrict__ flag)

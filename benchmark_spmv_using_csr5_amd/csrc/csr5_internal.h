@@ -95,6 +95,9 @@ struct DeviceArrays {
     const uint32_t *col16;     // [(p-1) * T / 2] two 16-bit codes per word: elements (2d, lane) | (2d+1, lane) << 16 of tile t at
                                // t * T/2 + d * 64 + lane, code = column - base16[t]; nullptr = not built
     const int32_t *base16;     // [p] smallest column of every tile
+    // flagged column words of the plain kernel at small sigma (csr5_spmv.hip C31): the tile-ordered column_index of tiles
+    // 0 .. p-2 with the element's row-start flag in bit 31 (a column index is < 2^31); nullptr = not built
+    const uint32_t *col31;     // [(p-1) * T]
 };
 
 // ---- conversion (csr5_format.hip) ----
@@ -115,6 +118,10 @@ hipError_t launch_col16(const Geometry &g, const DeviceArrays &d, uint32_t *col1
                         hipStream_t s);
 constexpr int COL16_SPAN = 32768; // columns a tile may span for the narrow codes: 15 bits of column, bit 15 = row-start flag
 constexpr bool col16_sigma(int sigma) { return sigma == 8 || sigma == 12 || sigma == 16 || sigma == 24 || sigma == 32; }
+// flagged column words: column_index | row-start flag << 31, for the sigmas where the descriptor word is a visible share of a tile's
+// stream (256 B next to 64 sigma x 12 B: 5.6 % at sigma = 6, 2 % at 16) and one of its few load instructions
+hipError_t launch_col31(const Geometry &g, const DeviceArrays &d, uint32_t *col31, hipStream_t s);
+constexpr bool col31_sigma(int sigma) { return sigma >= 4 && sigma <= 8; }
 hipError_t launch_warmup(hipStream_t s);
 // flag[0] |= 1 if row_ptr is not 0 = row_ptr[0] <= ... <= row_ptr[m] = nnz, |= 2 if a column index lies outside [0, n)
 hipError_t launch_validate_csr(int m, int n, int nnz, const int32_t *row_ptr, const int32_t *col, uint32_t *flag,
@@ -159,6 +166,7 @@ struct SpmvOptions {
     int long_runs;   // resolved: the matrix has rows spanning > RUN_SERIAL_MAX tiles (fused mode adds k_calibrate)
     int hot;         // resolved: column-slab child whose columns are hot-encoded: persistent k_spmv_range + k_range_finish
     int col16;       // resolved: 1 = the x-window kernel streams 16-bit column codes (2 bytes per non-zero less)
+    int col31;       // resolved: 1 = the plain kernel streams the flagged column words (no descriptor load)
 };
 // deferred carries, auto rule (measured break-evens, scripts/experiments/round5/defer_ab.py): what deferral saves grows with the
 // number of tiles -- per tile the two scattered spill loads (sigma cache lines each) and, where rows are too long for short-spill

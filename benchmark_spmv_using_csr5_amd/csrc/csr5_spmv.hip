@@ -70,15 +70,17 @@ extern "C" int csr5hip_debug_tile_stamps_f64(unsigned long long *dst, int count)
 // SIGMA > 0: compile-time sigma (loads hoisted into registers, flag walk fully unrolled).
 // SIGMA == 0: run-time sigma (any 1..32), same code shape, used for sigma < 4 and as a cross-check.
 // One tile, one wavefront.  `wave_lds` = this wavefront's private LDS region (x-window / y segments).
-template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT, bool C16 = false>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT, bool C16 = false, bool C31 = false>
 __device__ __forceinline__ void
 tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restrict__ col, const VT *__restrict__ val,
           const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ tile_desc,
           const int32_t *__restrict__ offset_ptr, const int32_t *__restrict__ offset, VT *__restrict__ calibrator,
           VT *__restrict__ y, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta, const uint32_t *__restrict__ hdr,
-          char *wave_lds, const uint32_t *__restrict__ col16 = nullptr, const int32_t *__restrict__ base16 = nullptr)
+          char *wave_lds, const uint32_t *__restrict__ col16 = nullptr, const int32_t *__restrict__ base16 = nullptr,
+          const uint32_t *__restrict__ col31 = nullptr)
 {
     static_assert(!C16 || (SIGMA > 0 && SIGMA % 2 == 0 && FUSED && !NT), "narrow column codes: two per word, fused kernel");
+    static_assert(!C31 || (SIGMA > 0 && FUSED && !XWIN && !C16), "flagged column words: plain fused kernel, compile-time sigma");
     auto gather = [&](int32_t cw) -> VT { return x[(uint32_t)cw]; };
     const int sigma = SIGMA > 0 ? SIGMA : g.sigma;
     const int bit_y = SIGMA > 0 ? bit_y_of(SIGMA > 0 ? SIGMA : 1) : g.bit_y;
@@ -91,7 +93,8 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     //      and no data-dependent branch sits between them, so one memory round trip covers all
     //      of them and a second one covers the x gathers.
     const size_t base = (size_t)t * T + lane;
-    const int32_t *ct = col + base;
+    // (C31: the same words with the element's row-start flag in bit 31, from the kernel-side copy)
+    const int32_t *ct = (C31 ? reinterpret_cast<const int32_t *>(col31) : col) + base;
     const VT *vt = val + base;
     const uint32_t *d = tile_desc + (size_t)t * OMEGA * num_packet;
     // The wave-uniform words (tile_ptr pair, carry meta) deliberately go through the VECTOR memory
@@ -160,7 +163,7 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     }
     // (narrow column codes carry the bit flags themselves and y_offset is recomputed from them: no descriptor load)
     uint32_t w0 = 0, w1 = 0;
-    if constexpr (!C16) {
+    if constexpr (!C16 && !C31) {
         w0 = d[lane];
         w1 = num_packet > 1 ? d[OMEGA + lane] : 0u;
     }
@@ -213,6 +216,13 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
                 const uint32_t w = (uint32_t)c[dd];
                 c[2 * dd + 1] = base + (int32_t)((w >> 16) & 0x7FFFu);
                 c[2 * dd] = base + (int32_t)(w & 0x7FFFu);
+            }
+        }
+        if constexpr (C31) {
+#pragma unroll
+            for (int i = 0; i < SIGMA; i++) { // element i's flag -> bit 31 - i (the descriptor's order), then the bare column
+                flags16 |= ((uint32_t)c[i] >> 31) << (31 - i);
+                c[i] &= 0x7FFFFFFF;
             }
         }
         VT xv[NREG];
@@ -310,12 +320,12 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
     uint32_t flags = w0 << bit_all; // element i -> bit 31-i
     if (num_packet > 1)
         flags |= w1 >> (32 - bit_all);
-    if constexpr (C16)
+    if constexpr (C16 || C31)
         flags = flags16;
     int y_off = (int)(w0 >> (32 - bit_y));
     const bool f0 = (flags >> 31) | (lane == 0);
     const bool present = f0 | ((flags & 0x7FFFFFFFu) != 0);
-    if constexpr (C16) {
+    if constexpr (C16 || C31) {
         // y_offset of the reference's descriptor (format_cuda.h:161-267) from the flags: segments that start in the lane,
         // exclusive wave prefix, minus one for lanes > 0 (as k_spmv_range does; equal to the stored field on every lane that
         // owns a flag)
@@ -485,14 +495,15 @@ tile_body(const Geometry &g, const int t, const int lane, const int32_t *__restr
 }
 
 // One tile per wavefront, WAVES_PER_BLOCK tiles per workgroup; the CSR tail = extra workgroups of the same grid.
-template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false, bool C16 = false>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false, bool C16 = false, bool C31 = false>
 __global__ void __launch_bounds__(BLOCK)
 k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
        const VT *__restrict__ val, const VT *__restrict__ x, const uint32_t *__restrict__ tile_ptr,
        const uint32_t *__restrict__ tile_desc, const int32_t *__restrict__ offset_ptr,
        const int32_t *__restrict__ offset, VT *__restrict__ calibrator, VT *__restrict__ y,
        int tile_blocks, int xcd_remap, VT *acc, uint32_t *cnt, const uint4 *__restrict__ meta,
-       const uint32_t *__restrict__ hdr, const uint32_t *__restrict__ col16, const int32_t *__restrict__ base16)
+       const uint32_t *__restrict__ hdr, const uint32_t *__restrict__ col16, const int32_t *__restrict__ base16,
+       const uint32_t *__restrict__ col31)
 {
     // Pull EVERY kernel argument into SGPRs with the first batch of scalar loads: an argument that is
     // first touched further down would otherwise cost its own kernarg round trip on the critical path.
@@ -527,9 +538,9 @@ k_spmv(Geometry g, const int32_t *__restrict__ row_ptr, const int32_t *__restric
     if (t >= g.p - 1)
         return;
     TILE_STAMP(0, false);
-    tile_body<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, C16>(
+    tile_body<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, C16, C31>(
         g, t, lane, col, val, x, tile_ptr, tile_desc, offset_ptr, offset, calibrator, y, acc, cnt, meta, hdr,
-        smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>(), col16, base16);
+        smem + (threadIdx.x >> 6) * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>(), col16, base16, col31);
     TILE_STAMP(2, false);
 }
 
@@ -603,7 +614,7 @@ k_calibrate(Geometry g, const uint32_t *__restrict__ tile_ptr, const uint4 *__re
 }
 
 // ---- dispatch ------------------------------------------------------------------------------------
-template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false, bool C16 = false>
+template <typename VT, int SIGMA, bool FUSED, bool XWIN, bool LDSY_REQ, bool NT = false, bool C16 = false, bool C31 = false>
 static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const void *x, void *y,
                              const SpmvOptions &opt, hipStream_t s)
 {
@@ -615,11 +626,11 @@ static hipError_t launch_one(const Geometry &g, const DeviceArrays &d, const voi
     size_t lds = (size_t)g.tile_elems * sizeof(VT); // tail product buffer (tail workgroups)
     if (lds < (size_t)WAVES_PER_BLOCK * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>())
         lds = (size_t)WAVES_PER_BLOCK * wave_lds_bytes<VT, SIGMA, XWIN, LDSY_REQ>();
-    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, C16>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), lds, s,
+    hipLaunchKernelGGL((k_spmv<VT, SIGMA, FUSED, XWIN, LDSY_REQ, NT, C16, C31>), dim3(tile_blocks + tail_blocks), dim3(BLOCK), lds, s,
                        g, d.row_ptr, d.col, (const VT *)d.val, (const VT *)x, d.tile_ptr,
                        d.tile_desc, d.offset_ptr, d.offset, (VT *)d.calibrator, (VT *)y, tile_blocks,
                        opt.xcd_remap, (VT *)d.carry_acc, d.carry_cnt,
-                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr, d.col16, d.base16);
+                       reinterpret_cast<const uint4 *>(d.carry_meta), d.tile_hdr, d.col16, d.base16, d.col31);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || (FUSED && !opt.long_runs))
         return e;
@@ -646,6 +657,15 @@ static hipError_t launch_sigma(const Geometry &g, const DeviceArrays &d, const v
             if (opt.x_window)                                                                      \
                 return opt.lds_y ? launch_one<VT, S, FUSED, true, true>(g, d, x, y, opt, s)        \
                                  : launch_one<VT, S, FUSED, true, false>(g, d, x, y, opt, s);      \
+            if constexpr (col31_sigma(S)) {                                                        \
+                if (opt.col31 && d.col31) {                                                        \
+                    if (opt.stream_nt)                                                             \
+                        return opt.lds_y ? launch_one<VT, S, FUSED, false, true, true, false, true>(g, d, x, y, opt, s)   \
+                                         : launch_one<VT, S, FUSED, false, false, true, false, true>(g, d, x, y, opt, s); \
+                    return opt.lds_y ? launch_one<VT, S, FUSED, false, true, false, false, true>(g, d, x, y, opt, s)      \
+                                     : launch_one<VT, S, FUSED, false, false, false, false, true>(g, d, x, y, opt, s);    \
+                }                                                                                  \
+            }                                                                                      \
             if (opt.stream_nt)                                                                     \
                 return opt.lds_y ? launch_one<VT, S, FUSED, false, true, true>(g, d, x, y, opt, s) \
                                  : launch_one<VT, S, FUSED, false, false, true>(g, d, x, y, opt, s); \

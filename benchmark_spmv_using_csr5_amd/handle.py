@@ -165,6 +165,11 @@ class anonymouslibHandle:
         atomics): 0 = off, 1 = auto (default), 2 = force; set before asCSR5 (csr5hip.h CSR5HIP_OPT_DEFER_CARRIES)"""
         return self.setOption(_capi.OPT_DEFER_CARRIES, int(value))
 
+    def setFlaggedColumns(self, value: int) -> int:
+        """plain kernel at sigma 4..8: stream column words that carry the row-start flag in bit 31 (no descriptor load): 1 = auto
+        (default: matrices whose streams exceed the Infinity Cache), 0 = off, 2 = force (csr5hip.h CSR5HIP_OPT_FLAGGED_COLUMNS)"""
+        return self.setOption(_capi.OPT_FLAGGED_COLUMNS, int(value))
+
     def setNarrowColumns(self, value: int) -> int:
         """x-window kernel: 1 = auto (default) stream 16-bit column codes (15 bits of column + the row-start flag) when every tile spans < 32 768 columns, 0 = off
         (csr5hip.h CSR5HIP_OPT_NARROW_COLUMNS)"""

@@ -129,6 +129,13 @@ typedef enum { CSR5HIP_F64 = 0, CSR5HIP_F32 = 1 } csr5hip_value_type;
                                       one call.  1 = auto (default: by tiles, sigma and average row length), 0 = off, 2 = force.
                                       Takes effect at asCSR5(): set it while the matrix is in CSR form.
                                       csr5hip_info.carries_deferred says what happened. */
+#define CSR5HIP_OPT_FLAGGED_COLUMNS 18 /* plain fused kernel at sigma 4 .. 8 (short rows: the auto rule's sigma): the kernel streams a private
+                                      copy of the tile-ordered column_index that carries the element's row-start flag in bit 31 instead
+                                      of column_index + the descriptor words: 256 bytes and one load instruction less per tile, the same
+                                      gathers, bit-identical results; the four reference arrays and column_index stay as they are.
+                                      +4 bytes per non-zero of device memory.  1 = auto (default: when the column / value streams exceed
+                                      the 256-MiB Infinity Cache -- the saving is bytes, not latency: -2.2 % there, +1..5 % on cache-sized
+                                      matrices), 0 = off, 2 = force.  csr5hip_info.flagged_columns says what happened. */
 /* (option number 17, CSR5HIP_OPT_CARRY_FINISH of round 6 -- the deferred carries added by trailing workgroups of the tile kernel's own
    launch instead of a second launch -- was parity-green and bit-identical but 2 us SLOWER on nd24k-like (the parties' stores must be
    written through to be seen inside the launch) and was taken out again: scripts/experiments/round6/carry_finish_in_launch/) */
@@ -174,6 +181,7 @@ typedef struct csr5hip_info {
     int slab_values_narrowed;      /* 1 = CSR5HIP_OPT_NARROW_VALUES took effect: the slab kernel streams fp32 values       */
     int carries_deferred;          /* 1 = cut rows are finished by a second small launch (CSR5HIP_OPT_DEFER_CARRIES)             */
     int narrow_columns;            /* 1 = the x-window kernel streams 16-bit column codes (CSR5HIP_OPT_NARROW_COLUMNS)            */
+    int flagged_columns;           /* 1 = the plain kernel streams column words with the row-start flag in bit 31 (CSR5HIP_OPT_FLAGGED_COLUMNS) */
 } csr5hip_info;
 
 /* anonymouslibHandle(m, n) -- anonymouslib_cuda.h:15.  Uses the current HIP device. */

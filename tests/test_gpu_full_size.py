@@ -160,3 +160,18 @@ def test_rmat24_eight_row_blocks_at_size(oracle):
             for r in recs:
                 f.write(json.dumps(r) + "\n")
             f.write(f"# slowest block {slow} us; cost imbalance max/mean {cost.max() / cost.mean():.3f}\n")
+
+
+def test_short_rows_beyond_the_infinity_cache_take_the_flagged_column_words(oracle):
+    """CSR5HIP_OPT_FLAGGED_COLUMNS at the size its auto rule is for: 4 M rows x 6 per row (24 M non-zeros, 288 MB of streams --
+    beyond the 256-MiB Infinity Cache), local columns -> plain kernel, sigma 6, deferred carries, column words with the row-start
+    flag in bit 31 (no descriptor load).  Default options; exact against the oracle's CSR product on the CLI's integer data."""
+    m = 4_000_000
+    mat = M.csr_from_row_lengths(np.full(m, 6), m, np.random.default_rng(17), band=0.9, name="short-rows-24M")
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=18, mode="int")
+    rp, ci = torch.from_numpy(mat.row_ptr).to(DEV), torch.from_numpy(mat.col).to(DEV)
+    va, xd = torch.from_numpy(val).to(DEV), torch.from_numpy(x).to(DEV)
+    y, info = _hip_default(mat.m, mat.n, mat.nnz, rp, ci, va, xd, "float64")
+    assert info.sigma == 6 and info.column_slabs == 0 and info.x_window_active == 0 and info.flagged_columns == 1, \
+        (info.sigma, info.column_slabs, info.x_window_active, info.flagged_columns)
+    assert np.array_equal(y, oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x))

@@ -30,7 +30,7 @@ def _device_csr(mat, val, dtype):
 
 def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin=None, ldsy=None, nt=None,
          slabs=None, slab_shift=None, zero_empty=None, info_out=None, hot=None, x_snapshot=None, narrow=None,
-         narrow_cols=None, defer=None, x_misaligned=False):
+         narrow_cols=None, defer=None, x_misaligned=False, flagged=None):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     rp, ci, va = _device_csr(mat, val, dtype)
     xd = torch.from_numpy(x.astype(dtype)).to(DEV)
@@ -65,6 +65,8 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         assert A.setNarrowColumns(narrow_cols) == 0
     if defer is not None:
         assert A.setDeferCarries(defer) == 0
+    if flagged is not None:
+        assert A.setFlaggedColumns(flagged) == 0
     assert A.spmv(1.0, yd) == H.ANONYMOUSLIB_UNSUPPORTED_CSR_SPMV  # still CSR (anonymouslib_cuda.h:268-271)
     assert A.asCSR5() == 0, _capi.last_error()
     arrays = A.csr5_arrays()
@@ -73,7 +75,8 @@ def _run(mat, val, x, sigma, mode, dtype=np.float64, y0=Y_POISON, repeat=1, xwin
         info_out.update(column_slabs=i.column_slabs, slab_segments=i.slab_segments, slab_sigma=i.slab_sigma,
                         slab_tiles=i.slab_tiles, sigma=i.sigma, slab_hot=i.slab_hot,
                         slab_hot_cover_pct=i.slab_hot_cover_pct, p=i.p, x_window_active=i.x_window_active,
-                        narrow_columns=i.narrow_columns, carries_deferred=i.carries_deferred)
+                        narrow_columns=i.narrow_columns, carries_deferred=i.carries_deferred,
+                        flagged_columns=i.flagged_columns)
     col_t = ci.cpu().numpy().copy()
     val_t = va.cpu().numpy().copy()
     ys = []
@@ -528,9 +531,11 @@ def test_seeded_fuzz_against_oracle(oracle):
             rng.choice([0, 1, 2, 3, 7, 40])
         # cut rows finished by the second launch instead of the arrival protocol (forced) on every other fused case
         defer = (0, 2)[(case // 2) % 2] if mode == H.SPMV_FUSED else None
+        # sigma 4 .. 8, plain fused kernel: the flagged column words (auto = off at this size) forced on two cases of three
+        flagged = 2 if case % 3 != 1 else None
         fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
         arrays, col_t, val_t, ys = _run(mat, val, x, sigma, mode, dtype=dtype, xwin=xwin, ldsy=ldsy, nt=nt, repeat=2,
-                                        slabs=slabs, hot=hot, x_snapshot=snap, narrow=narrow, defer=defer)
+                                        slabs=slabs, hot=hot, x_snapshot=snap, narrow=narrow, defer=defer, flagged=flagged)
         _check_format(arrays, col_t, val_t, fmt)
         exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
         for y in ys:
@@ -970,6 +975,73 @@ def test_deferred_carries(oracle):
         nonempty = np.diff(mat.row_ptr) > 0
         ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val.astype(np.float64), x.astype(np.float64))
         assert np.array_equal(ys[0].astype(np.float64)[nonempty], ref[nonempty]), mat.name
+
+
+@pytest.mark.gpu
+def test_flagged_column_words(oracle):
+    """CSR5HIP_OPT_FLAGGED_COLUMNS: at sigma 4 .. 8 the plain fused kernel streams a kernel-side copy of the tile-ordered
+    column_index with the element's row-start flag in bit 31 and loads no descriptor word (y_offset recomputed from the flags).
+    Same gathers, same arithmetic: bit-identical to the column_index + tile_desc kernel on real data, exact against the oracle
+    on integer data; the zoo (empty rows, hub rows, one-row tiles, ragged tails), every kernel family it has (LDS y, NT streams,
+    deferred carries); the exposed format arrays -- column_index among them -- stay bit-exact; other sigmas, the x-window kernel
+    and the two-pass mode keep the descriptor words."""
+    mats = zoo.small_zoo() + [M.scircuit_like(scale=0.2), M.webbase_like(scale=0.05)]
+    for mat in mats:
+        for sigma, dtype, kw in ((4, np.float64, {}), (6, np.float64, dict(ldsy=2)), (6, np.float64, dict(ldsy=0, defer=2)),
+                                 (8, np.float64, dict(nt=2)), (5, np.float32, {}), (8, np.float32, dict(ldsy=2, nt=2)),
+                                 (7, np.float32, dict(defer=2))):
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=81, mode="int")
+            if dtype == np.float32:
+                val, x = (val % 3).astype(np.float32), (x % 3).astype(np.float32)
+            fmt = oracle.convert(64, sigma, mat.m, mat.row_ptr, mat.col, val)
+            info = {}
+            arrays, col_t, val_t, ys = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, xwin=0, repeat=2, info_out=info,
+                                            flagged=2, **kw)
+            _check_format(arrays, col_t, val_t, fmt)  # (column_index is only read: still the reference's transposed array)
+            assert info["flagged_columns"] == (1 if fmt.p > 1 else 0), (mat.name, sigma, info)
+            exp = _expected_y(oracle, fmt, mat, x, Y_POISON)
+            assert np.array_equal(ys[0], exp) and np.array_equal(ys[1], exp), (mat.name, sigma, np.dtype(dtype).name, kw)
+            val, x = M.fill_values(mat.nnz, mat.n, dtype, seed=82, mode="real")
+            _, _, _, yf = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, xwin=0, repeat=2, flagged=2, **kw)
+            info = {}
+            _, _, _, yd = _run(mat, val, x, sigma, H.SPMV_FUSED, dtype=dtype, slabs=0, xwin=0, flagged=0, info_out=info, **kw)
+            assert info["flagged_columns"] == 0
+            assert np.array_equal(yf[0], yd[0]) and np.array_equal(yf[0], yf[1]), (mat.name, sigma, "bit-identical")
+    mat = M.scircuit_like(scale=0.2)
+    val, x = M.fill_values(mat.nnz, mat.n, np.float64, seed=83, mode="int")
+    for sigma, mode, kw, expect in ((12, H.SPMV_FUSED, dict(xwin=0, flagged=2), 0), (6, H.SPMV_TWO_PASS, dict(flagged=2), 0),
+                                    (6, H.SPMV_FUSED, dict(xwin=2, flagged=2), 0),
+                                    (H.ANONYMOUSLIB_AUTO_TUNED_SIGMA, H.SPMV_FUSED, dict(flagged=2), 1),  # (auto sigma of 5.6 per row: 6)
+                                    (6, H.SPMV_FUSED, {}, 0)):  # auto: a 2-MB matrix is latency-bound, the saving is bytes -> off
+        info = {}
+        _, _, _, ys = _run(mat, val, x, sigma, mode, slabs=0, info_out=info, **kw)
+        assert info["flagged_columns"] == expect, (sigma, mode, kw, info)
+        assert np.array_equal(ys[0], _expected_y(oracle, oracle.convert(64, info["sigma"], mat.m, mat.row_ptr, mat.col, val), mat, x, Y_POISON))
+    # switched on a converted handle, and across asCSR / asCSR5
+    rp, ci, va = _device_csr(mat, val, np.float64)
+    xd = torch.from_numpy(x).to(DEV)
+    yd = torch.full((mat.m,), Y_POISON, dtype=torch.float64, device=DEV)
+    ref = oracle.csr_spmv(mat.m, mat.row_ptr, mat.col, val, x)
+    A = H.anonymouslibHandle(mat.m, mat.n)
+    assert A.inputCSR(mat.nnz, rp, ci, va) == 0 and A.setX(xd) == 0 and A.setSigma(6) == 0 and A.setFlaggedColumns(0) == 0
+    assert A.asCSR5() == 0 and A.info().flagged_columns == 0
+    for on in (2, 0, 2):
+        assert A.setFlaggedColumns(on) == 0 and A.info().flagged_columns == on // 2
+        yd.fill_(Y_POISON)
+        assert A.spmv(1.0, yd) == 0 and A.spmv_repeat(1.0, yd, 2) == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(yd.cpu().numpy(), ref), on
+    assert A.asCSR() == 0 and A.setSigma(8) == 0 and A.asCSR5() == 0 and A.info().flagged_columns == 1
+    assert A.spmv(1.0, yd) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), ref)
+    assert A.setSpmvMode(H.SPMV_TWO_PASS) == 0 and A.info().flagged_columns == 0 and A.spmv(1.0, yd) == 0
+    assert A.setSpmvMode(H.SPMV_FUSED) == 0 and A.info().flagged_columns == 1 and A.spmv(1.0, yd) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), ref)
+    assert A.destroy() == 0
+    assert np.array_equal(ci.cpu().numpy(), mat.col), "the caller's column_index comes back untouched"
+    A.close()
 
 
 @pytest.mark.gpu
