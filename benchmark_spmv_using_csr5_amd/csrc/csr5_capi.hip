@@ -312,7 +312,7 @@ int csr5hip_set_x(csr5hip_handle h, const void *d_x)
 
 // gfx950 tables in the shape of the reference's (r, s, t, u) rule (anonymouslib_cuda.h:297-313, one table per
 // architecture and precision there too): k = nnz/m; sigma = r if k <= r; k if k <= s; s if k <= t; else u.
-// fp64: (6, 16, 256, 16); fp32: (8, 16, 256, 24) -- from sweeps of all sigma over mean row lengths 2..512, random and
+// fp64: (6, 16, 256, 16); fp32: (8, 16, 256, 16) -- from sweeps of all sigma over mean row lengths 2..512, random and
 // near-diagonal columns (scripts/experiments/sigma_table.py; profiles/r01_sigma_table.txt, re-run on the round-4 kernels in
 // profiles/r04_sigma_table.txt): the sigma surface is flat on gfx950 and the rules stay within a few per cent of the measured
 // best everywhere.  r = 6 instead of the reference's 4 costs random-column fp64 matrices < 1 % and gains 4-8 % where the

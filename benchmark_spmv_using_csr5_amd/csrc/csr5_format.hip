@@ -606,7 +606,7 @@ __global__ void __launch_bounds__(1024) k_stats_export(Geometry g, const uint32_
 // (fp32: 6 instead of 8.25 bytes per non-zero in all).  One wavefront per
 // tile t < p-1: minimum and maximum of the tile's column words, the codes of a lane's elements (2 dd, 2 dd + 1) in its word dd
 // (element i of lane l = position i * 64 + l of the tile-ordered column_index, so a code pairs with the value there whether or
-// not the tile was transposed), a lane's words in 16-byte pieces, base16[t]; a tile that spans 65 536 columns or more counts
+// not the tile was transposed), a lane's words in 16-byte pieces, base16[t]; a tile that spans 32 768 columns or more counts
 // into *wide_tiles -- the codes are used only when that stays 0.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(FMT_BLOCK) k_col16(Geometry g, const int32_t *__restrict__ col,

@@ -3,7 +3,7 @@
 # WRITE_SIZE, TCC hit/miss; counters only), parsed ON THE BOX into small files under gpurun_out/profiles_$ROUND/
 # (the raw rocprofv3 directories are deleted: gpurun copies back at most 64 MiB).
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=$REPO/gpurun_out/profiles_$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
