@@ -944,6 +944,15 @@ def cpu_baseline(prob, y_gpu, budget_s: float, host=None, what=None) -> dict:
         # The reference runs with the ambient OpenMP thread count; on a 2-socket host the full count is far from
         # its best for a small matrix, so give it the best of a few counts (short probe each), then time that one.
         full = ref.avx2_threads()
+        # torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks: at N > 1 the ambient count says nothing about the host.
+        # Rank 0 times the baseline alone (the other ranks wait in a barrier), so the host's cores are its own: start from half
+        # the hardware threads this process may run on, the ambient default of the N = 1 run on the same box.
+        try:
+            allowed = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            allowed = os.cpu_count() or 1
+        if os.environ.get("OMP_NUM_THREADS") == "1" and "WORLD_SIZE" in os.environ and allowed > 2:
+            full = max(full, allowed // 2)
         tried = {}
         counts = sorted({full, max(full // 2, 1), max(full // 4, 1)} | (set() if big else {max(full // 8, 1), 16, 8}))
         for t in counts:

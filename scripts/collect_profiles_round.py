@@ -58,4 +58,8 @@ with open(os.path.join(dst, f"{ROUND}_summary.md"), "w") as f:
             main["avg_ns"] / 1e3, step, roof["launch_us"], b / 1e6, "n/a" if t is None else "%.1f" % (t / 1e6),
             "n/a" if t is None else "%.2f" % (t / b), b / (step * 1e-6) / 8e12 if step else 0,
             "n/a" if not hit else "%.0f %%" % (100 * hit / (hit + miss))))
+tail = os.path.join(dst, f"{ROUND}_summary_tail.md")  # hand-written deltas of the round, kept across re-collections
+if os.path.isfile(tail):
+    with open(os.path.join(dst, f"{ROUND}_summary.md"), "a") as f:
+        f.write(open(tail).read())
 print(open(os.path.join(dst, f"{ROUND}_summary.md")).read())
