@@ -1100,6 +1100,7 @@ static int build_slabs_impl(csr5hip_handle h)
                 const int seen = h->hot_cover_pct;
                 release_slabs(h);
                 h->hot_cover_pct = seen; // (csr5hip_info.slab_hot_cover_pct keeps the estimate that explains the choice)
+                h->t_slab = now_ms() - t0; // (the column sample that decided it: part of the conversion's time)
                 return CSR5HIP_SUCCESS;
             }
             S = S_plain; // the table was the reason for that slab count
