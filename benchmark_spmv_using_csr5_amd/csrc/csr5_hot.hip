@@ -551,12 +551,35 @@ k_range_finish(Geometry g, const int32_t *__restrict__ row_ptr,
                 tail_lead = (part[0] + part[1]) + (part[2] + part[3]);
         }
         if (blockIdx.x == 0)
-            for (int r = g.tail_start + 1 + tid; r < g.m; r += 256) {
-                const int a = (int)((long long)row_ptr[r] - first_tail), b = (int)((long long)row_ptr[r + 1] - first_tail);
+            for (int r0 = g.tail_start + 1; r0 < g.m; r0 += 256) { // (uniform trip count: the wavefront works together below)
+                const int r = r0 + tid;
+                const bool valid = r < g.m;
+                int a = 0, b = 0;
+                if (valid)
+                    a = (int)((long long)row_ptr[r] - first_tail), b = (int)((long long)row_ptr[r + 1] - first_tail);
+                // A tail row longer than 32 elements is summed by its whole wavefront (lane-strided partial sums, fixed-shape
+                // reduction), as csr5_carry.h tail_rows does: ONE thread walking a hub row's few hundred products through
+                // dependent LDS reads was 7 of this kernel's 11.7 us on a row block of hub rows (round 6, timing-only
+                // ablations: profiles/r06_probes.txt section 5).
+                const bool longrow = valid && b - a > 32;
                 VT s1 = 0;
-                for (int k = a; k < b; k++)
-                    s1 += sprod[k];
-                P[r] = s1;
+                if (valid && !longrow)
+                    for (int k = a; k < b; k++)
+                        s1 += sprod[k];
+                unsigned long long todo = __ballot(longrow);
+                while (todo) {
+                    const int src = __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    const int aa = __shfl(a, src, OMEGA), bb = __shfl(b, src, OMEGA);
+                    VT part = 0;
+                    for (int k = aa + lane; k < bb; k += OMEGA)
+                        part += sprod[k];
+                    part = wave_sum(part);
+                    if (lane == src)
+                        s1 = part;
+                }
+                if (valid)
+                    P[r] = s1;
             }
     }
     __syncthreads();
