@@ -123,6 +123,7 @@ struct csr5hip_handle_s {
     unsigned col16_wide = 0;     // tiles that span >= 32 768 columns (the codes are used only when there is none)
     Buffer b_col16;              // codes [(p-1) * T / 2 words], then base16 [p]
     // flagged column words of the plain kernel at sigma 4..8 (csr5_format.hip k_col31)
+    size_t device_total_bytes = 0; // hipMemGetInfo's total, asked once (build_slabs_impl)
     int col31_request = 1;       // CSR5HIP_OPT_FLAGGED_COLUMNS: 0 off, 1 auto (default), 2 force
     bool col31_built = false;
     Buffer b_col31;              // [(p-1) * T words]
@@ -984,8 +985,14 @@ static int build_slabs_impl(csr5hip_handle h)
     // all temporaries of the build in one allocation.  Up to 1/64 of the device memory (4.5 GB of 288) they stay with
     // the handle between conversions: giving 2 GB back and asking for it again cost 120-170 ms per reconversion of
     // R-MAT 24 until the runtime's pool had settled, ten times the 16 ms the conversion itself takes.
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
+    // (the device's total memory, asked once per handle: hipMemGetInfo walks the allocator -- a visible share of the 0.5-ms
+    //  conversion of a 3 M-nnz matrix when it ran in every build)
+    if (!h->device_total_bytes) {
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        h->device_total_bytes = total_b ? total_b : 1;
+    }
+    const size_t total_b = h->device_total_bytes;
     const size_t SLAB_TMP_KEEP = std::max((size_t)64 << 20, total_b / 64);
     size_t scan_bytes = 0, sel_bytes = 0;
     HIP_TRY(slab_scan_tmp_bytes((size_t)S_alloc * g.p, &scan_bytes));
