@@ -46,6 +46,13 @@ def test_hip_against_the_reference_goldens(path):
             well = nonempty & (np.abs(g["y_avx2_real"]) >= 1e-3 * abs_ax)
             assert np.all(err[well] <= 1e-6 * np.abs(g["y_avx2_real"][well])), (sigma, mode)
     if mat.nnz >= 2 * 64 * 4:
+        # the kernel-side column streams (round 6: column words with the row-start flag in bit 31, forced; round 5: narrow codes
+        # with the x-window forced) against the reference's arrays and y directly
+        gold = _golden_format(g, 64, 4)
+        for kw in (dict(flagged=2, xwin=0), dict(flagged=2, xwin=0, defer=2), dict(xwin=2)):
+            arrays, col_t, val_t, ys = _run(mat, g["val_int"], g["x_int"], 4 if "flagged" in kw else 16, H.SPMV_FUSED, slabs=0, **kw)
+            _check_format(arrays, col_t, val_t, gold if "flagged" in kw else _golden_format(g, 64, 16))
+            assert np.array_equal(ys[0][nonempty], g["y_avx2_int"][nonempty]), kw
         # the kernel-side structures (column slabs, forced; hot table where the slab count allows) change nothing exposed
         gold = _golden_format(g, 64, 4)
         arrays, col_t, val_t, ys = _run(mat, g["val_int"], g["x_int"], 4, H.SPMV_FUSED, slabs=8, hot=2)
