@@ -1104,9 +1104,9 @@ static int build_slabs_impl(csr5hip_handle h)
                 // Skewed columns on a matrix too small for the table: the popular part of x stays in every XCD's L2 by itself and
                 // the plain kernel beats slabs without a table at every size measured (28.0 / 51.3 / 102 us against 32.2 / 56.2 /
                 // 110 on webbase-like x 1 / 2 / 4 with power-law columns): no structure at all.
-                const int seen = h->hot_cover_pct;
-                release_slabs(h);
-                h->hot_cover_pct = seen; // (csr5hip_info.slab_hot_cover_pct keeps the estimate that explains the choice)
+                // (nothing is active -- deactivate_slabs above -- and the selection's buffers stay with the handle like every other
+                //  buffer of the structure: freeing and re-allocating them was 0.3 of this path's 0.49 ms per reconversion of a
+                //  3 M-nnz matrix; csr5hip_info.slab_hot_cover_pct keeps the estimate that explains the choice)
                 h->t_slab = now_ms() - t0; // (the column sample that decided it: part of the conversion's time)
                 return CSR5HIP_SUCCESS;
             }
